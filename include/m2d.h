@@ -1,0 +1,116 @@
+/* m2d.h — C-ABI of libm2d_hip.so: the MI355X (gfx950) kernels behind the WGAN-GP hot
+ * path of clementabary/music2dance.
+ *
+ * The reference has no FFI of its own: it is pure Python on stock PyTorch ops. Each entry
+ * point below therefore replaces the stock op that the cited reference line calls, and is
+ * what a maintainer would bind (ctypes stub in INTEGRATION.md) to move that op onto the
+ * hand-written CDNA4 kernels.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (int32 for `lengths`) owned by the caller;
+ *     tensors are dense row-major in the reference's own layouts: activations (B, C, L),
+ *     conv weights (Cout, Cin, k), linear weights (out, in), sequences (B, T, H);
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue on it: no allocation,
+ *     no host synchronisation, safe under hipGraph stream capture;
+ *   - `ws` / `ws_bytes`: scratch sized by the matching *_workspace_bytes() query;
+ *   - return 0 on success, a negative M2D_ERR_* code otherwise (m2d_last_error() gives the
+ *     thread-local message); nothing throws across the boundary;
+ *   - `act`: 0 none, 1 ReLU, 2 LeakyReLU(slope). A `*_mask` argument multiplies an operand
+ *     or the result by (mask > 0 ? 1 : mask_slope) — the derivative of the fused
+ *     activation — which closes the op set under differentiation for the gradient
+ *     penalty's double backward (losses.py:40-44).
+ */
+#ifndef M2D_H
+#define M2D_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M2D_OK 0
+#define M2D_ERR_ARG -1
+#define M2D_ERR_HIP -2
+#define M2D_ERR_WORKSPACE -3
+#define M2D_ERR_RANGE -4
+
+/* ---- runtime ------------------------------------------------------------------------ */
+const char* m2d_last_error(void);
+int m2d_version(void);
+/* HIP-event profiler used by bench.py: per kernel family {ms, launches, flops, bytes}.
+ * Families: 0 gemm engine, 1 batch-norm, 2 gru, 3 pointwise, 4 reductions. */
+int m2d_prof_begin(void);
+int m2d_prof_end(double* out, int n_out /* >= 20 */);
+
+/* ---- conv1d: nn.Conv1d forward and both halves of its backward -------------------------
+ * reference: phase3/archis/default.py:64-70 (DefaultAudioEncoder), :90-97,216 (U-Net),
+ * :117-128 (WaveGAN), :201-204 (TemporalBlock), :298-303 (AudioDiscriminator),
+ * :326-333 (StickDiscriminator); phase2/archis/default.py:31-38,154-157. */
+int m2d_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int L,
+                   int Cout, int ks, int stride, int pad, int act, float slope, const float* residual,
+                   const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream);
+int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int L, int Cout, int ks,
+                        int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
+                        size_t ws_bytes, void* stream);
+int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int L, int Cout,
+                          int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
+                          size_t ws_bytes, void* stream);
+/* which: 0 forward, 1 backward-data, 2 backward-weight */
+size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, int ks, int stride, int pad);
+
+/* ---- dense GEMMs behind nn.Linear and the GRU input projection --------------------------
+ * reference: phase3/archis/default.py:153,161,176-177,256-257,352;
+ * phase1/archis/residual.py:11,19,35,41,54-55.
+ * mode 0: C[M,N] = A[M,K] B[N,K]^T + bias[N]; mode 1: C = A[M,K] B[K,N]; mode 2: C = A[K,M]^T B[K,N] */
+int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float* c, int M, int N, int K,
+             int act, float slope, const float* a_mask, float a_mask_slope, const float* out_mask,
+             float out_mask_slope, void* ws, size_t ws_bytes, void* stream);
+size_t m2d_gemm_workspace_bytes(int mode, int M, int N, int K);
+
+/* ---- BatchNorm1d (train/eval forward, train backward) + per-channel sums -----------------
+ * reference: phase3/archis/default.py:65,68,91,94,118-127,154,179-180,217. */
+size_t m2d_bn_workspace_bytes(int C);
+int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+               float* running_var, float* y, float* save_mean, float* save_invstd, int B, int C, int L,
+               float eps, float momentum, int training, int act, float slope, const float* residual, void* ws,
+               size_t ws_bytes, void* stream);
+int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+               const float* save_invstd, float* dx, float* dgamma, float* dbeta, int B, int C, int L, int act,
+               float slope, void* ws, size_t ws_bytes, void* stream);
+int m2d_channel_sums(const float* x, const float* mask, float slope, float* out, int B, int C, int L, void* ws,
+                     size_t ws_bytes, void* stream);
+
+/* ---- GRU recurrence (one layer, all T steps) ---------------------------------------------
+ * reference: nn.GRU inside NoiseGen, phase3/archis/default.py:349-355,
+ * phase2/archis/default.py:90-96. gi = x W_ih^T + b_ih is an m2d_gemm (mode 0). */
+int m2d_gru_layer_fwd(const float* gi, const float* w_hh_t, const float* b_hh, const int* lengths, float* out,
+                      float* r_s, float* z_s, float* n_s, float* hn_s, int B, int T, int H, void* stream);
+int m2d_gru_layer_bwd(const float* dout, const float* out, const float* r_s, const float* z_s, const float* n_s,
+                      const float* hn_s, const float* w_hh, const int* lengths, float* dgi, float* dgh,
+                      float* dh_buf, int B, int T, int H, void* stream);
+
+/* ---- gradient penalty (losses.py:5-60) ----------------------------------------------------- */
+int m2d_gp_interpolate(const float* real, const float* fake, const float* alpha, float* out, int B, int n,
+                       void* stream);
+int m2d_gp_penalty_fwd(const float* g, float* norms, float* penalty, int B, int n, int lp, void* stream);
+int m2d_gp_penalty_bwd(const float* g, const float* norms, const float* gout, float* dg, int B, int n, int lp,
+                       void* stream);
+
+/* ---- L1 / total-variation losses (phase3/train.py:170,226; losses.py:76-82) ---------------- */
+size_t m2d_reduce_workspace_bytes(void);
+int m2d_l1_mean_fwd(const float* a, const float* b, float* out, size_t n, void* ws, size_t ws_bytes, void* stream);
+int m2d_l1_mean_bwd(const float* a, const float* b, const float* gout, float* da, size_t n, void* stream);
+int m2d_tv_mean_fwd(const float* x, float* out, int B, int C, int T, long sb, long sc, long st, void* ws,
+                    size_t ws_bytes, void* stream);
+int m2d_tv_mean_bwd(const float* x, const float* gout, float* dx, int B, int C, int T, long sb, long sc, long st,
+                    void* stream);
+
+/* ---- U-Net encoder resampling (phase3/archis/default.py:235-245) --------------------------- */
+int m2d_maxpool2_fwd(const float* x, float* y, size_t rows, int L, void* stream);
+int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, int L, void* stream);
+int m2d_upsample2_fwd(const float* x, float* y, size_t rows, int L, void* stream);
+int m2d_upsample2_bwd(const float* dy, float* dx, size_t rows, int L, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M2D_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libm2d_hip.so (include/m2d.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback. If it has not been
+built, `lib()` raises; if a tensor handed to a kernel wrapper is not a contiguous fp32
+tensor on a HIP device, the wrapper raises.
+"""
+import ctypes
+import os
+
+_c = ctypes
+_F = _c.c_void_p   # const float* / float*  (device pointers travel as integers)
+_I = _c.c_int
+_S = _c.c_size_t
+_f = _c.c_float
+_L = _c.c_long
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libm2d_hip.so")
+
+# name -> (restype, argtypes); mirrors include/m2d.h line by line
+SIGNATURES = {
+    "m2d_last_error": (_c.c_char_p, []),
+    "m2d_version": (_I, []),
+    "m2d_prof_begin": (_I, []),
+    "m2d_prof_end": (_I, [_c.POINTER(_c.c_double), _I]),
+    "m2d_conv1d_fwd": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _I, _f, _F, _F, _f, _F, _S, _F]),
+    "m2d_conv1d_bwd_data": (_I, [_F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _S, _F]),
+    "m2d_conv1d_bwd_weight": (_I, [_F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _S, _F]),
+    "m2d_conv1d_workspace_bytes": (_S, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "m2d_gemm": (_I, [_I, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _f, _F, _f, _F, _S, _F]),
+    "m2d_gemm_workspace_bytes": (_S, [_I, _I, _I, _I]),
+    "m2d_bn_workspace_bytes": (_S, [_I]),
+    "m2d_bn_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _I, _f, _F, _F, _S, _F]),
+    "m2d_bn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F]),
+    "m2d_channel_sums": (_I, [_F, _F, _f, _F, _I, _I, _I, _F, _S, _F]),
+    "m2d_gru_layer_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
+    "m2d_gru_layer_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
+    "m2d_gp_interpolate": (_I, [_F, _F, _F, _F, _I, _I, _F]),
+    "m2d_gp_penalty_fwd": (_I, [_F, _F, _F, _I, _I, _I, _F]),
+    "m2d_gp_penalty_bwd": (_I, [_F, _F, _F, _F, _I, _I, _I, _F]),
+    "m2d_reduce_workspace_bytes": (_S, []),
+    "m2d_l1_mean_fwd": (_I, [_F, _F, _F, _S, _F, _S, _F]),
+    "m2d_l1_mean_bwd": (_I, [_F, _F, _F, _F, _S, _F]),
+    "m2d_tv_mean_fwd": (_I, [_F, _F, _I, _I, _I, _L, _L, _L, _F, _S, _F]),
+    "m2d_tv_mean_bwd": (_I, [_F, _F, _F, _I, _I, _I, _L, _L, _L, _F]),
+    "m2d_maxpool2_fwd": (_I, [_F, _F, _S, _I, _F]),
+    "m2d_maxpool2_bwd": (_I, [_F, _F, _F, _S, _I, _F]),
+    "m2d_upsample2_fwd": (_I, [_F, _F, _S, _I, _F]),
+    "m2d_upsample2_bwd": (_I, [_F, _F, _S, _I, _F]),
+}
+
+_lib = None
+
+
+class M2dError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly when the .so is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise M2dError(
+            "libm2d_hip.so is not built (%s). Run `python -m music2dance_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    h = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(h, name)  # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = h
+    return _lib
+
+
+def install_backend(handle):
+    """Test hook: replace the library handle (tests/fake_backend.py). Never used by the product."""
+    global _lib
+    prev = _lib
+    _lib = handle
+    return prev
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().m2d_last_error()
+        raise M2dError("%s failed (%d): %s" % (what, rc, msg.decode() if isinstance(msg, bytes) else msg))

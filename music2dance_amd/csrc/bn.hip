@@ -1,0 +1,380 @@
+// BatchNorm1d (training and eval forward, training backward) on (B, C, L) / (B, C) fp32
+// tensors, plus the per-channel sum used for conv / linear bias gradients.
+//
+// Reference semantics: nn.BatchNorm1d(eps=1e-5, momentum=0.1) exactly as
+// phase3/archis/default.py:65,68,118-127,154,179-180,217 uses it:
+//   train: y = gamma * (x - mean_b) / sqrt(var_biased + eps) + beta,
+//          running_mean <- (1-m) rm + m mean_b, running_var <- (1-m) rv + m var_unbiased
+//   eval : the same with the running statistics.
+// These kernels are HBM-bound: the statistics pass reads x once (coalesced along the
+// contiguous (c,l) run of every sample row, whatever L is), the apply pass reads x once
+// and writes y once with the activation (ReLU / LeakyReLU) and an optional residual add
+// fused. Partial sums are combined in fp64 so the result does not depend on the grid.
+#include "m2d_common.h"
+
+__device__ __forceinline__ void bn_divmod(int n, int d, float inv, int& q, int& r) {
+  q = (int)((float)n * inv);
+  r = n - q * d;
+  if (r < 0) {
+    q -= 1;
+    r += d;
+  } else if (r >= d) {
+    q += 1;
+    r -= d;
+  }
+}
+
+// mode 0: (x, x*x)                      forward statistics
+// mode 1: (dz, dz * xhat)               backward reductions, dz = dy * act'(gamma*xhat+beta)
+// mode 2: (x * (mask>0 ? 1 : slope), 0) masked channel sum (bias gradients)
+struct BnReduceArgs {
+  const float* x;
+  const float* dy;     // mode 1
+  const float* mask;   // mode 2 (optional)
+  const float* gamma;  // mode 1
+  const float* beta;   // mode 1
+  const float* mean;   // mode 1
+  const float* invstd; // mode 1
+  double* acc;         // [C][2]
+  int B, C, L;
+  int cpb;             // channels per block
+  int rows_per_block;
+  int mode, act;
+  float slope;
+};
+
+__global__ void __launch_bounds__(256) m2d_bn_reduce_kernel(const BnReduceArgs a) {
+  __shared__ double sh0[256];
+  __shared__ double sh1[256];
+  const int t = threadIdx.x;
+  const int c0 = blockIdx.x * a.cpb;
+  const int nch = (a.C - c0) < a.cpb ? (a.C - c0) : a.cpb;
+  const int P = nch * a.L;  // contiguous positions of this block inside one sample row
+  const int n_begin = blockIdx.y * a.rows_per_block;
+  int n_end = n_begin + a.rows_per_block;
+  if (n_end > a.B) n_end = a.B;
+  const size_t row_stride = (size_t)a.C * a.L;
+  float s0 = 0.f, s1 = 0.f;
+  for (int p = t; p < P; p += 256) {
+    const int c = c0 + (a.cpb > 1 ? p / a.L : 0);
+    float g = 0.f, bt = 0.f, mu = 0.f, is = 0.f;
+    if (a.mode == 1) {
+      g = a.gamma[c];
+      bt = a.beta[c];
+      mu = a.mean[c];
+      is = a.invstd[c];
+    }
+    const size_t base = (size_t)c0 * a.L + p;
+    for (int n = n_begin; n < n_end; ++n) {
+      const size_t idx = (size_t)n * row_stride + base;
+      const float xv = a.x[idx];
+      if (a.mode == 0) {
+        s0 += xv;
+        s1 += xv * xv;
+      } else if (a.mode == 1) {
+        const float xh = (xv - mu) * is;
+        float dz = a.dy[idx];
+        if (a.act) {
+          const float z = g * xh + bt;
+          if (!(z > 0.f)) dz = a.act == 1 ? 0.f : dz * a.slope;
+        }
+        s0 += dz;
+        s1 += dz * xh;
+      } else {
+        float v = xv;
+        if (a.mask) v *= (a.mask[idx] > 0.f ? 1.f : a.slope);
+        s0 += v;
+      }
+    }
+  }
+  sh0[t] = (double)s0;
+  sh1[t] = (double)s1;
+  __syncthreads();
+  if (a.cpb > 1) {
+    // thread j < nch sums the L partials of its channel (L <= 256 / cpb)
+    if (t < nch) {
+      double r0 = 0.0, r1 = 0.0;
+      for (int l = 0; l < a.L; ++l) {
+        r0 += sh0[t * a.L + l];
+        r1 += sh1[t * a.L + l];
+      }
+      atomicAdd(&a.acc[2 * (c0 + t)], r0);
+      if (a.mode != 2) atomicAdd(&a.acc[2 * (c0 + t) + 1], r1);
+    }
+  } else {
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) {
+        sh0[t] += sh0[t + s];
+        sh1[t] += sh1[t + s];
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      atomicAdd(&a.acc[2 * c0], sh0[0]);
+      if (a.mode != 2) atomicAdd(&a.acc[2 * c0 + 1], sh1[0]);
+    }
+  }
+}
+
+static int launch_reduce(BnReduceArgs& a, hipStream_t stream) {
+  a.cpb = a.L >= 256 ? 1 : 256 / a.L;
+  if (a.cpb < 1) a.cpb = 1;
+  if (a.cpb > a.C) a.cpb = a.C;
+  const int groups = m2d_ceil_div(a.C, a.cpb);
+  int nsplit = m2d_ceil_div(1024, groups);
+  if (nsplit > a.B) nsplit = a.B;
+  if (nsplit > 65535) nsplit = 65535;
+  if (nsplit < 1) nsplit = 1;
+  a.rows_per_block = m2d_ceil_div(a.B, nsplit);
+  nsplit = m2d_ceil_div(a.B, a.rows_per_block);
+  if (hipMemsetAsync(a.acc, 0, sizeof(double) * 2 * a.C, stream) != hipSuccess)
+    M2D_FAIL(M2D_ERR_HIP, "bn reduce: memset failed");
+  hipLaunchKernelGGL(m2d_bn_reduce_kernel, dim3(groups, nsplit), dim3(256), 0, stream, a);
+  M2D_CHECK_LAUNCH("m2d_bn_reduce_kernel");
+  return M2D_OK;
+}
+
+// ---- finalize kernels (one thread per channel) ---------------------------------
+__global__ void m2d_bn_finalize_fwd_kernel(const double* acc, float* mean, float* invstd,
+                                           float* running_mean, float* running_var, int C, double count,
+                                           float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = acc[2 * c] / count;
+  double var = acc[2 * c + 1] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+  }
+}
+
+__global__ void m2d_bn_eval_stats_kernel(const float* running_mean, const float* running_var, float* mean,
+                                         float* invstd, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+__global__ void m2d_bn_finalize_bwd_kernel(const double* acc, float* dgamma, float* dbeta, float* s_dz,
+                                           float* s_dzx, int C, double count) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)acc[2 * c];
+  dgamma[c] = (float)acc[2 * c + 1];
+  s_dz[c] = (float)(acc[2 * c] / count);
+  s_dzx[c] = (float)(acc[2 * c + 1] / count);
+}
+
+__global__ void m2d_acc_to_float_kernel(const double* acc, float* out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = (float)acc[2 * c];
+}
+
+// ---- elementwise apply ------------------------------------------------------------
+struct BnApplyArgs {
+  const float* x;
+  const float* dy;        // backward only
+  const float* residual;  // forward only (optional)
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* invstd;
+  const float* s_dz;      // backward: sum(dz)/count
+  const float* s_dzx;     // backward: sum(dz*xhat)/count
+  float* out;
+  int C, L;
+  float L_inv;
+  int row_len;            // C*L
+  int backward, act;
+  float slope;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, size_t total_vec) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total_vec; v += (size_t)gridDim.x * 256) {
+    const size_t idx = v * VEC;
+    const int p = (int)(idx % (size_t)a.row_len);
+    float xv[VEC], dv[VEC], rv[VEC], ov[VEC];
+    if constexpr (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(a.x + idx);
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+      if (a.backward) {
+        const float4 d = *reinterpret_cast<const float4*>(a.dy + idx);
+        dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+      }
+      if (a.residual) {
+        const float4 r = *reinterpret_cast<const float4*>(a.residual + idx);
+        rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
+      }
+    } else {
+      xv[0] = a.x[idx];
+      if (a.backward) dv[0] = a.dy[idx];
+      if (a.residual) rv[0] = a.residual[idx];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      int c, l;
+      if (a.L == 1) c = p + j;
+      else bn_divmod(p + j, a.L, a.L_inv, c, l);
+      const float g = a.gamma[c], bt = a.beta[c], mu = a.mean[c], is = a.invstd[c];
+      const float xh = (xv[j] - mu) * is;
+      const float z = g * xh + bt;
+      if (!a.backward) {
+        float y = z;
+        if (a.act == 1) y = z > 0.f ? z : 0.f;
+        else if (a.act == 2) y = z > 0.f ? z : z * a.slope;
+        if (a.residual) y += rv[j];
+        ov[j] = y;
+      } else {
+        float dz = dv[j];
+        if (a.act && !(z > 0.f)) dz = a.act == 1 ? 0.f : dz * a.slope;
+        ov[j] = g * is * (dz - a.s_dz[c] - xh * a.s_dzx[c]);
+      }
+    }
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(a.out + idx) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    } else {
+      a.out[idx] = ov[0];
+    }
+  }
+}
+
+static int launch_apply(BnApplyArgs& a, int B, hipStream_t stream) {
+  const size_t total = (size_t)B * a.row_len;
+  const bool vec4 = (a.row_len % 4 == 0) && (a.L == 1 || a.L % 4 == 0);
+  const size_t total_vec = vec4 ? total / 4 : total;
+  size_t blocks = (total_vec + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (vec4) hipLaunchKernelGGL(m2d_bn_apply_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a, total_vec);
+  else hipLaunchKernelGGL(m2d_bn_apply_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, total_vec);
+  M2D_CHECK_LAUNCH("m2d_bn_apply_kernel");
+  return M2D_OK;
+}
+
+extern "C" {
+
+// bytes of scratch every bn / channel-sum call needs (fp64 accumulators + 2 float rows)
+size_t m2d_bn_workspace_bytes(int C) { return (size_t)C * (2 * sizeof(double) + 2 * sizeof(float)) + 64; }
+
+// Training / eval forward of nn.BatchNorm1d fused with ReLU (act=1) / LeakyReLU (act=2)
+// and an optional residual add: y = residual + act(bn(x)).
+// training != 0: batch statistics, running stats updated in place (may be NULL),
+//                save_mean / save_invstd (C floats each) written for the backward.
+// training == 0: running statistics; save_* still written (mean, 1/sqrt(var+eps)).
+int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+               float* running_var, float* y, float* save_mean, float* save_invstd, int B, int C, int L,
+               float eps, float momentum, int training, int act, float slope, const float* residual,
+               void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd: bad shape");
+  if ((long long)C * L >= 16777216LL) M2D_FAIL(M2D_ERR_RANGE, "m2d_bn_fwd: C*L too large");
+  if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_fwd: workspace too small");
+  const double bytes = 4.0 * B * C * (double)L;
+  if (training) {
+    BnReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.x = x;
+    r.acc = (double*)ws;
+    r.B = B; r.C = C; r.L = L;
+    r.mode = 0;
+    {
+      M2dProfScope prof(M2D_FAM_BN, stream, 0.0, bytes);
+      int rc = launch_reduce(r, stream);
+      if (rc) return rc;
+      hipLaunchKernelGGL(m2d_bn_finalize_fwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
+                         (const double*)ws, save_mean, save_invstd, running_mean, running_var, C,
+                         (double)B * L, eps, momentum);
+      M2D_CHECK_LAUNCH("m2d_bn_finalize_fwd_kernel");
+    }
+  } else {
+    if (!running_mean || !running_var) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd: eval mode needs running stats");
+    hipLaunchKernelGGL(m2d_bn_eval_stats_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
+                       (const float*)running_mean, (const float*)running_var, save_mean, save_invstd, C, eps);
+    M2D_CHECK_LAUNCH("m2d_bn_eval_stats_kernel");
+  }
+  BnApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x;
+  a.residual = residual;
+  a.gamma = gamma; a.beta = beta;
+  a.mean = save_mean; a.invstd = save_invstd;
+  a.out = y;
+  a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
+  a.row_len = C * L;
+  a.act = act; a.slope = slope;
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, (residual ? 3.0 : 2.0) * bytes);
+  return launch_apply(a, B, stream);
+}
+
+// Training-mode backward. dz = dy * act'(bn(x)) is recomputed from x (no y needed):
+//   dgamma = sum(dz * xhat), dbeta = sum(dz),
+//   dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)).
+int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
+               const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+               int B, int C, int L, int act, float slope, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_bwd: bad shape");
+  if ((long long)C * L >= 16777216LL) M2D_FAIL(M2D_ERR_RANGE, "m2d_bn_bwd: C*L too large");
+  if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_bwd: workspace too small");
+  const double bytes = 4.0 * B * C * (double)L;
+  double* acc = (double*)ws;
+  float* s_dz = (float*)(acc + 2 * (size_t)C);
+  float* s_dzx = s_dz + C;
+  BnReduceArgs r;
+  memset(&r, 0, sizeof(r));
+  r.x = x; r.dy = dy;
+  r.gamma = gamma; r.beta = beta; r.mean = save_mean; r.invstd = save_invstd;
+  r.acc = acc;
+  r.B = B; r.C = C; r.L = L;
+  r.mode = 1; r.act = act; r.slope = slope;
+  {
+    M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.0 * bytes);
+    int rc = launch_reduce(r, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(m2d_bn_finalize_bwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
+                       (const double*)acc, dgamma, dbeta, s_dz, s_dzx, C, (double)B * L);
+    M2D_CHECK_LAUNCH("m2d_bn_finalize_bwd_kernel");
+  }
+  BnApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.dy = dy;
+  a.gamma = gamma; a.beta = beta; a.mean = save_mean; a.invstd = save_invstd;
+  a.s_dz = s_dz; a.s_dzx = s_dzx;
+  a.out = dx;
+  a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
+  a.row_len = C * L;
+  a.backward = 1; a.act = act; a.slope = slope;
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 3.0 * bytes);
+  return launch_apply(a, B, stream);
+}
+
+// out[c] = sum_{n,l} x[n,c,l] * (mask ? (mask[n,c,l] > 0 ? 1 : slope) : 1)
+// Bias gradient of conv1d (C = Cout) and of linear layers (L = 1), with the fused
+// activation derivative.
+int m2d_channel_sums(const float* x, const float* mask, float slope, float* out, int B, int C, int L,
+                     void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_channel_sums: bad shape");
+  if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_channel_sums: workspace too small");
+  BnReduceArgs r;
+  memset(&r, 0, sizeof(r));
+  r.x = x; r.mask = mask; r.slope = slope;
+  r.acc = (double*)ws;
+  r.B = B; r.C = C; r.L = L;
+  r.mode = 2;
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, (mask ? 8.0 : 4.0) * B * C * (double)L);
+  int rc = launch_reduce(r, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(m2d_acc_to_float_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
+                     (const double*)ws, out, C);
+  M2D_CHECK_LAUNCH("m2d_acc_to_float_kernel");
+  return M2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,361 @@
+// Implementation of the separable-gather fp32-MFMA GEMM engine (see gemm_engine.h).
+#include "gemm_engine.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void m2d_divmod(int n, int d, float inv, int& q, int& r) {
+  if (d == 1) {
+    q = n;
+    r = 0;
+    return;
+  }
+  q = (int)((float)n * inv);
+  r = n - q * d;
+  if (r < 0) {
+    q -= 1;
+    r += d;
+  } else if (r >= d) {
+    q += 1;
+    r -= d;
+  }
+}
+
+__device__ __forceinline__ float m2d_fetch(const M2dOperand& op, int off) {
+  float x = op.base[off];
+  if (op.mask) x *= (op.mask[off] > 0.f ? 1.f : op.mask_slope);
+  return x;
+}
+
+// Per-thread row bookkeeping for one operand tile of BR rows x M2D_BK k-values.
+//   k-fast map : thread owns ONE k (tid % BK) and NE rows (tid / BK + i * 256 / BK)
+//   row-fast map: thread owns ONE row (tid % BR) and NE k's (tid / BR + i * 256 / BR)
+template <bool KF, int BR>
+struct TileMap {
+  static constexpr int NE = BR * M2D_BK / 256;
+  static constexpr int NR = KF ? NE : 1;
+  int off[NR];
+  int pos[NR];
+  bool rv[NR];
+
+  __device__ __forceinline__ void prep(const M2dOperand& op, int row0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int rl = KF ? (tid / M2D_BK + i * (256 / M2D_BK)) : (tid % BR);
+      const int g = row0 + rl;
+      rv[i] = g < op.nrows;
+      int hi, lo;
+      m2d_divmod(rv[i] ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
+      off[i] = hi * op.r_hi_stride + lo * op.r_lo_stride + op.r_off;
+      pos[i] = lo * op.r_pos_mul + op.r_pos_off;
+    }
+  }
+
+  __device__ __forceinline__ void load(const M2dOperand& op, int k0, int kend, int tid,
+                                       float (&v)[NE]) const {
+    if constexpr (KF) {
+      const int k = k0 + (tid % M2D_BK);
+      const bool kv = k < kend;
+      int hi, lo;
+      m2d_divmod(kv ? k : 0, op.kdiv, op.kdiv_inv, hi, lo);
+      const int koff = hi * op.k_hi_stride + lo * op.k_lo_stride;
+      const int kpos = lo * op.k_pos_mul;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        bool ok = kv && rv[i];
+        if (op.lim > 0) ok = ok && ((unsigned)(pos[i] + kpos) < (unsigned)op.lim);
+        v[i] = ok ? m2d_fetch(op, off[i] + koff) : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int k = k0 + tid / BR + i * (256 / BR);
+        const bool kv = k < kend;
+        int hi, lo;
+        m2d_divmod(kv ? k : 0, op.kdiv, op.kdiv_inv, hi, lo);
+        const int koff = hi * op.k_hi_stride + lo * op.k_lo_stride;
+        const int kpos = lo * op.k_pos_mul;
+        bool ok = kv && rv[0];
+        if (op.lim > 0) ok = ok && ((unsigned)(pos[0] + kpos) < (unsigned)op.lim);
+        v[i] = ok ? m2d_fetch(op, off[0] + koff) : 0.f;
+      }
+    }
+  }
+
+  // LDS image is [k][row] with leading dimension LD (LD % 32 == 2 keeps the k-fast
+  // writes conflict-free; row-fast writes and fragment reads are conflict-free anyway).
+  template <int LD>
+  __device__ __forceinline__ void store(float* s, int tid, const float (&v)[NE]) const {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int kl = KF ? (tid % M2D_BK) : (tid / BR + i * (256 / BR));
+      const int rl = KF ? (tid / M2D_BK + i * (256 / M2D_BK)) : (tid % BR);
+      s[kl * LD + rl] = v[i];
+    }
+  }
+};
+
+__device__ __forceinline__ float m2d_epilogue(const M2dOutMap& o, float v, int row, int col, int addr) {
+  if (o.bias_mode == 1) v += o.bias[row];
+  else if (o.bias_mode == 2) v += o.bias[col];
+  if (o.act == 1) v = v > 0.f ? v : 0.f;
+  else if (o.act == 2) v = v > 0.f ? v : v * o.slope;
+  if (o.residual) v += o.residual[addr];
+  if (o.mask) v *= (o.mask[addr] > 0.f ? 1.f : o.mask_slope);
+  return v;
+}
+
+template <int BM, int BN, bool AKF, bool BKF>
+__global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p) {
+  constexpr int LDA = BM + 2;
+  constexpr int LDB = BN + 2;
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  constexpr int STAGE = M2D_BK * (LDA + LDB);
+  __shared__ float smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM;
+  const int wn = wave / WM;
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+
+  M2dOperand A = p.A;
+  M2dOperand B = p.B;
+  M2dOutMap O = p.O;
+  int K = p.K;
+  int N = p.N;
+  int split = blockIdx.z;
+  if (p.bwd_data) {
+    // conv backward-data: output phase r of the stride-s lattice uses taps r, r+s, ...
+    //   dx[n, ci, s*q + r - pad] = sum_{co, t} W[co, ci, r + s*t] * dy[n, co, q - t]
+    const int r = blockIdx.z;
+    const int s = p.phases;
+    split = 0;
+    const int taps = r < p.ph_ks ? (p.ph_ks - r + s - 1) / s : 0;
+    const int qmin = r >= p.ph_pad ? 0 : (p.ph_pad - r + s - 1) / s;
+    const int top = p.ph_L - 1 + p.ph_pad - r;
+    const int nq = top >= 0 ? (top / s - qmin + 1) : 0;
+    if (nq <= 0) return;
+    N = p.ph_batch * nq;
+    if ((int)(blockIdx.x * BN) >= N) return;
+    K = p.ph_cout * taps;
+    const int d = taps > 0 ? taps : 1;
+    A.r_off += r;
+    A.kdiv = d;
+    A.kdiv_inv = 1.f / (float)d;
+    B.kdiv = d;
+    B.kdiv_inv = A.kdiv_inv;
+    B.nrows = N;
+    B.rdiv = nq;
+    B.rdiv_inv = 1.f / (float)nq;
+    B.r_off = qmin;
+    B.r_pos_off = qmin;
+    O.cdiv = nq;
+    O.cdiv_inv = B.rdiv_inv;
+    O.c_off = s * qmin + r - p.ph_pad;
+    O.c_pos_off = O.c_off;
+  }
+
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+
+  TileMap<AKF, BM> ta;
+  TileMap<BKF, BN> tb;
+  ta.prep(A, m0, tid);
+  tb.prep(B, n0, tid);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = (K + M2D_BK - 1) / M2D_BK;
+  const int cps = (nchunks + p.splits - 1) / p.splits;
+  const int c0 = split * cps;
+  const int c1 = (c0 + cps < nchunks) ? (c0 + cps) : nchunks;
+
+  float va[TileMap<AKF, BM>::NE];
+  float vb[TileMap<BKF, BN>::NE];
+
+  if (c0 < c1) {
+    ta.load(A, c0 * M2D_BK, K, tid, va);
+    tb.load(B, c0 * M2D_BK, K, tid, vb);
+    ta.template store<LDA>(smem, tid, va);
+    tb.template store<LDB>(smem + M2D_BK * LDA, tid, vb);
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+      const int cur = (c - c0) & 1;
+      const bool more = (c + 1) < c1;
+      if (more) {
+        ta.load(A, (c + 1) * M2D_BK, K, tid, va);
+        tb.load(B, (c + 1) * M2D_BK, K, tid, vb);
+      }
+      const float* as = smem + cur * STAGE + wm * (TM * 32) + l31;
+      const float* bs = smem + cur * STAGE + M2D_BK * LDA + wn * (TN * 32) + l31;
+#pragma unroll
+      for (int kk = 0; kk < M2D_BK / 2; ++kk) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + lh) * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + lh) * LDB + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) {
+        float* nxt = smem + (cur ^ 1) * STAGE;
+        ta.template store<LDA>(nxt, tid, va);
+        tb.template store<LDB>(nxt + M2D_BK * LDA, tid, vb);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31,
+  //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+    const bool cv = col < N;
+    int chi, clo;
+    m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
+    const int caddr = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
+    bool cok = cv;
+    if (O.c_lim > 0) cok = cok && ((unsigned)(clo * O.c_pos_mul + O.c_pos_off) < (unsigned)O.c_lim);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.M) {
+          if (p.splits > 1) {
+            if (cv) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + col] = acc[i][j][r];
+          } else if (cok) {
+            const int addr = row * O.m_stride + caddr;
+            O.out[addr] = m2d_epilogue(O, acc[i][j][r], row, col, addr);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue.
+__global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmParams p) {
+  const size_t total = (size_t)p.M * p.N;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int row = (int)(idx / p.N);
+    const int col = (int)(idx - (size_t)row * p.N);
+    float s = 0.f;
+    for (int z = 0; z < p.splits; ++z) s += p.slab[(size_t)z * total + idx];
+    int chi, clo;
+    m2d_divmod(col, p.O.cdiv, p.O.cdiv_inv, chi, clo);
+    bool ok = true;
+    if (p.O.c_lim > 0) ok = (unsigned)(clo * p.O.c_pos_mul + p.O.c_pos_off) < (unsigned)p.O.c_lim;
+    if (ok) {
+      const int addr = row * p.O.m_stride + chi * p.O.c_hi_stride + clo * p.O.c_lo_stride + p.O.c_off;
+      p.O.out[addr] = m2d_epilogue(p.O, s, row, col, addr);
+    }
+  }
+}
+
+M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split) {
+  M2dGemmPlan pl;
+  // pick the M tile that wastes the fewest padded rows; small tiles carry a penalty
+  // because their waves re-read the B tile more often per flop.
+  const int cands[3] = {32, 64, 128};
+  const double pen[3] = {1.4, 1.1, 1.0};
+  double best = 1e30;
+  pl.bm = 128;
+  for (int i = 0; i < 3; ++i) {
+    const double cost = (double)m2d_ceil_div(M, cands[i]) * cands[i] * pen[i];
+    if (cost < best - 1e-9 || (cost <= best + 1e-9 && cands[i] > pl.bm)) {
+      best = cost;
+      pl.bm = cands[i];
+    }
+  }
+  pl.splits = 1;
+  pl.ws_bytes = 0;
+  if (allow_split && phases <= 1) {
+    const long long base = (long long)m2d_ceil_div(M, pl.bm) * m2d_ceil_div(N, 128);
+    const int nchunks = m2d_ceil_div(K, M2D_BK);
+    if (base < 256 && nchunks >= 8) {
+      long long s = m2d_ceil_div64(512, base);
+      if (s > nchunks / 4) s = nchunks / 4;
+      if (s > 128) s = 128;
+      if (s < 1) s = 1;
+      pl.splits = (int)s;
+    }
+  }
+  if (pl.splits > 1) pl.ws_bytes = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
+  return pl;
+}
+
+template <int BM, bool AKF, bool BKF>
+static void launch_tile(const M2dGemmParams& p, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF>), grid, dim3(256), 0, stream, p);
+}
+
+template <int BM>
+static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hipStream_t stream) {
+  if (akf && !bkf) launch_tile<BM, true, false>(p, grid, stream);
+  else if (!akf && !bkf) launch_tile<BM, false, false>(p, grid, stream);
+  else if (akf && bkf) launch_tile<BM, true, true>(p, grid, stream);
+  else launch_tile<BM, false, true>(p, grid, stream);
+  return 0;
+}
+
+int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
+                    size_t ws_bytes, hipStream_t stream, const char* what) {
+  if (p.M <= 0 || p.N <= 0) return M2D_OK;
+  if (p.phases < 1) p.phases = 1;
+  const M2dGemmPlan pl = m2d_gemm_plan(p.M, p.N, p.K, p.bwd_data ? 2 : 1, allow_split);
+  p.splits = pl.splits;
+  p.slab = nullptr;
+  if (pl.splits > 1) {
+    if (ws == nullptr || ws_bytes < pl.ws_bytes)
+      M2D_FAIL(M2D_ERR_WORKSPACE, "%s: split-K needs %zu workspace bytes, got %zu", what, pl.ws_bytes,
+               ws_bytes);
+    p.slab = (float*)ws;
+  }
+  const int mt = m2d_ceil_div(p.M, pl.bm);
+  const long long nt = m2d_ceil_div(p.N, 128);
+  if (mt > 65535) M2D_FAIL(M2D_ERR_RANGE, "%s: M too large (%d)", what, p.M);
+  dim3 grid((unsigned)nt, (unsigned)mt, (unsigned)(p.bwd_data ? p.phases : pl.splits));
+  double flops = 2.0 * p.M * (double)p.N * p.K;
+  if (p.bwd_data) {
+    flops = 0.0;
+    for (int r = 0; r < p.phases; ++r) {
+      const int taps = r < p.ph_ks ? (p.ph_ks - r + p.phases - 1) / p.phases : 0;
+      const int qmin = r >= p.ph_pad ? 0 : (p.ph_pad - r + p.phases - 1) / p.phases;
+      const int top = p.ph_L - 1 + p.ph_pad - r;
+      const int nq = top >= 0 ? (top / p.phases - qmin + 1) : 0;
+      if (nq > 0) flops += 2.0 * p.M * (double)p.ph_batch * nq * p.ph_cout * taps;
+    }
+  }
+  {
+    M2dProfScope prof(M2D_FAM_GEMM, stream, flops, 0.0);
+    if (pl.bm == 32) launch_maps<32>(p, a_kfast, b_kfast, grid, stream);
+    else if (pl.bm == 64) launch_maps<64>(p, a_kfast, b_kfast, grid, stream);
+    else launch_maps<128>(p, a_kfast, b_kfast, grid, stream);
+    M2D_CHECK_LAUNCH(what);
+    if (pl.splits > 1) {
+      const size_t total = (size_t)p.M * p.N;
+      unsigned blocks = (unsigned)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(m2d_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+      M2D_CHECK_LAUNCH(what);
+    }
+  }
+  return M2D_OK;
+}

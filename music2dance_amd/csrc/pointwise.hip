@@ -1,0 +1,373 @@
+// HBM-bound elementwise / reduction kernels of the WGAN-GP step:
+//   * gradient-penalty interpolate and per-sample grad-norm penalty (losses.py:13-25,47-60)
+//   * L1 loss and total-variation loss with their gradients (phase3/train.py:226,
+//     losses.py:76-82)
+//   * MaxPool1d(2,2) and Upsample(x2, linear, align_corners=False) of the U-Net encoder
+//     (phase3/archis/default.py:235-245)
+// Reductions are two-stage and deterministic: per-block fp64 partials, then one block.
+#include "m2d_common.h"
+
+// ---------------------------------------------------------------- block reduce helper
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) sh[t] += sh[t + s];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) m2d_finish_sum_kernel(const double* partial, int n, double scale,
+                                                             float* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) out[0] = (float)(s * scale);
+}
+
+// ---------------------------------------------------------------- GP interpolate
+// out[b,i] = alpha[b] * real[b,i] + (1 - alpha[b]) * fake[b,i], three separately rounded
+// fp32 operations exactly like the reference expression (losses.py:20).
+__global__ void __launch_bounds__(256) m2d_gp_interpolate_kernel(const float* real, const float* fake,
+                                                                 const float* alpha, float* out, int B,
+                                                                 int n) {
+  const int b = blockIdx.y;
+  const float al = alpha[b];
+  const float om = __fsub_rn(1.0f, al);
+  const size_t base = (size_t)b * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float t1 = __fmul_rn(al, real[base + i]);
+    const float t2 = __fmul_rn(om, fake[base + i]);
+    out[base + i] = __fadd_rn(t1, t2);
+  }
+}
+
+// ---------------------------------------------------------------- GP norm penalty
+// norms[b] = sqrt(sum_i g[b,i]^2 + eps)   (eps = 1e-12 for GP, 0 for LP; losses.py:47-54)
+__global__ void __launch_bounds__(256) m2d_gp_norm_kernel(const float* g, float* norms, int n, float eps) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x;
+  const float* row = g + (size_t)b * n;
+  float s = 0.f;
+  double acc = 0.0;
+  int cnt = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = row[i];
+    s += v * v;
+    if (++cnt == 64) {  // flush the fp32 partial regularly: keeps the sum accurate for 76 800 terms
+      acc += (double)s;
+      s = 0.f;
+      cnt = 0;
+    }
+  }
+  acc += (double)s;
+  acc = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) norms[b] = sqrtf((float)acc + eps);
+}
+
+// penalty = mean_b (norm_b - 1)^2            (lp == 0)
+//         = mean_b max(0, norm_b - 1)^2      (lp != 0)
+__global__ void __launch_bounds__(256) m2d_gp_penalty_kernel(const float* norms, int B, int lp, float* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float d = norms[b] - 1.0f;
+    if (lp && d < 0.f) d = 0.f;
+    s += (double)(d * d);
+  }
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) out[0] = (float)(s / (double)B);
+}
+
+// dg[b,i] = gout * 2 (norm_b - 1) / (norm_b * B) * g[b,i]   (LP: 0 where norm_b <= 1)
+__global__ void __launch_bounds__(256) m2d_gp_penalty_bwd_kernel(const float* g, const float* norms,
+                                                                 const float* gout, float* dg, int B, int n,
+                                                                 int lp) {
+  const int b = blockIdx.y;
+  const float nb = norms[b];
+  float d = nb - 1.0f;
+  if (lp && d < 0.f) d = 0.f;
+  const float coef = (d == 0.f) ? 0.f : gout[0] * 2.0f * d / (nb * (float)B);
+  const size_t base = (size_t)b * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dg[base + i] = coef * g[base + i];
+}
+
+// ---------------------------------------------------------------- L1 / TV
+// partial sums of |a[i] - b[i]|
+__global__ void __launch_bounds__(256) m2d_absdiff_partial_kernel(const float* a, const float* b, size_t n,
+                                                                  double* partial) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    s += (double)fabsf(a[i] - b[i]);
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// d/da mean|a - b| = gout * sign(a - b) / n
+__global__ void __launch_bounds__(256) m2d_absdiff_bwd_kernel(const float* a, const float* b, const float* gout,
+                                                              float* da, size_t n) {
+  const float sc = gout[0] / (float)n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    da[i] = d > 0.f ? sc : (d < 0.f ? -sc : 0.f);
+  }
+}
+
+// total variation over the time axis of a (B, C, T) tensor stored with strides
+// (sb, sc, st) in elements: mean over B*C*(T-1) of |x[t+1] - x[t]|.
+__global__ void __launch_bounds__(256) m2d_tv_partial_kernel(const float* x, int B, int C, int T, long sb,
+                                                             long sc, long st, double* partial) {
+  __shared__ double sh[256];
+  const size_t total = (size_t)B * C * (T - 1);
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i % (size_t)(T - 1));
+    const size_t bc = i / (size_t)(T - 1);
+    const int c = (int)(bc % (size_t)C);
+    const int b = (int)(bc / (size_t)C);
+    const float* p = x + b * sb + c * sc + t * st;
+    s += (double)fabsf(p[st] - p[0]);
+  }
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) m2d_tv_bwd_kernel(const float* x, const float* gout, float* dx, int B,
+                                                         int C, int T, long sb, long sc, long st) {
+  const size_t total = (size_t)B * C * T;
+  const float scl = gout[0] / (float)((size_t)B * C * (T - 1));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i % (size_t)T);
+    const size_t bc = i / (size_t)T;
+    const int c = (int)(bc % (size_t)C);
+    const int b = (int)(bc / (size_t)C);
+    const float* p = x + b * sb + c * sc + t * st;
+    float g = 0.f;
+    if (t > 0) {
+      const float d = p[0] - p[-st];
+      g += d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    }
+    if (t + 1 < T) {
+      const float d = p[st] - p[0];
+      g -= d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    }
+    dx[b * sb + c * sc + t * st] = g * scl;
+  }
+}
+
+// ---------------------------------------------------------------- pool / upsample
+// MaxPool1d(2,2): y[r, j] = max(x[r, 2j], x[r, 2j+1]), rows = B*C, Lout = L/2
+__global__ void __launch_bounds__(256) m2d_maxpool2_fwd_kernel(const float* x, float* y, size_t rows, int L,
+                                                               int Lout) {
+  const size_t total = rows * Lout;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / Lout;
+    const int j = (int)(i - r * Lout);
+    const float a = x[r * L + 2 * j], b = x[r * L + 2 * j + 1];
+    y[i] = a > b ? a : b;  // ties take the first element's value (same number either way)
+  }
+}
+
+// gradient goes to the arg-max (first element on ties, like torch); other positions 0
+__global__ void __launch_bounds__(256) m2d_maxpool2_bwd_kernel(const float* x, const float* dy, float* dx,
+                                                               size_t rows, int L, int Lout) {
+  const size_t total = rows * L;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / L;
+    const int p = (int)(i - r * L);
+    const int j = p >> 1;
+    float g = 0.f;
+    if (j < Lout) {
+      const float a = x[r * L + 2 * j], b = x[r * L + 2 * j + 1];
+      const bool first = a >= b || a != a;  // NaN propagates through the first slot
+      if (((p & 1) == 0) == first) g = dy[r * Lout + j];
+    }
+    dx[i] = g;
+  }
+}
+
+// Upsample(scale_factor=2, mode="linear", align_corners=False):
+//   src = max((j + 0.5) / 2 - 0.5, 0); i0 = floor(src); i1 = min(i0 + 1, L - 1); w = src - i0
+__global__ void __launch_bounds__(256) m2d_upsample2_fwd_kernel(const float* x, float* y, size_t rows, int L) {
+  const int Lo = 2 * L;
+  const size_t total = rows * Lo;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / Lo;
+    const int j = (int)(i - r * Lo);
+    float src = ((float)j + 0.5f) * 0.5f - 0.5f;
+    if (src < 0.f) src = 0.f;
+    const int i0 = (int)src;
+    const int i1 = i0 + 1 < L ? i0 + 1 : L - 1;
+    const float w1 = src - (float)i0;
+    const float w0 = 1.0f - w1;
+    y[i] = w0 * x[r * L + i0] + w1 * x[r * L + i1];
+  }
+}
+
+// transpose of the interpolation: dx[i] = sum_j coef(j -> i) dy[j]; each input position
+// receives from at most 4 outputs (2i-1 .. 2i+2), gathered here so there are no atomics.
+__global__ void __launch_bounds__(256) m2d_upsample2_bwd_kernel(const float* dy, float* dx, size_t rows, int L) {
+  const int Lo = 2 * L;
+  const size_t total = rows * L;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / L;
+    const int p = (int)(i - r * L);
+    float g = 0.f;
+    for (int j = 2 * p - 2; j <= 2 * p + 2; ++j) {
+      if (j < 0 || j >= Lo) continue;
+      float src = ((float)j + 0.5f) * 0.5f - 0.5f;
+      if (src < 0.f) src = 0.f;
+      const int i0 = (int)src;
+      const int i1 = i0 + 1 < L ? i0 + 1 : L - 1;
+      const float w1 = src - (float)i0;
+      const float d = dy[r * Lo + j];
+      if (i0 == p) g += (1.0f - w1) * d;
+      if (i1 == p) g += w1 * d;
+    }
+    dx[i] = g;
+  }
+}
+
+static unsigned grid_for(size_t n, unsigned cap = 2048) {
+  size_t b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+extern "C" {
+
+// losses.py:13-20 — interpolation between real and fake with one alpha per sample.
+int m2d_gp_interpolate(const float* real, const float* fake, const float* alpha, float* out, int B, int n,
+                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || n <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_gp_interpolate: bad shape");
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * B * (double)n);
+  unsigned gx = grid_for((size_t)n, 64);
+  hipLaunchKernelGGL(m2d_gp_interpolate_kernel, dim3(gx, B), dim3(256), 0, stream, real, fake, alpha, out, B, n);
+  M2D_CHECK_LAUNCH("m2d_gp_interpolate_kernel");
+  return M2D_OK;
+}
+
+// losses.py:47-60 — per-sample L2 norm of the critic's input gradient and the penalty.
+// norms: B floats (saved for the backward), penalty: 1 float.
+int m2d_gp_penalty_fwd(const float* g, float* norms, float* penalty, int B, int n, int lp, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || n <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_gp_penalty_fwd: bad shape");
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 4.0 * B * (double)n);
+  hipLaunchKernelGGL(m2d_gp_norm_kernel, dim3(B), dim3(256), 0, stream, g, norms, n, lp ? 0.0f : 1e-12f);
+  hipLaunchKernelGGL(m2d_gp_penalty_kernel, dim3(1), dim3(256), 0, stream, (const float*)norms, B, lp, penalty);
+  M2D_CHECK_LAUNCH("m2d_gp_penalty_kernel");
+  return M2D_OK;
+}
+
+int m2d_gp_penalty_bwd(const float* g, const float* norms, const float* gout, float* dg, int B, int n, int lp,
+                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || n <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_gp_penalty_bwd: bad shape");
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 8.0 * B * (double)n);
+  unsigned gx = grid_for((size_t)n, 64);
+  hipLaunchKernelGGL(m2d_gp_penalty_bwd_kernel, dim3(gx, B), dim3(256), 0, stream, g, norms, gout, dg, B, n, lp);
+  M2D_CHECK_LAUNCH("m2d_gp_penalty_bwd_kernel");
+  return M2D_OK;
+}
+
+size_t m2d_reduce_workspace_bytes(void) { return 2048 * sizeof(double); }
+
+// torch.nn.L1Loss(reduction='mean') (phase3/train.py:170,226): out = mean |a - b|
+int m2d_l1_mean_fwd(const float* a, const float* b, float* out, size_t n, void* ws, size_t ws_bytes,
+                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) M2D_FAIL(M2D_ERR_ARG, "m2d_l1_mean_fwd: empty");
+  if (!ws || ws_bytes < m2d_reduce_workspace_bytes()) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_l1_mean_fwd: workspace");
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 8.0 * (double)n);
+  const unsigned gx = grid_for(n);
+  hipLaunchKernelGGL(m2d_absdiff_partial_kernel, dim3(gx), dim3(256), 0, stream, a, b, n, (double*)ws);
+  hipLaunchKernelGGL(m2d_finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, (int)gx,
+                     1.0 / (double)n, out);
+  M2D_CHECK_LAUNCH("m2d_l1_mean_fwd");
+  return M2D_OK;
+}
+
+int m2d_l1_mean_bwd(const float* a, const float* b, const float* gout, float* da, size_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * (double)n);
+  hipLaunchKernelGGL(m2d_absdiff_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, b, gout, da, n);
+  M2D_CHECK_LAUNCH("m2d_l1_mean_bwd");
+  return M2D_OK;
+}
+
+// losses.py:76-82 tv_loss on a (B, C, T) tensor given by element strides.
+int m2d_tv_mean_fwd(const float* x, float* out, int B, int C, int T, long sb, long sc, long st, void* ws,
+                    size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || T < 2) M2D_FAIL(M2D_ERR_ARG, "m2d_tv_mean_fwd: bad shape");
+  if (!ws || ws_bytes < m2d_reduce_workspace_bytes()) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_tv_mean_fwd: workspace");
+  const size_t total = (size_t)B * C * (T - 1);
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 4.0 * (double)total);
+  const unsigned gx = grid_for(total);
+  hipLaunchKernelGGL(m2d_tv_partial_kernel, dim3(gx), dim3(256), 0, stream, x, B, C, T, sb, sc, st, (double*)ws);
+  hipLaunchKernelGGL(m2d_finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, (int)gx,
+                     1.0 / (double)total, out);
+  M2D_CHECK_LAUNCH("m2d_tv_mean_fwd");
+  return M2D_OK;
+}
+
+int m2d_tv_mean_bwd(const float* x, const float* gout, float* dx, int B, int C, int T, long sb, long sc,
+                    long st, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || T < 2) M2D_FAIL(M2D_ERR_ARG, "m2d_tv_mean_bwd: bad shape");
+  const size_t total = (size_t)B * C * T;
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 8.0 * (double)total);
+  hipLaunchKernelGGL(m2d_tv_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, gout, dx, B, C, T, sb, sc, st);
+  M2D_CHECK_LAUNCH("m2d_tv_mean_bwd");
+  return M2D_OK;
+}
+
+// nn.MaxPool1d(2, 2) on (rows = B*C, L) (phase3/archis/default.py:235)
+int m2d_maxpool2_fwd(const float* x, float* y, size_t rows, int L, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Lout = L / 2;
+  if (rows == 0 || Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_maxpool2_fwd: bad shape");
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 6.0 * rows * (double)L);
+  hipLaunchKernelGGL(m2d_maxpool2_fwd_kernel, dim3(grid_for(rows * Lout, 4096)), dim3(256), 0, stream, x, y, rows, L, Lout);
+  M2D_CHECK_LAUNCH("m2d_maxpool2_fwd");
+  return M2D_OK;
+}
+
+int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, int L, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Lout = L / 2;
+  if (rows == 0 || Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_maxpool2_bwd: bad shape");
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 10.0 * rows * (double)L);
+  hipLaunchKernelGGL(m2d_maxpool2_bwd_kernel, dim3(grid_for(rows * L, 4096)), dim3(256), 0, stream, x, dy, dx, rows, L, Lout);
+  M2D_CHECK_LAUNCH("m2d_maxpool2_bwd");
+  return M2D_OK;
+}
+
+// nn.Upsample(scale_factor=2, mode="linear", align_corners=False) (phase3/archis/default.py:236)
+int m2d_upsample2_fwd(const float* x, float* y, size_t rows, int L, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (rows == 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_fwd: bad shape");
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L);
+  hipLaunchKernelGGL(m2d_upsample2_fwd_kernel, dim3(grid_for(rows * 2 * L, 4096)), dim3(256), 0, stream, x, y, rows, L);
+  M2D_CHECK_LAUNCH("m2d_upsample2_fwd");
+  return M2D_OK;
+}
+
+int m2d_upsample2_bwd(const float* dy, float* dx, size_t rows, int L, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (rows == 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_bwd: bad shape");
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L);
+  hipLaunchKernelGGL(m2d_upsample2_bwd_kernel, dim3(grid_for(rows * L, 4096)), dim3(256), 0, stream, dy, dx, rows, L);
+  M2D_CHECK_LAUNCH("m2d_upsample2_bwd");
+  return M2D_OK;
+}
+
+}  // extern "C"

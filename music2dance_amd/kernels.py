@@ -1,0 +1,342 @@
+"""Tensor-level wrappers over the C-ABI (include/m2d.h): raw kernels, no autograd.
+
+PyTorch is plumbing here: it owns device memory (outputs and scratch come from the
+caching allocator, so the calls are hipGraph-capture safe) and the current HIP stream.
+Every method enqueues hand-written gfx950 kernels and nothing else; inputs must be
+contiguous fp32 tensors on a HIP device, otherwise the call raises (no fallback).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.M2dError("m2d kernels need HIP device tensors (got %s); there is no CPU path" % t.device)
+        if t.dtype != torch.float32:
+            raise _lib.M2dError("m2d kernels are fp32 only (got %s)" % t.dtype)
+        if not t.is_contiguous():
+            raise _lib.M2dError("m2d kernels need contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise _lib.M2dError("tensors on different devices")
+    return dev
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _ws(nbytes, dev):
+    if nbytes <= 0:
+        return None
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+
+
+def conv_out_len(L, ks, stride, pad):
+    return (L + 2 * pad - ks) // stride + 1
+
+
+class HipKernels:
+    """The product implementation: every method is one or a few HIP kernel launches."""
+
+    name = "hip"
+
+    # ---------------------------------------------------------------- conv1d
+    def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
+                   out_mask_slope=0.0):
+        dev = _chk(x, w, bias, residual, out_mask)
+        B, Cin, L = x.shape
+        Cout, Cin2, ks = w.shape
+        assert Cin == Cin2, "conv1d: channel mismatch"
+        Lout = conv_out_len(L, ks, stride, pad)
+        y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_conv1d_workspace_bytes(0, B, Cin, L, Cout, ks, stride, pad), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_conv1d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, Cin, L, Cout, ks, stride, pad, act,
+                                  slope, _ptr(residual), _ptr(out_mask), out_mask_slope, _ptr(ws),
+                                  0 if ws is None else ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_conv1d_fwd")
+        return y
+
+    def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0):
+        dev = _chk(dy, w, dy_mask)
+        B, Cout, Lout = dy.shape
+        Cout2, Cin, ks = w.shape
+        assert Cout == Cout2 and Lout == conv_out_len(L, ks, stride, pad)
+        dx = torch.empty((B, Cin, L), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_conv1d_workspace_bytes(1, B, Cin, L, Cout, ks, stride, pad), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_conv1d_bwd_data(_ptr(dy), _ptr(w), _ptr(dx), B, Cin, L, Cout, ks, stride, pad,
+                                       _ptr(dy_mask), dy_mask_slope, _ptr(ws),
+                                       0 if ws is None else ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_conv1d_bwd_data")
+        return dx
+
+    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0):
+        dev = _chk(x, dy, dy_mask)
+        B, Cin, L = x.shape
+        B2, Cout, Lout = dy.shape
+        assert B == B2 and Lout == conv_out_len(L, ks, stride, pad)
+        dw = torch.empty((Cout, Cin, ks), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_conv1d_workspace_bytes(2, B, Cin, L, Cout, ks, stride, pad), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, L, Cout, ks, stride, pad,
+                                         _ptr(dy_mask), dy_mask_slope, _ptr(ws),
+                                         0 if ws is None else ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_conv1d_bwd_weight")
+        return dw
+
+    # ---------------------------------------------------------------- gemm
+    def gemm(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,
+             out_mask_slope=0.0):
+        """mode 0: a(M,K) b(N,K)^T (+bias[N]); 1: a(M,K) b(K,N); 2: a(K,M)^T b(K,N)."""
+        dev = _chk(a, b, bias, a_mask, out_mask)
+        if mode == 0:
+            M, K = a.shape
+            N, K2 = b.shape
+        elif mode == 1:
+            M, K = a.shape
+            K2, N = b.shape
+        else:
+            K, M = a.shape
+            K2, N = b.shape
+        assert K == K2, "gemm: inner dimension mismatch"
+        c = torch.empty((M, N), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_gemm_workspace_bytes(mode, M, N, K), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_gemm(mode, _ptr(a), _ptr(b), _ptr(bias), _ptr(c), M, N, K, act, slope, _ptr(a_mask),
+                            a_mask_slope, _ptr(out_mask), out_mask_slope, _ptr(ws),
+                            0 if ws is None else ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_gemm")
+        return c
+
+    # ---------------------------------------------------------------- batch norm
+    def channel_sums(self, x, mask=None, slope=0.0):
+        """x: (B, C, L) or (B, C) -> (C,) sums over batch and length (optionally masked)."""
+        dev = _chk(x, mask)
+        B, C = x.shape[0], x.shape[1]
+        L = x.shape[2] if x.dim() == 3 else 1
+        out = torch.empty((C,), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_bn_workspace_bytes(C), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_channel_sums(_ptr(x), _ptr(mask), slope, _ptr(out), B, C, L, _ptr(ws), ws.numel() * 4,
+                                    _stream(dev))
+        _lib.check(rc, "m2d_channel_sums")
+        return out
+
+    def bn_fwd(self, x, gamma, beta, running_mean, running_var, training, eps, momentum, act=0, slope=0.0,
+               residual=None):
+        dev = _chk(x, gamma, beta, running_mean, running_var, residual)
+        B, C = x.shape[0], x.shape[1]
+        L = x.shape[2] if x.dim() == 3 else 1
+        y = torch.empty_like(x)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_bn_workspace_bytes(C), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_bn_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
+                              _ptr(save_mean), _ptr(save_invstd), B, C, L, eps, momentum, 1 if training else 0,
+                              act, slope, _ptr(residual), _ptr(ws), ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_bn_fwd")
+        return y, save_mean, save_invstd
+
+    def bn_bwd(self, dy, x, gamma, beta, save_mean, save_invstd, act=0, slope=0.0):
+        dev = _chk(dy, x, gamma, beta, save_mean, save_invstd)
+        B, C = x.shape[0], x.shape[1]
+        L = x.shape[2] if x.dim() == 3 else 1
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_bn_workspace_bytes(C), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_bn_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_invstd),
+                              _ptr(dx), _ptr(dgamma), _ptr(dbeta), B, C, L, act, slope, _ptr(ws), ws.numel() * 4,
+                              _stream(dev))
+        _lib.check(rc, "m2d_bn_bwd")
+        return dx, dgamma, dbeta
+
+    # ---------------------------------------------------------------- GRU
+    def gru_layer_fwd(self, gi, w_hh_t, b_hh, lengths=None, save=True):
+        """gi: (B, T, 3H) with b_ih added; w_hh_t: (H, 3H). Returns out (B,T,H), saved gates or None."""
+        dev = _chk(gi, w_hh_t, b_hh)
+        B, T, H3 = gi.shape
+        H = H3 // 3
+        out = torch.empty((B, T, H), dtype=torch.float32, device=dev)
+        saved = None
+        if save:
+            saved = torch.empty((4, B, T, H), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        with torch.cuda.device(dev):
+            rc = h.m2d_gru_layer_fwd(_ptr(gi), _ptr(w_hh_t), _ptr(b_hh), _ptr(lengths), _ptr(out),
+                                     _ptr(saved[0]) if save else 0, _ptr(saved[1]) if save else 0,
+                                     _ptr(saved[2]) if save else 0, _ptr(saved[3]) if save else 0, B, T, H,
+                                     _stream(dev))
+        _lib.check(rc, "m2d_gru_layer_fwd")
+        return out, saved
+
+    def gru_layer_bwd(self, dout, out, saved, w_hh, lengths=None):
+        dev = _chk(dout, out, saved, w_hh)
+        B, T, H = out.shape
+        dgi = torch.empty((B, T, 3 * H), dtype=torch.float32, device=dev)
+        dgh = torch.empty((B, T, 3 * H), dtype=torch.float32, device=dev)
+        dh_buf = torch.empty((2, B, H), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        with torch.cuda.device(dev):
+            rc = h.m2d_gru_layer_bwd(_ptr(dout), _ptr(out), _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]),
+                                     _ptr(saved[3]), _ptr(w_hh), _ptr(lengths), _ptr(dgi), _ptr(dgh),
+                                     _ptr(dh_buf), B, T, H, _stream(dev))
+        _lib.check(rc, "m2d_gru_layer_bwd")
+        return dgi, dgh
+
+    # ---------------------------------------------------------------- gradient penalty
+    def gp_interpolate(self, real, fake, alpha):
+        """real, fake: (B, n); alpha: (B,) -> alpha*real + (1-alpha)*fake."""
+        dev = _chk(real, fake, alpha)
+        B, n = real.shape
+        out = torch.empty_like(real)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_gp_interpolate(_ptr(real), _ptr(fake), _ptr(alpha), _ptr(out), B, n, _stream(dev))
+        _lib.check(rc, "m2d_gp_interpolate")
+        return out
+
+    def gp_penalty_fwd(self, g, lp):
+        dev = _chk(g)
+        B, n = g.shape
+        norms = torch.empty((B,), dtype=torch.float32, device=dev)
+        pen = torch.empty((), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_gp_penalty_fwd(_ptr(g), _ptr(norms), _ptr(pen), B, n, 1 if lp else 0, _stream(dev))
+        _lib.check(rc, "m2d_gp_penalty_fwd")
+        return pen, norms
+
+    def gp_penalty_bwd(self, g, norms, gout, lp):
+        dev = _chk(g, norms, gout)
+        B, n = g.shape
+        dg = torch.empty_like(g)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_gp_penalty_bwd(_ptr(g), _ptr(norms), _ptr(gout), _ptr(dg), B, n, 1 if lp else 0,
+                                               _stream(dev))
+        _lib.check(rc, "m2d_gp_penalty_bwd")
+        return dg
+
+    # ---------------------------------------------------------------- losses
+    def l1_mean_fwd(self, a, b):
+        dev = _chk(a, b)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_reduce_workspace_bytes(), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_l1_mean_fwd(_ptr(a), _ptr(b), _ptr(out), a.numel(), _ptr(ws), ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_l1_mean_fwd")
+        return out
+
+    def l1_mean_bwd(self, a, b, gout):
+        dev = _chk(a, b, gout)
+        da = torch.empty_like(a)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_l1_mean_bwd(_ptr(a), _ptr(b), _ptr(gout), _ptr(da), a.numel(), _stream(dev))
+        _lib.check(rc, "m2d_l1_mean_bwd")
+        return da
+
+    def tv_mean_fwd(self, x, B, C, T, sb, sc, st):
+        """x: storage holding a (B, C, T) view with element strides (sb, sc, st)."""
+        dev = _chk(x)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_reduce_workspace_bytes(), dev)
+        with torch.cuda.device(dev):
+            rc = h.m2d_tv_mean_fwd(_ptr(x), _ptr(out), B, C, T, sb, sc, st, _ptr(ws), ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_tv_mean_fwd")
+        return out
+
+    def tv_mean_bwd(self, x, gout, B, C, T, sb, sc, st):
+        dev = _chk(x, gout)
+        dx = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_tv_mean_bwd(_ptr(x), _ptr(gout), _ptr(dx), B, C, T, sb, sc, st, _stream(dev))
+        _lib.check(rc, "m2d_tv_mean_bwd")
+        return dx
+
+    # ---------------------------------------------------------------- U-Net resampling
+    def maxpool2_fwd(self, x):
+        dev = _chk(x)
+        B, C, L = x.shape
+        y = torch.empty((B, C, L // 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_maxpool2_fwd(_ptr(x), _ptr(y), B * C, L, _stream(dev))
+        _lib.check(rc, "m2d_maxpool2_fwd")
+        return y
+
+    def maxpool2_bwd(self, x, dy):
+        dev = _chk(x, dy)
+        B, C, L = x.shape
+        dx = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_maxpool2_bwd(_ptr(x), _ptr(dy), _ptr(dx), B * C, L, _stream(dev))
+        _lib.check(rc, "m2d_maxpool2_bwd")
+        return dx
+
+    def upsample2_fwd(self, x):
+        dev = _chk(x)
+        B, C, L = x.shape
+        y = torch.empty((B, C, 2 * L), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_upsample2_fwd(_ptr(x), _ptr(y), B * C, L, _stream(dev))
+        _lib.check(rc, "m2d_upsample2_fwd")
+        return y
+
+    def upsample2_bwd(self, dy):
+        dev = _chk(dy)
+        B, C, Lo = dy.shape
+        dx = torch.empty((B, C, Lo // 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_upsample2_bwd(_ptr(dy), _ptr(dx), B * C, Lo // 2, _stream(dev))
+        _lib.check(rc, "m2d_upsample2_bwd")
+        return dx
+
+    # ---------------------------------------------------------------- profiler
+    def prof_begin(self):
+        _lib.check(_lib.lib().m2d_prof_begin(), "m2d_prof_begin")
+
+    def prof_end(self):
+        buf = (ctypes.c_double * 20)()
+        _lib.check(_lib.lib().m2d_prof_end(buf, 20), "m2d_prof_end")
+        fams = ["gemm", "bn", "gru", "pointwise", "reduce"]
+        return {f: {"ms": buf[4 * i], "launches": int(buf[4 * i + 1]), "flops": buf[4 * i + 2],
+                    "bytes": buf[4 * i + 3]} for i, f in enumerate(fams)}
+
+
+_impl = HipKernels()
+
+
+def impl():
+    return _impl
+
+
+def set_impl(obj):
+    """Test hook (tests/fake_backend.py installs a CPU stand-in to exercise host logic)."""
+    global _impl
+    prev = _impl
+    _impl = obj
+    return prev

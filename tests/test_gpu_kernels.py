@@ -1,0 +1,369 @@
+"""Op-level parity of every HIP kernel (through the C-ABI) against plain fp64/fp32 torch
+CPU ops — the primitives the oracle (oracle/) is written in. Covers every
+(Cin, Cout, k, stride, pad, L) the hot path uses at small batch.
+
+Tolerance: fp32 contraction noise. err = max|got - ref64| / max(1, max|ref64|) <= 2e-5
+for contractions (K up to 38 400 terms), 1e-6-level for elementwise kernels.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def K():
+    from music2dance_amd import kernels
+    return kernels.impl()
+
+
+def rel_err(got, ref64):
+    got = got.detach().cpu().double()
+    ref64 = ref64.detach().double()
+    assert got.shape == ref64.shape, (got.shape, ref64.shape)
+    denom = max(1.0, ref64.abs().max().item())
+    return (got - ref64).abs().max().item() / denom
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# (name, B, Cin, L, Cout, k, stride, pad)
+CONV_CASES = [
+    ("stick.conv1", 3, 69, 120, 128, 25, 1, 12),
+    ("stick.conv1.k9", 2, 69, 120, 128, 9, 1, 4),
+    ("temporal.k7", 3, 128, 120, 128, 7, 1, 3),
+    ("stick.fconv", 5, 128, 120, 100, 120, 1, 0),
+    ("p2.lastconv", 4, 128, 120, 1, 120, 1, 0),
+    ("audio_d.l1", 2, 1, 76800, 32, 25, 4, 11),
+    ("audio_d.l2", 2, 32, 19200, 64, 25, 4, 11),
+    ("audio_d.l3", 2, 64, 4800, 128, 25, 4, 11),
+    ("audio_d.l4", 2, 128, 1200, 256, 25, 4, 11),
+    ("audio_d.l5", 2, 256, 300, 512, 25, 4, 11),
+    ("audio_d.l6", 3, 512, 75, 100, 75, 1, 0),
+    ("enc.c0", 6, 1, 3200, 32, 250, 50, 124),
+    ("enc.c1", 6, 32, 64, 64, 4, 2, 1),
+    ("enc.c2", 6, 64, 32, 128, 4, 2, 1),
+    ("enc.c3", 6, 128, 16, 256, 4, 2, 1),
+    ("enc.c4", 6, 256, 8, 512, 4, 2, 1),
+    ("enc.c5", 6, 512, 4, 1024, 4, 2, 1),
+    ("enc.c6", 6, 1024, 2, 250, 2, 1, 0),
+    ("wg.l1", 3, 1, 3200, 32, 25, 4, 0),
+    ("wg.l2", 3, 32, 794, 64, 25, 4, 0),
+    ("wg.l3", 3, 64, 193, 128, 25, 4, 0),
+    ("wg.l4", 3, 128, 43, 256, 25, 4, 0),
+    ("wg.l5", 3, 256, 5, 250, 5, 1, 0),
+    ("unet.c0", 2, 1, 3200, 32, 160, 4, 79),
+    ("unet.c1", 2, 32, 800, 64, 4, 2, 1),
+    ("unet.k3", 2, 128, 200, 128, 3, 1, 1),
+    ("unet.k3cat", 2, 256, 50, 128, 3, 1, 1),
+    ("unet.k3.25", 2, 128, 25, 128, 3, 1, 1),
+    ("unet.fc", 3, 128, 200, 250, 200, 1, 0),
+    ("odd.a", 2, 3, 17, 5, 3, 2, 1),
+    ("odd.b", 1, 7, 33, 9, 5, 3, 0),
+    ("odd.c", 2, 2, 40, 33, 6, 4, 5),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv1d_fwd_bwd(case):
+    name, B, Cin, L, Cout, ks, s, p = case
+    x = gen(B, Cin, L, seed=1)
+    w = gen(Cout, Cin, ks, seed=2, scale=1.0 / math.sqrt(Cin * ks))
+    b = gen(Cout, seed=3, scale=0.1)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    ref = F.conv1d(x.double(), w.double(), b.double(), stride=s, padding=p)
+    y = K().conv1d_fwd(xd, wd, bd, s, p)
+    assert rel_err(y, ref) < 2e-5, "fwd"
+    # fused bias + ReLU
+    y = K().conv1d_fwd(xd, wd, bd, s, p, act=1)
+    assert rel_err(y, ref.clamp_min(0)) < 2e-5, "fwd+relu"
+    # backward-data / backward-weight vs autograd of the fp64 op
+    dy = gen(*ref.shape, seed=4)
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    out = F.conv1d(x64, w64, None, stride=s, padding=p)
+    gx, gw = torch.autograd.grad(out, (x64, w64), dy.double())
+    dx = K().conv1d_bwd_data(dy.to(DEV), wd, L, s, p)
+    assert rel_err(dx, gx) < 2e-5, "bwd_data"
+    dw = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p)
+    assert rel_err(dw, gw) < 3e-5, "bwd_weight"
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[6], CONV_CASES[12], CONV_CASES[29]],
+                         ids=lambda c: c[0])
+def test_conv1d_masks_and_epilogue(case):
+    name, B, Cin, L, Cout, ks, s, p = case
+    x = gen(B, Cin, L, seed=1)
+    w = gen(Cout, Cin, ks, seed=2, scale=1.0 / math.sqrt(Cin * ks))
+    b = gen(Cout, seed=3, scale=0.1)
+    ref = F.conv1d(x.double(), w.double(), b.double(), stride=s, padding=p)
+    mask = gen(*ref.shape, seed=5)
+    res = gen(*ref.shape, seed=6)
+    slope = 0.2
+    m64 = torch.where(mask.double() > 0, torch.ones_like(ref), torch.full_like(ref, slope))
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    # leaky + residual + out mask
+    y = K().conv1d_fwd(xd, wd, bd, s, p, act=2, slope=slope, residual=res.to(DEV), out_mask=mask.to(DEV),
+                       out_mask_slope=slope)
+    want = (F.leaky_relu(ref, slope) + res.double()) * m64
+    assert rel_err(y, want) < 2e-5
+    # masked dy in both backward halves (mask slope 0 = ReLU derivative)
+    dy = gen(*ref.shape, seed=4)
+    m0 = (mask.double() > 0).double()
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    out = F.conv1d(x64, w64, None, stride=s, padding=p)
+    gx, gw = torch.autograd.grad(out, (x64, w64), dy.double() * m0)
+    dx = K().conv1d_bwd_data(dy.to(DEV), wd, L, s, p, dy_mask=mask.to(DEV), dy_mask_slope=0.0)
+    assert rel_err(dx, gx) < 2e-5
+    dw = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p, dy_mask=mask.to(DEV), dy_mask_slope=0.0)
+    assert rel_err(dw, gw) < 3e-5
+
+
+GEMM_CASES = [(64, 128, 200), (7680, 256, 250), (3840, 720, 250), (33, 69, 256), (1, 1, 128), (100, 1, 128),
+              (257, 131, 77), (64, 15360, 100)]
+
+
+@pytest.mark.parametrize("mnk", GEMM_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_gemm_modes(mnk):
+    M, N, Kd = mnk
+    a = gen(M, Kd, seed=1)
+    bt = gen(N, Kd, seed=2, scale=1.0 / math.sqrt(Kd))
+    bias = gen(N, seed=3)
+    ref = a.double() @ bt.double().t() + bias.double()
+    c = K().gemm(0, a.to(DEV), bt.to(DEV), bias.to(DEV))
+    assert rel_err(c, ref) < 2e-5, "NT"
+    c = K().gemm(0, a.to(DEV), bt.to(DEV), bias.to(DEV), act=1)
+    assert rel_err(c, ref.clamp_min(0)) < 2e-5, "NT+relu"
+    b = bt.t().contiguous()  # (K, N)
+    c = K().gemm(1, a.to(DEV), b.to(DEV))
+    assert rel_err(c, a.double() @ b.double()) < 2e-5, "NN"
+    at = a.t().contiguous()  # (K, M)
+    c = K().gemm(2, at.to(DEV), b.to(DEV))
+    assert rel_err(c, at.double().t() @ b.double()) < 2e-5, "TN"
+    # masks
+    am = gen(M, Kd, seed=7)
+    om = gen(M, N, seed=8)
+    a_eff = a.double() * torch.where(am.double() > 0, 1.0, 0.0)
+    want = (a_eff @ b.double()) * torch.where(om.double() > 0, 1.0, 0.2)
+    c = K().gemm(1, a.to(DEV), b.to(DEV), a_mask=am.to(DEV), a_mask_slope=0.0, out_mask=om.to(DEV),
+                 out_mask_slope=0.2)
+    assert rel_err(c, want) < 2e-5, "NN masked"
+
+
+def test_gemm_tn_long_k():
+    # dW = dy^T x with K = B*T rows (split-K path)
+    Kd, M, N = 7680, 256, 250
+    a = gen(Kd, M, seed=1)
+    b = gen(Kd, N, seed=2)
+    c = K().gemm(2, a.to(DEV), b.to(DEV))
+    assert rel_err(c, a.double().t() @ b.double()) < 3e-5
+
+
+BN_CASES = [(64, 128, 1), (7680, 256, 1), (48, 32, 64), (48, 1024, 2), (24, 64, 193), (24, 128, 43), (24, 256, 5),
+            (6, 32, 800), (6, 128, 25), (5, 3, 7)]
+
+
+@pytest.mark.parametrize("shape", BN_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_bn_train_fwd_bwd(shape, act):
+    B, C, L = shape
+    x = gen(B, C, L, seed=1) * 1.5 + 0.3
+    if L == 1:
+        x = x.view(B, C)
+    gamma = 1.0 + gen(C, seed=2, scale=0.1)
+    beta = gen(C, seed=3, scale=0.1)
+    rm = gen(C, seed=4, scale=0.1)
+    rv = 1.0 + gen(C, seed=5, scale=0.1).abs()
+    slope = 0.2
+    x64 = x.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = beta.double().requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    z = F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+    ref = z if act == 0 else (F.relu(z) if act == 1 else F.leaky_relu(z, slope))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    y, mean, invstd = K().bn_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), rmd, rvd, True, 1e-5, 0.1, act, slope)
+    assert rel_err(y, ref) < 1e-5
+    assert rel_err(rmd, rm64) < 1e-6 and rel_err(rvd, rv64) < 1e-6
+    dy = gen(*x.shape, seed=6)
+    gx, gg, gb = torch.autograd.grad(ref, (x64, g64, b64), dy.double())
+    dx, dg, db = K().bn_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), beta.to(DEV), mean, invstd, act, slope)
+    assert rel_err(dx, gx) < 2e-5
+    assert rel_err(dg, gg) < 2e-5 and rel_err(db, gb) < 2e-5
+
+
+def test_bn_eval_and_residual():
+    B, C = 40, 256
+    x = gen(B, C, seed=1)
+    res = gen(B, C, seed=9)
+    gamma, beta = 1.0 + gen(C, seed=2, scale=0.1), gen(C, seed=3, scale=0.1)
+    rm, rv = gen(C, seed=4, scale=0.1), 1.0 + gen(C, seed=5, scale=0.1).abs()
+    ref = F.batch_norm(x.double(), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    y, _, _ = K().bn_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), rmd, rvd, False, 1e-5, 0.1, 1, 0.0,
+                         residual=res.to(DEV))
+    assert rel_err(y, res.double() + F.relu(ref)) < 1e-5
+    assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv)
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 120), (7, 5, 3), (64, 100, 1), (3, 32, 19200)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_channel_sums(shape):
+    x = gen(*shape, seed=1)
+    m = gen(*shape, seed=2)
+    got = K().channel_sums(x.to(DEV))
+    assert rel_err(got, x.double().sum(dim=(0, 2))) < 1e-5
+    got = K().channel_sums(x.to(DEV), m.to(DEV), 0.2)
+    want = (x.double() * torch.where(m.double() > 0, 1.0, 0.2)).sum(dim=(0, 2))
+    assert rel_err(got, want) < 1e-5
+
+
+def _gru_ref(x, w_ih, w_hh, b_ih, b_hh, lengths=None):
+    I, H = w_ih.shape[1], w_hh.shape[1]
+    rnn = torch.nn.GRU(I, H, 1, batch_first=True).double()
+    with torch.no_grad():
+        rnn.weight_ih_l0.copy_(w_ih)
+        rnn.weight_hh_l0.copy_(w_hh)
+        rnn.bias_ih_l0.copy_(b_ih)
+        rnn.bias_hh_l0.copy_(b_hh)
+    return rnn
+
+
+@pytest.mark.parametrize("dims", [(5, 7, 250, 240), (3, 12, 10, 10), (32, 9, 50, 50), (17, 5, 33, 21)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_gru_layer_fwd_bwd(dims):
+    B, T, I, H = dims
+    x = gen(B, T, I, seed=1)
+    w_ih = gen(3 * H, I, seed=2, scale=1 / math.sqrt(I))
+    w_hh = gen(3 * H, H, seed=3, scale=1 / math.sqrt(H))
+    b_ih, b_hh = gen(3 * H, seed=4, scale=0.1), gen(3 * H, seed=5, scale=0.1)
+    rnn = _gru_ref(x, w_ih, w_hh, b_ih, b_hh)
+    x64 = x.double().requires_grad_(True)
+    ref, _ = rnn(x64)
+    k = K()
+    gi = k.gemm(0, x.view(B * T, I).to(DEV), w_ih.to(DEV), b_ih.to(DEV)).view(B, T, 3 * H)
+    out, saved = k.gru_layer_fwd(gi, w_hh.t().contiguous().to(DEV), b_hh.to(DEV))
+    assert rel_err(out, ref) < 1e-5
+    dout = gen(B, T, H, seed=6)
+    grads = torch.autograd.grad(ref, (x64, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0),
+                                dout.double())
+    dgi, dgh = k.gru_layer_bwd(dout.to(DEV), out, saved, w_hh.to(DEV))
+    dgi2 = dgi.view(B * T, 3 * H)
+    dgh2 = dgh.view(B * T, 3 * H)
+    dx = k.gemm(1, dgi2, w_ih.to(DEV)).view(B, T, I)
+    dw_ih = k.gemm(2, dgi2, x.view(B * T, I).to(DEV))
+    hprev = torch.cat([torch.zeros(B, 1, H, device=DEV), out[:, :-1]], 1).contiguous().view(B * T, H)
+    dw_hh = k.gemm(2, dgh2, hprev)
+    assert rel_err(dx, grads[0]) < 2e-5
+    assert rel_err(dw_ih, grads[1]) < 2e-5
+    assert rel_err(dw_hh, grads[2]) < 2e-5
+    assert rel_err(k.channel_sums(dgi2.view(B * T, 3 * H, 1)), grads[3]) < 2e-5
+    assert rel_err(k.channel_sums(dgh2.view(B * T, 3 * H, 1)), grads[4]) < 2e-5
+
+
+def test_gru_lengths():
+    B, T, I, H = 4, 6, 8, 16
+    lengths = [6, 5, 3, 1]
+    x = gen(B, T, I, seed=1)
+    w_ih, w_hh = gen(3 * H, I, seed=2, scale=0.3), gen(3 * H, H, seed=3, scale=0.3)
+    b_ih, b_hh = gen(3 * H, seed=4, scale=0.1), gen(3 * H, seed=5, scale=0.1)
+    rnn = _gru_ref(x, w_ih, w_hh, b_ih, b_hh)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x.double(), lengths, batch_first=True)
+    ref, _ = torch.nn.utils.rnn.pad_packed_sequence(rnn(packed)[0], batch_first=True)
+    k = K()
+    gi = k.gemm(0, x.view(B * T, I).to(DEV), w_ih.to(DEV), b_ih.to(DEV)).view(B, T, 3 * H)
+    lens = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    out, _ = k.gru_layer_fwd(gi, w_hh.t().contiguous().to(DEV), b_hh.to(DEV), lengths=lens)
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("n", [69, 8280, 76800])
+@pytest.mark.parametrize("lp", [False, True])
+def test_gp_ops(n, lp):
+    B = 6
+    real, fake = gen(B, n, seed=1), gen(B, n, seed=2)
+    alpha = torch.rand(B, generator=torch.Generator().manual_seed(3))
+    got = K().gp_interpolate(real.to(DEV), fake.to(DEV), alpha.to(DEV))
+    want = alpha.view(B, 1) * real + (1 - alpha.view(B, 1)) * fake  # fp32, same three roundings
+    assert torch.equal(got.cpu(), want)
+    scale = torch.tensor([0.2, 0.9, 1.0, 1.1, 3.0, 0.0]).view(B, 1) / math.sqrt(n)
+    g = (gen(B, n, seed=4) * scale)
+    g64 = g.double().requires_grad_(True)
+    if lp:
+        d = (g64.norm(2, dim=1) - 1).clamp_min(0)
+        ref = (d ** 2).mean()
+    else:
+        ref = ((torch.sqrt((g64 ** 2).sum(1) + 1e-12) - 1) ** 2).mean()
+    pen, norms = K().gp_penalty_fwd(g.to(DEV), lp)
+    assert abs(pen.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    (gref,) = torch.autograd.grad(ref, g64)
+    gout = torch.tensor(0.7, device=DEV)
+    dg = K().gp_penalty_bwd(g.to(DEV), norms, gout, lp)
+    err = (dg.cpu().double() - 0.7 * gref).abs().max().item()
+    assert err < 1e-5 * max(1e-3, gref.abs().max().item()) + 1e-9
+
+
+def test_l1_tv():
+    B, C, T = 5, 69, 120
+    a, b = gen(B, C, T, seed=1), gen(B, C, T, seed=2)
+    a64 = a.double().requires_grad_(True)
+    ref = (a64 - b.double()).abs().mean()
+    got = K().l1_mean_fwd(a.to(DEV), b.to(DEV))
+    assert abs(got.item() - ref.item()) < 1e-6
+    (gref,) = torch.autograd.grad(ref, a64)
+    gout = torch.tensor(1.3, device=DEV)
+    da = K().l1_mean_bwd(a.to(DEV), b.to(DEV), gout)
+    assert rel_err(da, 1.3 * gref) < 1e-6
+    # TV on the generator's native (B*T, C) layout, viewed as (B, C, T)
+    rows = gen(B * T, C, seed=3)
+    v64 = rows.double().requires_grad_(True)
+    seq = v64.view(B, T, C).permute(0, 2, 1)
+    ref = (seq[:, :, 1:] - seq[:, :, :-1]).abs().mean()
+    got = K().tv_mean_fwd(rows.to(DEV), B, C, T, T * C, 1, C)
+    assert abs(got.item() - ref.item()) < 1e-6
+    (gref,) = torch.autograd.grad(ref, v64)
+    dx = K().tv_mean_bwd(rows.to(DEV), gout, B, C, T, T * C, 1, C)
+    assert (dx.cpu().double() - 1.3 * gref).abs().max().item() < 1e-9
+
+
+@pytest.mark.parametrize("L", [200, 100, 50, 25])
+def test_pool_upsample(L):
+    B, C = 3, 128
+    x = gen(B, C, L, seed=1)
+    x64 = x.double().requires_grad_(True)
+    ref = F.max_pool1d(x64, 2, 2)
+    got = K().maxpool2_fwd(x.to(DEV))
+    assert torch.equal(got.cpu(), F.max_pool1d(x, 2, 2))
+    dy = gen(*ref.shape, seed=2)
+    (gref,) = torch.autograd.grad(ref, x64, dy.double())
+    dx = K().maxpool2_bwd(x.to(DEV), dy.to(DEV))
+    assert rel_err(dx, gref) < 1e-7
+    up = torch.nn.Upsample(scale_factor=2, mode="linear", align_corners=False)
+    ref = up(x64)
+    got = K().upsample2_fwd(x.to(DEV))
+    assert rel_err(got, ref) < 1e-6
+    dy = gen(*ref.shape, seed=3)
+    (gref,) = torch.autograd.grad(ref, x64, dy.double())
+    dx = K().upsample2_bwd(dy.to(DEV))
+    assert rel_err(dx, gref) < 1e-6
+
+
+def test_profiler_counts_gemm_launches():
+    k = K()
+    x = gen(2, 8, 64, seed=1).to(DEV)
+    w = gen(16, 8, 3, seed=2).to(DEV)
+    k.prof_begin()
+    k.conv1d_fwd(x, w, None, 1, 1)
+    k.conv1d_fwd(x, w, None, 1, 1)
+    stats = k.prof_end()
+    assert stats["gemm"]["launches"] == 2
+    assert stats["gemm"]["flops"] == 2 * (2.0 * 16 * (2 * 64) * (8 * 3))
+    assert stats["gemm"]["ms"] > 0
