@@ -455,3 +455,73 @@ def p2_train_iterations(gen_sd, critic_sd, real, n_iters, rng_seed, n_cells=3, n
     gen_out = {k: v.detach() for k, v in g_params.items()}
     gen_out.update(g_buf)
     return trace, gen_out, {k: v.detach() for k, v in d_params.items()}
+
+
+def _keep_mask(shape):
+    """The Bernoulli(0.5) keep-mask F.dropout draws from the default CPU generator."""
+    return torch.empty(shape).bernoulli_(0.5)
+
+
+def p1_critic_iteration_values(gen_sd, critic_sd, z, real, rng_seed, nblocks=1, size=128, gamma=10.0):
+    """One phase-1 critic iteration (phase1/train_wgan-gp.py:84-92) in train mode with the
+    dropout masks and alpha drawn in the reference's order from the CPU RNG."""
+    torch.manual_seed(rng_seed)
+    B = real.shape[0]
+    g_params, g_buf = split_state(gen_sd)
+    d_params, _ = split_state(critic_sd)
+    sd = dict(g_params)
+    sd.update(g_buf)
+    fake = p1_generator(sd, z, nblocks, True, _keep_mask((B, size)))
+    alpha = torch.rand(B, 1)
+    mask_gp = _keep_mask((B, size))
+    gp, _, _ = gradient_penalty(lambda x: p1_critic(d_params, x, nblocks, mask_gp), real, fake, alpha)
+    err_real = p1_critic(d_params, real, nblocks, _keep_mask((B, size))).mean()
+    err_fake = p1_critic(d_params, fake.detach(), nblocks, _keep_mask((B, size))).mean()
+    err_critic = err_fake - err_real + gamma * gp
+    grads = grads_of(err_critic, d_params)
+    return {"fake": fake.detach(), "gp": gp.item(), "err_real": err_real.item(), "err_fake": err_fake.item(),
+            "grads": grads, "gen_buffers": {k: sd[k] for k in g_buf}}
+
+
+def p1_train_iterations(gen_sd, critic_sd, real, n_iters, rng_seed, nblocks=1, latent=10, size=128, gamma=10.0,
+                        lr=1e-4, n_critic=5):
+    """Re-enactment of phase1/train_wgan-gp.py:79-110 on one fixed batch of real poses."""
+    torch.manual_seed(rng_seed)
+    B = real.shape[0]
+    g_params, g_buf = split_state(gen_sd)
+    d_params, _ = split_state(critic_sd)
+    opt_d, opt_g = Adam(lr), Adam(lr)
+    trace = {"loss_critic": [], "loss_gen": []}
+
+    def gen_forward():
+        sd = dict(g_params)
+        sd.update(g_buf)
+        noise = torch.randn(B, latent)
+        out = p1_generator(sd, noise, nblocks, True, _keep_mask((B, size)))
+        for k in g_buf:
+            g_buf[k] = sd[k]
+        return out
+
+    for it in range(1, n_iters + 1):
+        fake = gen_forward()
+        alpha = torch.rand(B, 1)
+        mask_gp = _keep_mask((B, size))
+        gp, _, _ = gradient_penalty(lambda x: p1_critic(d_params, x, nblocks, mask_gp), real, fake, alpha)
+        err_real = p1_critic(d_params, real, nblocks, _keep_mask((B, size))).mean()
+        err_fake = p1_critic(d_params, fake.detach(), nblocks, _keep_mask((B, size))).mean()
+        err_critic = err_fake - err_real + gamma * gp
+        trace["loss_critic"].append(err_critic.item())
+        new = opt_d.step({k: v.detach() for k, v in d_params.items()}, grads_of(err_critic, d_params))
+        d_params = {k: v.detach().clone().requires_grad_(True) for k, v in new.items()}
+        if it % n_critic:
+            continue
+        fake = gen_forward()
+        err_real = p1_critic(d_params, real, nblocks, _keep_mask((B, size))).mean()
+        err_fake = p1_critic(d_params, fake, nblocks, _keep_mask((B, size))).mean()
+        err_gen = err_real - err_fake
+        trace["loss_gen"].append(err_gen.item())
+        new = opt_g.step({k: v.detach() for k, v in g_params.items()}, grads_of(err_gen, g_params))
+        g_params = {k: v.detach().clone().requires_grad_(True) for k, v in new.items()}
+    gen_out = {k: v.detach() for k, v in g_params.items()}
+    gen_out.update(g_buf)
+    return trace, gen_out, {k: v.detach() for k, v in d_params.items()}

@@ -1,0 +1,347 @@
+"""Fixture generator — runs ONLY in the build container, where /root/reference exists.
+
+Imports the reference's own modules (phase{1,2,3}/archis, losses.py) with `librosa`
+stubbed, fills them with the seeded patterns of patterns.py, runs the cases of
+SURVEY.md 8(c) and stores the reference's OUTPUTS (never its source) as small .npz
+fixtures next to this script. The training scripts themselves cannot be imported
+(module-level code, missing dataset / tensorboard), so the loop cases are re-enactments of
+phase3/train.py:186-237, phase2/train.py:135-180 and phase1/train_wgan-gp.py:79-110
+written here around the imported reference modules, with torch.optim.Adam.
+
+    python tests/golden/make_golden.py            # regenerate everything
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import patterns as P  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.modules.setdefault("librosa", types.ModuleType("librosa"))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    mods = {
+        "p1": importlib.import_module("phase1.archis.residual"),
+        "p2": importlib.import_module("phase2.archis.default"),
+        "p3": importlib.import_module("phase3.archis.default"),
+        "losses": importlib.import_module("losses"),
+        "utils": importlib.import_module("utils"),
+    }
+    return mods
+
+
+def load_filled(module, seed):
+    sd = P.fill_state_dict(module.state_dict(), seed)
+    module.load_state_dict(sd)
+    return sd
+
+
+def grad_norms(module):
+    out = []
+    for _, p in module.named_parameters():
+        out.append(float("nan") if p.grad is None else p.grad.double().norm().item())
+    return np.array(out)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
+
+
+def npf(t):
+    return t.detach().cpu().numpy()
+
+
+def layout(module):
+    """state_dict key names and shapes (data the oracle needs to rebuild the same dict)."""
+    sd = module.state_dict()
+    return np.array(list(sd.keys())), np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+
+
+# ------------------------------------------------------------------------------ phase 1
+def case_p1(R):
+    B, latent, size, nb = 8, 10, 128, 1
+    gen = R["p1"].Generator(latent, size, 69, nb)
+    critic = R["p1"].Discriminator(69, size, nb)
+    gsd = load_filled(gen, 1000)
+    dsd = load_filled(critic, 2000)
+    z = P.noise(B, 1, latent, seed=21).view(B, latent)
+    real = P.poses(B, 1, seed=22).view(B, 23, 3)
+    out = {"gen_sd_sum": P.sd_checksums(gsd), "critic_sd_sum": P.sd_checksums(dsd),
+           "z_sum": P.checksum(z), "real_sum": P.checksum(real)}
+    out["gen_keys"], out["gen_shapes"] = layout(gen)
+    out["critic_keys"], out["critic_shapes"] = layout(critic)
+    gen.eval(); critic.eval()
+    with torch.no_grad():
+        out["gen_eval"] = npf(gen(z))
+        out["critic_eval"] = npf(critic(real))
+    # one critic iteration in train mode (dropout active in G and D, CPU RNG, seed 5)
+    gen.train(); critic.train()
+    torch.manual_seed(5)
+    fake = gen(z)
+    gp = R["losses"].gradient_penalty(critic, B, real, fake)
+    err_real = critic(real).mean()
+    err_fake = critic(fake.detach()).mean()
+    err_critic = err_fake - err_real + 10 * gp
+    critic.zero_grad()
+    err_critic.backward()
+    out["gen_train"] = npf(fake)
+    out["gp"] = gp.item(); out["err_real"] = err_real.item(); out["err_fake"] = err_fake.item()
+    out["critic_grad_norms"] = grad_norms(critic)
+    out["gen_bn_after"] = P.sd_checksums({k: v for k, v in gen.state_dict().items() if "running" in k})
+    # 6-iteration trace, n_critic 5, lr 1e-4 (phase1/configs/b1l10s128.yaml)
+    load_filled(gen, 1000); load_filled(critic, 2000)
+    opt_d = torch.optim.Adam(critic.parameters(), lr=1e-4)
+    opt_g = torch.optim.Adam(gen.parameters(), lr=1e-4)
+    torch.manual_seed(6)
+    lc, lg = [], []
+    for it in range(1, 7):
+        opt_d.zero_grad()
+        noise = torch.randn(B, latent)
+        fake = gen(noise)
+        gp = R["losses"].gradient_penalty(critic, B, real, fake)
+        err_real = critic(real).mean()
+        err_fake = critic(fake.detach()).mean()
+        err_critic = err_fake - err_real + 10 * gp
+        lc.append(err_critic.item())
+        err_critic.backward()
+        opt_d.step()
+        if it % 5:
+            continue
+        opt_g.zero_grad()
+        noise = torch.randn(B, latent)
+        fake = gen(noise)
+        err_gen = critic(real).mean() - critic(fake).mean()
+        lg.append(err_gen.item())
+        err_gen.backward()
+        opt_g.step()
+    out["trace_loss_critic"] = np.array(lc); out["trace_loss_gen"] = np.array(lg)
+    out["gen_final_sum"] = P.sd_checksums(gen.state_dict())
+    out["critic_final_sum"] = P.sd_checksums(critic.state_dict())
+    save("p1", **out)
+
+
+# ------------------------------------------------------------------------------ phase 2
+def case_p2(R):
+    B, T = 2, 120
+    gen = R["p2"].SequenceGenerator(50, 50, 256, 69, 2, 3, "cpu")
+    critic = R["p2"].SequenceDiscriminator(69, 128, T, 25, 3, "cpu")
+    gsd = load_filled(gen, 3000)
+    dsd = load_filled(critic, 4000)
+    noise = P.noise(B, T, 50, seed=31)
+    real = P.poses(B, T, seed=32)
+    real_c = real.view(B, T, 69).permute(0, 2, 1).contiguous()
+    out = {"gen_sd_sum": P.sd_checksums(gsd), "critic_sd_sum": P.sd_checksums(dsd),
+           "noise_sum": P.checksum(noise), "real_sum": P.checksum(real)}
+    out["gen_keys"], out["gen_shapes"] = layout(gen)
+    out["critic_keys"], out["critic_shapes"] = layout(critic)
+    gen.train()
+    fake_rows = gen(noise, [T] * B)
+    out["gen_train"] = npf(fake_rows)
+    out["gen_bn_after"] = P.sd_checksums({k: v for k, v in gen.state_dict().items() if "running" in k})
+    gen.eval()
+    with torch.no_grad():
+        out["gen_eval"] = npf(gen(noise, [T] * B))
+        out["gen_eval_lengths"] = npf(gen(noise, [T, 100]))
+    gen.train()
+    fake = fake_rows.view(B, T, 69).permute(0, 2, 1).contiguous()
+    out["score_real"] = npf(critic(real_c)); out["score_fake"] = npf(critic(fake.detach()))
+    torch.manual_seed(7)
+    lp = R["losses"].gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=True)
+    torch.manual_seed(7)
+    gp = R["losses"].gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=False)
+    torch.manual_seed(7)
+    out["alpha"] = npf(torch.rand(B, 1))
+    out["lp"] = lp.item(); out["gp"] = gp.item()
+    err_critic = critic(fake.detach()).mean() - critic(real_c).mean() + 10 * lp
+    critic.zero_grad(); err_critic.backward()
+    out["critic_grad_norms"] = grad_norms(critic)
+    fake_g = fake_rows.view(B, T, 69).permute(0, 2, 1)
+    err_gen = critic(real_c).mean() - critic(fake_g).mean() + 50 * R["losses"].tv_loss(fake_g)
+    gen.zero_grad(); err_gen.backward()
+    out["gen_grad_norms"] = grad_norms(gen)
+    out["err_gen"] = err_gen.item(); out["tv"] = R["losses"].tv_loss(fake_g).item()
+    # 8-iteration trace (one generator step), phase2/configs/default.yaml hyper-parameters
+    load_filled(gen, 3000); load_filled(critic, 4000)
+    opt_d = torch.optim.Adam(critic.parameters(), lr=5e-4)
+    opt_g = torch.optim.Adam(gen.parameters(), lr=5e-4)
+    torch.manual_seed(8)
+    tr = {"loss_critic": [], "gp": [], "w_dist": [], "loss_gen": []}
+    for it in range(1, 9):
+        opt_d.zero_grad()
+        nz = torch.randn(B, T, 50)
+        fake = gen(nz, [T] * B).view(B, T, 69).permute(0, 2, 1).contiguous()
+        gp = R["losses"].gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=True)
+        err_real = critic(real_c).mean(); err_fake = critic(fake.detach()).mean()
+        err_critic = err_fake - err_real + 10 * gp
+        tr["loss_critic"].append(err_critic.item()); tr["gp"].append(gp.item())
+        tr["w_dist"].append((err_fake - err_real).item())
+        err_critic.backward(retain_graph=True)
+        opt_d.step()
+        if it % 8:
+            continue
+        opt_g.zero_grad()
+        nz = torch.randn(B, T, 50)
+        fake = gen(nz, [T] * B).view(B, T, 69).permute(0, 2, 1)
+        err_gen = critic(real_c).mean() - critic(fake).mean() + 50 * R["losses"].tv_loss(fake)
+        tr["loss_gen"].append(err_gen.item())
+        err_gen.backward()
+        opt_g.step()
+    for k, v in tr.items():
+        out["trace_" + k] = np.array(v)
+    out["gen_final_sum"] = P.sd_checksums(gen.state_dict())
+    out["critic_final_sum"] = P.sd_checksums(critic.state_dict())
+    save("p2", **out)
+
+
+# ------------------------------------------------------------------------------ phase 3
+def build_p3(R, enc, activ, ablated, T):
+    gen = R["p3"].SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, enc, activ, "cpu")
+    cls = R["p3"].AblatedSequenceDiscriminator if ablated else R["p3"].SequenceDiscriminator
+    critic = cls(69, 128, 100, T, init_ker=25, activ=activ, device="cpu")
+    return gen, critic
+
+
+def case_p3(R, enc, activ, ablated, T=120, B=2, trace=False):
+    name = "p3_%s_%s_%s%s" % (enc, activ, "abl" if ablated else "full", "" if T == 120 else "_T%d" % T)
+    gen, critic = build_p3(R, enc, activ, ablated, T)
+    gsd = load_filled(gen, 5000)
+    dsd = load_filled(critic, 6000)
+    real = P.poses(B, T, seed=41)
+    aud = P.audio(B, T, seed=42)
+    sl = P.slices(aud)
+    nz = P.noise(B, T, 10, seed=43)
+    ref_sl = R["utils"].slice_audio_batch(aud, P.WINDOW, P.HOP, P.PAD)
+    assert torch.equal(ref_sl, sl), "slice_audio_batch restatement differs from the reference"
+    real_c = real.view(B, T, 69).permute(0, 2, 1).contiguous()
+    audio_c = aud.unsqueeze(1)
+    out = {"gen_sd_sum": P.sd_checksums(gsd), "critic_sd_sum": P.sd_checksums(dsd),
+           "real_sum": P.checksum(real), "audio_sum": P.checksum(aud), "noise_sum": P.checksum(nz)}
+    out["gen_keys"], out["gen_shapes"] = layout(gen)
+    out["critic_keys"], out["critic_shapes"] = layout(critic)
+    gen.train()
+    rows = gen(sl, [T] * B, nz)
+    out["gen_train"] = npf(rows)
+    out["gen_bn_after"] = P.sd_checksums({k: v for k, v in gen.state_dict().items() if "running" in k or "tracked" in k})
+    gen.eval()
+    with torch.no_grad():
+        out["gen_eval"] = npf(gen(sl, [T] * B, nz))
+    gen.train()
+    fake = rows.view(B, T, 69).permute(0, 2, 1).contiguous()
+
+    def D(x, a=None):
+        return critic(x) if ablated else critic(x, a)
+
+    out["score_real"] = npf(D(real_c, audio_c)); out["score_fake"] = npf(D(fake.detach(), audio_c))
+    torch.manual_seed(9)
+    a_gp = None if ablated else audio_c.clone()
+    gp = R["losses"].gradient_penalty(critic, B, real_c, fake, a_gp, is_seq=True, lp=False)
+    torch.manual_seed(9)
+    out["alpha"] = npf(torch.rand(B, 1))
+    out["gp"] = gp.item()
+    err_critic = D(fake.detach(), audio_c).mean() - D(real_c, audio_c).mean() + 10 * gp
+    critic.zero_grad(); err_critic.backward()
+    out["critic_grad_norms"] = grad_norms(critic)
+    out["err_critic"] = err_critic.item()
+    fake_g = rows.view(B, T, 69).permute(0, 2, 1)
+    l1 = torch.nn.L1Loss(reduction="mean")(real_c, fake_g)
+    err_gen = D(real_c, audio_c).mean() - D(fake_g, audio_c).mean() + 1.0 * l1 + 0.0 * R["losses"].tv_loss(fake_g)
+    gen.zero_grad(); err_gen.backward()
+    out["gen_grad_norms"] = grad_norms(gen)
+    out["err_gen"] = err_gen.item(); out["err_l1"] = l1.item()
+    if trace:
+        load_filled(gen, 5000); load_filled(critic, 6000)
+        opt_d = torch.optim.Adam(critic.parameters(), lr=2e-4)
+        opt_g = torch.optim.Adam(gen.parameters(), lr=2e-4)
+        torch.manual_seed(10)
+        tr = {"loss_critic": [], "gp": [], "w_dist": [], "loss_gen": [], "err_l1": []}
+        audio_loop = aud.unsqueeze(1)
+        for it in range(1, 9):
+            opt_d.zero_grad()
+            fake = gen(sl, [T] * B).view(B, T, 69).permute(0, 2, 1).contiguous()
+            if ablated:
+                gp = R["losses"].gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=False)
+            else:
+                gp = R["losses"].gradient_penalty(critic, B, real_c, fake, audio_loop, is_seq=True, lp=False)
+            err_real = D(real_c, audio_loop).mean(); err_fake = D(fake.detach(), audio_loop).mean()
+            err_critic = err_fake - err_real + 10 * gp
+            tr["loss_critic"].append(err_critic.item()); tr["gp"].append(gp.item())
+            tr["w_dist"].append((err_fake - err_real).item())
+            err_critic.backward(retain_graph=True)
+            opt_d.step()
+            if it % 8:
+                continue
+            opt_g.zero_grad()
+            fake = gen(sl, [T] * B).view(B, T, 69).permute(0, 2, 1)
+            l1 = torch.nn.L1Loss(reduction="mean")(real_c, fake)
+            err_real = D(real_c, audio_loop).mean(); err_fake = D(fake, audio_loop).mean()
+            err_gen = err_real - err_fake + 1.0 * l1 + 0.0 * R["losses"].tv_loss(fake)
+            tr["loss_gen"].append(err_gen.item()); tr["err_l1"].append(l1.item())
+            err_gen.backward()
+            opt_g.step()
+        for k, v in tr.items():
+            out["trace_" + k] = np.array(v)
+        out["gen_final_sum"] = P.sd_checksums(gen.state_dict())
+        out["critic_final_sum"] = P.sd_checksums(critic.state_dict())
+    save(name, **out)
+
+
+def case_init(R):
+    """Seeded-constructor parity (utils.initialize_weights, utils.py:267-313): checksums of
+    the state_dict a torch.manual_seed(0) constructor produces."""
+    out = {}
+    torch.manual_seed(0)
+    g = R["p3"].SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, "default", "id", "cpu")
+    c = R["p3"].SequenceDiscriminator(69, 128, 100, 120, init_ker=25, activ="id", device="cpu")
+    out["p3_default_gen"] = P.sd_checksums(g.state_dict()); out["p3_critic"] = P.sd_checksums(c.state_dict())
+    out["p3_gen_keys"] = np.array(list(g.state_dict().keys())); out["p3_critic_keys"] = np.array(list(c.state_dict().keys()))
+    torch.manual_seed(0)
+    g = R["p3"].SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, "wavegan", "tanh", "cpu")
+    c = R["p3"].AblatedSequenceDiscriminator(69, 128, 100, 120, init_ker=25, activ="tanh", device="cpu")
+    out["p3_wavegan_gen"] = P.sd_checksums(g.state_dict()); out["p3_ablated_critic"] = P.sd_checksums(c.state_dict())
+    out["p3_wavegan_gen_keys"] = np.array(list(g.state_dict().keys()))
+    out["p3_ablated_critic_keys"] = np.array(list(c.state_dict().keys()))
+    torch.manual_seed(0)
+    g = R["p3"].SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, "unet", "id", "cpu")
+    out["p3_unet_gen"] = P.sd_checksums(g.state_dict()); out["p3_unet_gen_keys"] = np.array(list(g.state_dict().keys()))
+    torch.manual_seed(0)
+    g = R["p2"].SequenceGenerator(50, 50, 256, 69, 2, 3, "cpu")
+    c = R["p2"].SequenceDiscriminator(69, 128, 120, 25, 3, "cpu")
+    out["p2_gen"] = P.sd_checksums(g.state_dict()); out["p2_critic"] = P.sd_checksums(c.state_dict())
+    out["p2_gen_keys"] = np.array(list(g.state_dict().keys())); out["p2_critic_keys"] = np.array(list(c.state_dict().keys()))
+    torch.manual_seed(0)
+    g = R["p1"].Generator(10, 128, 69, 1)
+    c = R["p1"].Discriminator(69, 128, 1)
+    out["p1_gen"] = P.sd_checksums(g.state_dict()); out["p1_critic"] = P.sd_checksums(c.state_dict())
+    out["p1_gen_keys"] = np.array(list(g.state_dict().keys())); out["p1_critic_keys"] = np.array(list(c.state_dict().keys()))
+    save("init", **out)
+
+
+def main():
+    torch.set_num_threads(8)
+    R = import_reference()
+    case_init(R)
+    case_p1(R)
+    case_p2(R)
+    case_p3(R, "default", "id", False, trace=True)
+    case_p3(R, "default", "tanh", False)
+    case_p3(R, "default", "relu", True)
+    case_p3(R, "wavegan", "id", False, trace=True)
+    case_p3(R, "wavegan", "tanh", True)
+    case_p3(R, "unet", "id", False)
+    case_p3(R, "unet", "id", True, trace=True)
+    case_p3(R, "unet", "id", True, T=300, B=1)
+
+
+if __name__ == "__main__":
+    main()
