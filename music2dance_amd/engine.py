@@ -1,0 +1,277 @@
+"""WGAN-GP training engine: the inner loops of the reference's train scripts
+(phase1/train_wgan-gp.py:79-110, phase2/train.py:135-180, phase3/train.py:186-243) as
+reusable step functions, device-resident and free of per-iteration host syncs.
+
+Results follow the reference's formulation; work the reference computes and discards is
+skipped: the critic-iteration generator forward keeps no autograd graph, the audio branch
+of the phase-3 critic is evaluated once per iteration (SequenceDiscriminator.shared_audio),
+the raw-audio gradient is not formed outside the penalty, and during generator steps the
+critic's parameters are frozen instead of receiving gradients that the next zero_grad
+throws away.
+"""
+import torch
+import torch.optim as optim
+
+from . import ops
+from .dp import GradExchange
+from .losses import gradient_penalty, tv_loss
+
+
+class _Freeze:
+    """Temporarily mark parameters as not requiring grad (generator steps)."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+
+
+class WganGpEngine:
+    """Common machinery: optimisers, n_critic gating, data-parallel gradient exchange with
+    the critic's optimiser step deferred behind the next generator forward."""
+
+    def __init__(self, gen, critic, lr_gen, lr_critic, n_critic_steps, data_parallel=True, fused_adam=None):
+        self.gen, self.critic = gen, critic
+        self.n_critic_steps = int(n_critic_steps)
+        dev = next(critic.parameters()).device
+        kw = {}
+        if fused_adam is None:
+            fused_adam = dev.type == "cuda"
+        if fused_adam:
+            kw["fused"] = True
+        self.optim_critic = optim.Adam(critic.parameters(), lr=lr_critic, **kw)
+        self.optim_gen = optim.Adam(gen.parameters(), lr=lr_gen, **kw)
+        self.total_iterations = 0
+        self.x_critic = GradExchange(critic.parameters()) if data_parallel else None
+        self.x_gen = GradExchange(gen.parameters()) if data_parallel else None
+        self._critic_step_pending = False
+        self.last = {}
+
+    # -- critic optimiser step, possibly deferred so its all-reduce overlaps the next G forward
+    def _finish_critic_step(self):
+        if self._critic_step_pending:
+            if self.x_critic is not None:
+                self.x_critic.finish()
+            self.optim_critic.step()
+            self._critic_step_pending = False
+
+    def _begin_critic_step(self):
+        if self.x_critic is not None and self.x_critic.active:
+            self.x_critic.start()
+            self._critic_step_pending = True
+        else:
+            self.optim_critic.step()
+
+    def _gen_step(self):
+        if self.x_gen is not None:
+            self.x_gen.exchange()
+        self.optim_gen.step()
+
+    def flush(self):
+        self._finish_critic_step()
+
+    def train_step(self, *batch):
+        """One loop body of the reference: a critic iteration, plus a generator iteration every
+        n_critic_steps-th call. Returns a dict of 0-dim device tensors (no host sync)."""
+        self.total_iterations += 1
+        out = self.critic_iteration(*batch)
+        if self.total_iterations % self.n_critic_steps == 0:
+            out.update(self.generator_iteration(*batch))
+        self.last = out
+        return out
+
+
+# =========================================================================================== phase 3
+class Phase3Engine(WganGpEngine):
+    """Audio-conditioned sequence WGAN-GP (phase3/train.py:186-243)."""
+
+    def __init__(self, gen, critic, cfg, ablated=False, **kw):
+        super().__init__(gen, critic, cfg["lr_gen"], cfg["lr_critic"], cfg["n_critic_steps"], **kw)
+        self.gamma, self.beta, self.eta = float(cfg["gamma"]), float(cfg["beta"]), float(cfg["eta"])
+        self.output_size = int(cfg.get("output_size", 69))
+        self.ablated = bool(ablated)
+
+    def _shapes(self, real):
+        B = real.size(0)
+        T = real.numel() // (B * self.output_size)
+        return B, T
+
+    def critic_iteration(self, real, audio, audio_slices):
+        """real (B, T, 69) [any view of B*T*69], audio (B, samples), audio_slices (B, T, window)."""
+        B, T = self._shapes(real)
+        self.optim_critic.zero_grad(set_to_none=True)
+        with torch.no_grad():  # the reference builds and drops this graph (phase3/train.py:195)
+            fake_rows = self.gen(audio_slices, [T] * B)
+        self._finish_critic_step()
+        fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
+        real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
+        audio_c = audio.unsqueeze(1)
+        if self.ablated:
+            gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=False, device=real.device)
+            err_real = self.critic(real_c).mean()
+            err_fake = self.critic(fake).mean()
+            err_critic = err_fake - err_real + self.gamma * gp
+            err_critic.backward()
+        else:
+            with self.critic.shared_audio():
+                gp = gradient_penalty(self.critic, B, real_c, fake, audio_c, is_seq=True, lp=False,
+                                      device=real.device)
+                err_real = self.critic(real_c, audio_c).mean()
+                err_fake = self.critic(fake, audio_c).mean()
+                err_critic = err_fake - err_real + self.gamma * gp
+                with ops.no_input_grad_for(audio_c):
+                    err_critic.backward()
+            audio_c.requires_grad_(False)
+        self._begin_critic_step()
+        return {"loss_critic": err_critic.detach(), "gp": gp.detach(), "w_dist": (err_fake - err_real).detach()}
+
+    def generator_iteration(self, real, audio, audio_slices):
+        B, T = self._shapes(real)
+        self._finish_critic_step()
+        self.optim_gen.zero_grad(set_to_none=True)
+        fake_rows = self.gen(audio_slices, [T] * B)
+        real_rows = real.reshape(B * T, self.output_size)
+        err_l1 = ops.l1_mean(real_rows, fake_rows)
+        fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1)
+        real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
+        audio_c = audio.unsqueeze(1)
+        with _Freeze(self.critic):
+            if self.ablated:
+                with torch.no_grad():
+                    err_real = self.critic(real_c).mean()
+                err_fake = self.critic(fake).mean()
+            else:
+                with self.critic.shared_audio():
+                    with torch.no_grad():
+                        err_real = self.critic(real_c, audio_c).mean()
+                    err_fake = self.critic(fake, audio_c).mean()
+            err_tv = tv_loss(fake)
+            err_gen = err_real - err_fake + self.beta * err_l1 + self.eta * err_tv
+            err_gen.backward()
+        self._gen_step()
+        return {"loss_gen": err_gen.detach(), "l1_loss_train": err_l1.detach()}
+
+
+# =========================================================================================== phase 2
+class Phase2Engine(WganGpEngine):
+    """Unconditional sequence WGAN-LP (phase2/train.py:135-180), with the reference's
+    MultiStepLR schedulers stepped on generator iterations only (:179-180)."""
+
+    def __init__(self, gen, critic, cfg, **kw):
+        super().__init__(gen, critic, cfg["lr_gen"], cfg["lr_critic"], cfg["n_critic_steps"], **kw)
+        self.gamma, self.eta = float(cfg["gamma"]), float(cfg["eta"])
+        self.input_size = int(cfg["input_vector_size"])
+        self.output_size = int(cfg.get("output_size", 69))
+        ms = [10000, 35000, 50000]
+        self.scheduler_critic = optim.lr_scheduler.MultiStepLR(self.optim_critic, milestones=ms, gamma=0.8)
+        self.scheduler_gen = optim.lr_scheduler.MultiStepLR(self.optim_gen, milestones=ms, gamma=0.8)
+        self.host_noise = True  # draw noise on the host generator (matches the CPU reference)
+
+    def _noise(self, B, T, device):
+        if self.host_noise:
+            return torch.randn(B, T, self.input_size).to(device)
+        return torch.randn(B, T, self.input_size, device=device)
+
+    def critic_iteration(self, real):
+        B = real.size(0)
+        T = real.numel() // (B * self.output_size)
+        self.optim_critic.zero_grad(set_to_none=True)
+        noise = self._noise(B, T, real.device)
+        with torch.no_grad():
+            fake_rows = self.gen(noise, [T] * B)
+        self._finish_critic_step()
+        fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
+        real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
+        gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=True, device=real.device)
+        err_real = self.critic(real_c).mean()
+        err_fake = self.critic(fake).mean()
+        err_critic = err_fake - err_real + self.gamma * gp
+        err_critic.backward()
+        self._begin_critic_step()
+        return {"loss_critic": err_critic.detach(), "gp": gp.detach(), "w_dist": (err_fake - err_real).detach()}
+
+    def generator_iteration(self, real):
+        B = real.size(0)
+        T = real.numel() // (B * self.output_size)
+        self._finish_critic_step()
+        self.optim_gen.zero_grad(set_to_none=True)
+        noise = self._noise(B, T, real.device)
+        fake = self.gen(noise, [T] * B).view(B, T, self.output_size).permute(0, 2, 1)
+        real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
+        with _Freeze(self.critic):
+            with torch.no_grad():
+                err_real = self.critic(real_c).mean()
+            err_fake = self.critic(fake).mean()
+            err_gen = err_real - err_fake + self.eta * tv_loss(fake)
+            err_gen.backward()
+        self._gen_step()
+        self.scheduler_critic.step()
+        self.scheduler_gen.step()
+        return {"loss_gen": err_gen.detach()}
+
+
+# =========================================================================================== phase 1
+class Phase1Engine(WganGpEngine):
+    """Still-pose WGAN-GP (phase1/train_wgan-gp.py:79-110). Dropout stays active in both
+    networks during every pass, as in the reference (it never calls .eval())."""
+
+    def __init__(self, gen, critic, cfg, **kw):
+        super().__init__(gen, critic, cfg["lr_gen"], cfg["lr_critic"], cfg["n_critic_steps"], **kw)
+        self.gamma = float(cfg["gamma"])
+        self.latent = int(cfg["latent_vector_size"])
+        self.host_noise = True
+
+    def _noise(self, B, device):
+        if self.host_noise:
+            return torch.randn(B, self.latent).to(device)
+        return torch.randn(B, self.latent, device=device)
+
+    def critic_iteration(self, real):
+        B = real.size(0)
+        self.optim_critic.zero_grad(set_to_none=True)
+        noise = self._noise(B, real.device)
+        with torch.no_grad():
+            fake = self.gen(noise)
+        self._finish_critic_step()
+        gp = gradient_penalty(self.critic, B, real, fake, device=real.device)
+        err_real = self.critic(real).mean()
+        err_fake = self.critic(fake).mean()
+        err_critic = err_fake - err_real + self.gamma * gp
+        err_critic.backward()
+        self._begin_critic_step()
+        return {"loss_critic": err_critic.detach(), "gp": gp.detach(), "w_dist": (err_fake - err_real).detach()}
+
+    def generator_iteration(self, real):
+        B = real.size(0)
+        self._finish_critic_step()
+        self.optim_gen.zero_grad(set_to_none=True)
+        fake = self.gen(self._noise(B, real.device))
+        with _Freeze(self.critic):
+            # the critic's dropout draws one mask per call, real first (train_wgan-gp.py:100-101)
+            with torch.no_grad():
+                err_real = self.critic(real).mean()
+            err_fake = self.critic(fake).mean()
+            err_gen = err_real - err_fake
+            err_gen.backward()
+        self._gen_step()
+        return {"loss_gen": err_gen.detach()}
+
+
+# =========================================================================================== synthetic data
+def synthetic_phase3_batch(B, T, device, seed=0, audio_rate=16000, video_rate=25, window_s=0.2):
+    """Random poses / audio of the dataset's shapes: poses U[0,1) (B, T, 69),
+    audio N(0, 0.1^2) (B, T*640), windows of 3200 samples every 640."""
+    from .utils import slice_audio_batch
+    g = torch.Generator().manual_seed(seed)
+    hop = audio_rate // video_rate
+    window = int(window_s * audio_rate)
+    real = torch.rand(B, T, 69, generator=g).to(device)
+    audio = (0.1 * torch.randn(B, hop * T, generator=g)).to(device)
+    slices = slice_audio_batch(audio, window, hop, window - hop)
+    return real, audio, slices

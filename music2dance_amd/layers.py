@@ -1,0 +1,103 @@
+"""Parameter holders with the reference's names and initialisation, HIP forward.
+
+Each class subclasses the torch.nn module the reference instantiates, so construction
+consumes the RNG identically (seeded-constructor parity) and
+state_dict keys / shapes are the reference's; only `forward` differs: it
+dispatches to the gfx950 kernels through ops.py and can fuse the following activation.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Conv1d(nn.Conv1d):
+    """nn.Conv1d (dilation 1, groups 1, zero padding) on the implicit-GEMM engine."""
+
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0):
+        if self.dilation[0] != 1 or self.groups != 1 or self.padding_mode != "zeros":
+            raise NotImplementedError("m2d Conv1d: dilation / groups / non-zero padding are not on the hot path")
+        return ops.conv1d(x, self.weight, self.bias, self.stride[0], self.padding[0], act, slope)
+
+
+class Linear(nn.Linear):
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0):
+        return ops.linear(x, self.weight, self.bias, act, slope)
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d on (N, C) / (N, C, L) with the following ReLU / LeakyReLU and an
+    optional residual add fused into the normalisation pass."""
+
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0, residual=None):
+        if self.momentum is None or not self.affine or not self.track_running_stats:
+            raise NotImplementedError("m2d BatchNorm1d: only the reference's configuration is supported")
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                              self.eps, self.momentum, act, slope, residual)
+
+    @torch.no_grad()
+    def observe(self, x):
+        """Advance the running statistics with a batch without producing an output graph
+        (the dead fc1 -> bn1 branch of LinearBlock, phase3/archis/default.py:184-187)."""
+        if self.training:
+            self.num_batches_tracked.add_(1)
+            ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, True, self.eps,
+                           self.momentum)
+
+
+class GRU(nn.GRU):
+    """nn.GRU(batch_first=True, unidirectional, no dropout): per layer one input-projection
+    GEMM for all time steps, then the recurrent step kernels. Accepts a dense (B, T, in)
+    tensor plus optional per-sequence lengths (the reference's packed input with equal
+    lengths is bit-identical to the dense one)."""
+
+    def forward(self, x, lengths=None):
+        if not self.batch_first or self.bidirectional or self.dropout != 0.0 or not self.bias:
+            raise NotImplementedError("m2d GRU: only batch_first / unidirectional / no-dropout is supported")
+        out = x
+        for layer in range(self.num_layers):
+            out = ops.gru_layer(out, getattr(self, "weight_ih_l%d" % layer), getattr(self, "weight_hh_l%d" % layer),
+                                getattr(self, "bias_ih_l%d" % layer), getattr(self, "bias_hh_l%d" % layer), lengths)
+        return out, None
+
+
+def lengths_tensor(lengths, T, device):
+    """None when every sequence is full length (the training case), else an int32 tensor."""
+    if lengths is None:
+        return None
+    ls = [int(v) for v in lengths]
+    if all(v == T for v in ls):
+        return None
+    return torch.tensor(ls, dtype=torch.int32, device=device)
+
+
+class Dropout(nn.Dropout):
+    """nn.Dropout whose Bernoulli keep-mask can come from the HOST generator: the
+    reference's CPU path draws `empty_like(x).bernoulli_(1-p)` from the default CPU RNG,
+    and with `host_rng=True` (default) this layer consumes that stream identically, so
+    seeded runs match the reference's CPU results. `host_rng=False` draws on the device."""
+
+    host_rng = True
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        if self.host_rng:
+            keep = torch.empty(x.shape, dtype=x.dtype).bernoulli_(1.0 - self.p).to(x.device)
+        else:
+            keep = torch.empty_like(x).bernoulli_(1.0 - self.p)
+        return x * keep * (1.0 / (1.0 - self.p))
+
+
+def head_activation(kind):
+    """The reference's 'id' | 'relu' | 'tanh' switch -> (module kept for state/print parity,
+    fused act code, needs_tanh)."""
+    if kind == "id":
+        return nn.Identity(), ops.ACT_NONE, False
+    if kind == "relu":
+        return nn.ReLU(True), ops.ACT_RELU, False
+    if kind == "tanh":
+        return nn.Tanh(), ops.ACT_NONE, True
+    raise ValueError("unknown activation %r" % (kind,))

@@ -1,0 +1,438 @@
+"""Differentiable ops on top of the raw HIP kernels (kernels.py).
+
+The gradient penalty differentiates the critic's input-gradient a second time
+(losses.py:40-44 of the reference), so the critic ops are written as a set that is
+closed under differentiation:
+
+    conv1d(x, W)            backward = bwd_data(gy, W),  bwd_weight(x, gy)
+    bwd_data(gy, W)         backward = conv1d(g, W) [d/d gy],  bwd_weight(g, gy) [d/d W]
+    bwd_weight(x, gy)       backward = bwd_data(gy, g) [d/d x], conv1d(x, g) [d/d gy]
+
+and the same triangle for linear layers (GEMM NT / NN / TN). Each backward is itself
+built from these Functions, so `create_graph=True` records the second-order graph. The
+fused activation (ReLU / LeakyReLU) is piecewise linear: its derivative is a mask that the
+kernels apply while loading an operand or storing the result, so neither order of
+derivative needs an extra elementwise pass over HBM.
+
+Generator-only ops (BatchNorm, GRU, pooling, losses) are first-order.
+"""
+import contextlib
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import kernels
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def K():
+    return kernels.impl()
+
+
+# ---------------------------------------------------------------------------------------
+# backward-pass pruning switches (results are unchanged; they only skip work whose result
+# the caller discards)
+_state = {"inputs_only": False, "dead_inputs": set()}
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Inside: backward passes compute gradients w.r.t. op INPUTS only (weight and bias
+    gradients return None). Used for the gradient penalty's first backward, which asks
+    for d critic / d input only (losses.py:40-44); weights still receive their gradient
+    through the double-backward graph."""
+    prev = _state["inputs_only"]
+    _state["inputs_only"] = True
+    try:
+        yield
+    finally:
+        _state["inputs_only"] = prev
+
+
+@contextlib.contextmanager
+def no_input_grad_for(*tensors):
+    """Inside: ops whose input is one of `tensors` (matched by storage address) do not
+    compute that input's gradient. The training engine uses it for the raw audio, whose
+    gradient the reference computes and throws away."""
+    keys = {t.data_ptr() for t in tensors if t is not None}
+    prev = _state["dead_inputs"]
+    _state["dead_inputs"] = prev | keys
+    try:
+        yield
+    finally:
+        _state["dead_inputs"] = prev
+
+
+def _mask_of(act, slope, y):
+    if act == ACT_NONE:
+        return None, 0.0
+    return y, (slope if act == ACT_LEAKY else 0.0)
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------- conv1d
+class _Conv1dAct(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, slope):
+        x, w, b = _c(x), _c(w), _c(b)
+        y = K().conv1d_fwd(x, w, b, stride, pad, act, slope)
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.cfg = (stride, pad, act, slope, b is not None, x.data_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, slope, has_bias, xkey = ctx.cfg
+        mask, mslope = _mask_of(act, slope, y)
+        gy = _c(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0] and xkey not in _state["dead_inputs"]:
+            gx = _Conv1dBwdData.apply(gy, w, mask, x.shape[2], stride, pad, mslope)
+        if not _state["inputs_only"]:
+            if ctx.needs_input_grad[1]:
+                gw = _Conv1dBwdWeight.apply(x, gy, mask, w.shape[2], stride, pad, mslope)
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = _ChannelSum.apply(gy, mask, mslope)
+        return gx, gw, gb, None, None, None, None
+
+
+class _Conv1dBwdData(Function):
+    """dx = conv_transpose(gy * act'(y), W). Differentiable w.r.t. gy and W."""
+
+    @staticmethod
+    def forward(ctx, gy, w, mask, L, stride, pad, mslope):
+        gy, w = _c(gy), _c(w)
+        dx = K().conv1d_bwd_data(gy, w, L, stride, pad, mask, mslope)
+        ctx.save_for_backward(gy, w, mask)
+        ctx.cfg = (stride, pad, mslope)
+        return dx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        gy, w, mask = ctx.saved_tensors
+        stride, pad, mslope = ctx.cfg
+        g = _c(g)
+        g_gy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_gy = K().conv1d_fwd(g, w, None, stride, pad, 0, 0.0, None, mask, mslope)
+        if ctx.needs_input_grad[1]:
+            g_w = K().conv1d_bwd_weight(g, gy, w.shape[2], stride, pad, mask, mslope)
+        return g_gy, g_w, None, None, None, None, None
+
+
+class _Conv1dBwdWeight(Function):
+    """dW = correlate(x, gy * act'(y)). Differentiable w.r.t. x and gy."""
+
+    @staticmethod
+    def forward(ctx, x, gy, mask, ks, stride, pad, mslope):
+        x, gy = _c(x), _c(gy)
+        dw = K().conv1d_bwd_weight(x, gy, ks, stride, pad, mask, mslope)
+        ctx.save_for_backward(x, gy, mask)
+        ctx.cfg = (stride, pad, mslope)
+        return dw
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, gy, mask = ctx.saved_tensors
+        stride, pad, mslope = ctx.cfg
+        g = _c(g)
+        g_x = g_gy = None
+        if ctx.needs_input_grad[0]:
+            g_x = K().conv1d_bwd_data(gy, g, x.shape[2], stride, pad, mask, mslope)
+        if ctx.needs_input_grad[1]:
+            g_gy = K().conv1d_fwd(x, g, None, stride, pad, 0, 0.0, None, mask, mslope)
+        return g_x, g_gy, None, None, None, None, None
+
+
+class _ChannelSum(Function):
+    """sum over (batch, length) of gy * act'(y): bias gradients."""
+
+    @staticmethod
+    def forward(ctx, gy, mask, mslope):
+        gy = _c(gy)
+        ctx.save_for_backward(mask)
+        ctx.mslope = mslope
+        ctx.shape = gy.shape
+        return K().channel_sums(gy, mask, mslope)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        shape = ctx.shape
+        view = (1, -1, 1) if len(shape) == 3 else (1, -1)
+        out = g.view(view).expand(shape)
+        if mask is not None:
+            out = out * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, ctx.mslope))
+        return out.contiguous(), None, None
+
+
+def conv1d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0):
+    """nn.Conv1d forward with optional fused ReLU / LeakyReLU, twice differentiable."""
+    return _Conv1dAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope))
+
+
+# --------------------------------------------------------------------------------------- linear
+class _LinearAct(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        x, w, b = _c(x), _c(w), _c(b)
+        y = K().gemm(0, x, w, b, act, slope)
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.cfg = (act, slope, b is not None, x.data_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        act, slope, has_bias, xkey = ctx.cfg
+        mask, mslope = _mask_of(act, slope, y)
+        gy = _c(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0] and xkey not in _state["dead_inputs"]:
+            gx = _LinearBwdData.apply(gy, w, mask, mslope)
+        if not _state["inputs_only"]:
+            if ctx.needs_input_grad[1]:
+                gw = _LinearBwdWeight.apply(gy, x, mask, mslope)
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = _ChannelSum.apply(gy, mask, mslope)
+        return gx, gw, gb, None, None
+
+
+class _LinearBwdData(Function):
+    """dx = (gy * act'(y)) W."""
+
+    @staticmethod
+    def forward(ctx, gy, w, mask, mslope):
+        gy, w = _c(gy), _c(w)
+        ctx.save_for_backward(gy, w, mask)
+        ctx.mslope = mslope
+        return K().gemm(1, gy, w, a_mask=mask, a_mask_slope=mslope)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        gy, w, mask = ctx.saved_tensors
+        g = _c(g)
+        g_gy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_gy = K().gemm(0, g, w, out_mask=mask, out_mask_slope=ctx.mslope)
+        if ctx.needs_input_grad[1]:
+            g_w = K().gemm(2, gy, g, a_mask=mask, a_mask_slope=ctx.mslope)
+        return g_gy, g_w, None, None
+
+
+class _LinearBwdWeight(Function):
+    """dW = (gy * act'(y))^T x."""
+
+    @staticmethod
+    def forward(ctx, gy, x, mask, mslope):
+        gy, x = _c(gy), _c(x)
+        ctx.save_for_backward(gy, x, mask)
+        ctx.mslope = mslope
+        return K().gemm(2, gy, x, a_mask=mask, a_mask_slope=mslope)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        gy, x, mask = ctx.saved_tensors
+        g = _c(g)
+        g_gy = g_x = None
+        if ctx.needs_input_grad[0]:
+            g_gy = K().gemm(0, x, g, out_mask=mask, out_mask_slope=ctx.mslope)
+        if ctx.needs_input_grad[1]:
+            g_x = K().gemm(1, gy, g, a_mask=mask, a_mask_slope=ctx.mslope)
+        return g_gy, g_x, None, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
+    """nn.Linear forward (x: (N, in)) with optional fused activation, twice differentiable."""
+    if x.dim() != 2:
+        lead = x.shape[:-1]
+        return linear(x.reshape(-1, x.shape[-1]), weight, bias, act, slope).view(*lead, weight.shape[0])
+    return _LinearAct.apply(x, weight, bias, int(act), float(slope))
+
+
+# --------------------------------------------------------------------------------------- batch norm
+class _BatchNormAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, eps, momentum, act, slope):
+        x, residual = _c(x), _c(residual)
+        y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, training, eps, momentum, act,
+                                     slope, residual)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.cfg = (training, act, slope, residual is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        training, act, slope, has_res = ctx.cfg
+        if not training:
+            raise NotImplementedError("m2d BatchNorm: backward in eval mode is not part of the training path")
+        gy = _c(gy)
+        dx, dgamma, dbeta = K().bn_bwd(gy, x, gamma, beta, mean, invstd, act, slope)
+        return dx, dgamma, dbeta, None, None, (gy if has_res else None), None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=ACT_NONE,
+               slope=0.0, residual=None):
+    """y = residual + act(batch_norm(x)); running buffers are updated in place when training."""
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps),
+                               float(momentum), int(act), float(slope))
+
+
+# --------------------------------------------------------------------------------------- GRU
+class _GRULayer(Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, lengths, save):
+        x, w_ih, w_hh = _c(x), _c(w_ih), _c(w_hh)
+        B, T, I = x.shape
+        H = w_hh.shape[1]
+        k = K()
+        gi = k.gemm(0, x.view(B * T, I), w_ih, b_ih).view(B, T, 3 * H)
+        out, saved = k.gru_layer_fwd(gi, w_hh.t().contiguous(), b_hh, lengths, save)
+        if save:
+            ctx.save_for_backward(x, w_ih, w_hh, out, saved, lengths)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, w_ih, w_hh, out, saved, lengths = ctx.saved_tensors
+        B, T, I = x.shape
+        H = w_hh.shape[1]
+        k = K()
+        dgi, dgh = k.gru_layer_bwd(_c(dout), out, saved, w_hh, lengths)
+        dgi2, dgh2 = dgi.view(B * T, 3 * H), dgh.view(B * T, 3 * H)
+        dx = k.gemm(1, dgi2, w_ih).view(B, T, I) if ctx.needs_input_grad[0] else None
+        dw_ih = k.gemm(2, dgi2, x.view(B * T, I))
+        hprev = torch.cat((out.new_zeros(B, 1, H), out[:, :-1]), 1).contiguous().view(B * T, H)
+        dw_hh = k.gemm(2, dgh2, hprev)
+        db_ih = k.channel_sums(dgi2.view(B * T, 3 * H, 1))
+        db_hh = k.channel_sums(dgh2.view(B * T, 3 * H, 1))
+        return dx, dw_ih, dw_hh, db_ih, db_hh, None, None
+
+
+def gru_layer(x, w_ih, w_hh, b_ih, b_hh, lengths=None):
+    """One nn.GRU layer (batch_first, h0 = 0) over a whole (B, T, in) sequence."""
+    save = torch.is_grad_enabled() and any(t.requires_grad for t in (x, w_ih, w_hh, b_ih, b_hh))
+    return _GRULayer.apply(x, w_ih, w_hh, b_ih, b_hh, lengths, save)
+
+
+# --------------------------------------------------------------------------------------- GP
+def gp_interpolate(real2d, fake2d, alpha):
+    """alpha*real + (1-alpha)*fake on detached inputs (losses.py:20); alpha: (B,)."""
+    return K().gp_interpolate(_c(real2d.detach()), _c(fake2d.detach()), _c(alpha))
+
+
+class _GPPenalty(Function):
+    @staticmethod
+    def forward(ctx, g, lp):
+        g = _c(g)
+        pen, norms = K().gp_penalty_fwd(g, lp)
+        ctx.save_for_backward(g, norms)
+        ctx.lp = lp
+        return pen
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        g, norms = ctx.saved_tensors
+        return K().gp_penalty_bwd(g, norms, _c(gout), ctx.lp), None
+
+
+def gp_penalty(grad2d, lp=False):
+    """mean_b (||g_b||_2 - 1)^2 (GP, eps 1e-12 inside the sqrt) or mean_b max(0, ||g_b|| - 1)^2 (LP)."""
+    return _GPPenalty.apply(grad2d, bool(lp))
+
+
+# --------------------------------------------------------------------------------------- losses
+class _L1Mean(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        return K().l1_mean_fwd(a, b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        gout = _c(gout)
+        ga = K().l1_mean_bwd(a, b, gout) if ctx.needs_input_grad[0] else None
+        gb = -K().l1_mean_bwd(a, b, gout) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def l1_mean(a, b):
+    """torch.nn.L1Loss(reduction='mean')(a, b); both tensors must share one memory layout."""
+    return _L1Mean.apply(a, b)
+
+
+class _TVMean(Function):
+    @staticmethod
+    def forward(ctx, store, B, C, T, sb, sc, st):
+        ctx.save_for_backward(store)
+        ctx.cfg = (B, C, T, sb, sc, st)
+        return K().tv_mean_fwd(store, B, C, T, sb, sc, st)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (store,) = ctx.saved_tensors
+        return (K().tv_mean_bwd(store, _c(gout), *ctx.cfg),) + (None,) * 6
+
+
+def tv_mean(seq):
+    """mean |x[:, :, 1:] - x[:, :, :-1]| of a (B, C, T) tensor or permuted view of a dense one."""
+    B, C, T = seq.shape
+    if seq.is_contiguous():
+        return _TVMean.apply(seq, B, C, T, C * T, T, 1)
+    base = seq.permute(0, 2, 1)
+    if base.is_contiguous():  # (B, T, C) storage viewed as (B, C, T): the generator's native layout
+        return _TVMean.apply(base, B, C, T, T * C, 1, C)
+    return tv_mean(seq.contiguous())
+
+
+# --------------------------------------------------------------------------------------- U-Net resampling
+class _MaxPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return K().maxpool2_fwd(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return K().maxpool2_bwd(x, _c(gy))
+
+
+class _Upsample2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return K().upsample2_fwd(_c(x))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        return K().upsample2_bwd(_c(gy))
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+def upsample2_linear(x):
+    return _Upsample2.apply(x)

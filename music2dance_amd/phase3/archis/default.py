@@ -1,0 +1,340 @@
+"""Phase-3 audio-conditioned generator and critics on the gfx950 kernels.
+
+Constructor signatures, attribute names and state_dict keys follow the reference
+(phase3/archis/default.py:6-355) so checkpoints and train scripts are interchangeable;
+forward passes launch fused conv(+bias+ReLU), BatchNorm(+ReLU / LeakyReLU), GEMM and GRU
+step kernels.
+
+One addition: `SequenceDiscriminator.shared_audio()`. The audio branch of the critic sees
+the same, never-interpolated audio in the gradient-penalty, real and fake passes of an
+iteration (losses.py:29, phase3/train.py:204-211), so inside that context its code is
+computed once and shared (identical scores).
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...layers import GRU, BatchNorm1d, Conv1d, Linear, head_activation, lengths_tensor
+from ...utils import initialize_weights
+
+
+def _descending(lengths):
+    ls = [int(v) for v in lengths]
+    if any(a < b for a, b in zip(ls, ls[1:])):
+        raise RuntimeError("`lengths` array must be sorted in decreasing order")
+    return ls
+
+
+def _head(module, conv, x):
+    """last conv of an encoder / critic branch followed by the 'id'|'relu'|'tanh' switch"""
+    y = conv(x, act=module._head_act)
+    return torch.tanh(y) if module._head_tanh else y
+
+
+class NoiseGen(nn.Module):
+    def __init__(self, input_size, output_size, n_layers):
+        super().__init__()
+        self.rnn = GRU(input_size, output_size, n_layers, batch_first=True)
+
+    def forward(self, x, lengths=None):
+        return self.rnn(x, lengths)[0]
+
+
+class LinearBlock(nn.Module):
+    """x + relu(bn2(fc2(x))); fc1 / bn1 are the reference's dead branch
+    (phase3/archis/default.py:183-192): only bn1's running statistics observe it."""
+
+    def __init__(self, size, use_bn=False):
+        super().__init__()
+        self.size = size
+        self.use_bn = use_bn
+        self.fc1 = Linear(size, size, bias=True)
+        self.fc2 = Linear(size, size, bias=True)
+        if use_bn:
+            self.bn1 = BatchNorm1d(size, eps=1e-5, momentum=0.1)
+            self.bn2 = BatchNorm1d(size, eps=1e-5, momentum=0.1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        if not self.use_bn:
+            return x + self.fc2(x, act=ops.ACT_RELU)
+        if self.training:
+            with torch.no_grad():
+                self.bn1.observe(self.fc1(x.detach()))
+        return self.bn2(self.fc2(x), act=ops.ACT_RELU, residual=x)
+
+
+class FrameDecoder(nn.Module):
+    def __init__(self, latent_size, size, output_size, nblocks):
+        super().__init__()
+        self.latent_size, self.size, self.output_size, self.nblocks = latent_size, size, output_size, nblocks
+        self.fc1 = Linear(latent_size, size)
+        self.bn1 = BatchNorm1d(size, eps=1e-5, momentum=0.1)
+        self.relu = nn.ReLU(inplace=True)
+        self.blocks = nn.Sequential(*[LinearBlock(size, use_bn=True) for _ in range(nblocks)])
+        self.lastfc = Linear(size, output_size)
+
+    def forward(self, x):
+        h = self.bn1(self.fc1(x), act=ops.ACT_RELU)
+        return self.lastfc(self.blocks(h))
+
+
+class TemporalBlock(nn.Module):
+    def __init__(self, channels, ksize):
+        super().__init__()
+        self.channels, self.ksize = channels, ksize
+        self.pad = int((ksize - 1) / 2)
+        self.conv1 = Conv1d(channels, channels, kernel_size=ksize, padding=self.pad, dilation=1)
+        self.conv2 = Conv1d(channels, channels, kernel_size=ksize, padding=self.pad, dilation=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        h = self.conv2(self.conv1(x, act=ops.ACT_RELU), act=ops.ACT_RELU)
+        return x + h
+
+
+# --------------------------------------------------------------------------------------- encoders
+class DefaultAudioEncoder(nn.Module):
+    """3200-sample window -> code: conv(k250,s50) then five stride-2 convs, each followed by
+    BatchNorm + ReLU, and a k=2 head (phase3/archis/default.py:59-82)."""
+
+    def __init__(self, f_maps, output_size, activ="id"):
+        super().__init__()
+        self.conv_layers = nn.ModuleList()
+        self.activations = nn.ModuleList()
+        self.conv_layers.append(Conv1d(1, f_maps, 250, 50, 124))
+        self.activations.append(nn.Sequential(BatchNorm1d(f_maps), nn.ReLU(True)))
+        for _ in range(5):
+            self.conv_layers.append(Conv1d(f_maps, f_maps * 2, 4, 2, 1))
+            self.activations.append(nn.Sequential(BatchNorm1d(f_maps * 2), nn.ReLU(True)))
+            f_maps *= 2
+        self.conv_layers.append(Conv1d(f_maps, output_size, 2))
+        mod, self._head_act, self._head_tanh = head_activation(activ)
+        self.activations.append(mod)
+
+    def forward(self, x):
+        for conv, post in zip(self.conv_layers[:-1], self.activations[:-1]):
+            x = post[0](conv(x), act=ops.ACT_RELU)
+        return _head(self, self.conv_layers[-1], x).squeeze()
+
+
+class BasisConvBlock(nn.Module):
+    def __init__(self, channels_in, channels_out):
+        super().__init__()
+        self.conv = Conv1d(channels_in, channels_out, 3, 1, 1)
+        self.bn = BatchNorm1d(channels_out)
+        self.relu = nn.LeakyReLU(0.2)
+
+    def forward(self, x):
+        return self.bn(self.conv(x), act=ops.ACT_LEAKY, slope=0.2)
+
+
+class UBlock(nn.Module):
+    """Four-level 1-D U-Net: conv blocks, MaxPool(2,2) down, linear x2 upsampling + skip concat up."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.convblock1 = BasisConvBlock(channels, channels)
+        self.convblock2 = BasisConvBlock(channels, channels)
+        self.convblock3 = BasisConvBlock(channels, channels)
+        self.convblock4 = BasisConvBlock(channels, channels)
+        self.convblock5 = BasisConvBlock(channels * 2, channels)
+        self.convblock6 = BasisConvBlock(channels * 2, channels)
+        self.convblock7 = BasisConvBlock(channels * 2, channels)
+        self.downsample = nn.MaxPool1d(2, 2)
+        self.upsample = nn.Upsample(scale_factor=2, mode="linear", align_corners=False)
+
+    def forward(self, x):
+        d1 = self.convblock1(x)
+        d2 = self.convblock2(ops.maxpool2(d1))
+        d3 = self.convblock3(ops.maxpool2(d2))
+        d4 = self.convblock4(ops.maxpool2(d3))
+        u3 = self.convblock5(torch.cat((ops.upsample2_linear(d4), d3), 1))
+        u2 = self.convblock6(torch.cat((ops.upsample2_linear(u3), d2), 1))
+        return self.convblock7(torch.cat((ops.upsample2_linear(u2), d1), 1))
+
+
+class UNetAudioEncoder(nn.Module):
+    def __init__(self, f_maps, output_size, activ="id"):
+        super().__init__()
+        self.conv_layers = nn.ModuleList()
+        self.activations = nn.ModuleList()
+        self.conv_layers.append(Conv1d(1, f_maps, 160, 4, 79))
+        self.activations.append(nn.Sequential(BatchNorm1d(f_maps), nn.LeakyReLU(0.2)))
+        for _ in range(2):
+            self.conv_layers.append(Conv1d(f_maps, f_maps * 2, 4, 2, 1))
+            self.activations.append(nn.Sequential(BatchNorm1d(f_maps * 2), nn.LeakyReLU(0.2)))
+            f_maps *= 2
+        self.ublock = UBlock(f_maps)
+        self.fc = Conv1d(f_maps, output_size, 200)
+        self.activ, self._head_act, self._head_tanh = head_activation(activ)
+
+    def forward(self, x):
+        for conv, post in zip(self.conv_layers, self.activations):
+            x = post[0](conv(x), act=ops.ACT_LEAKY, slope=0.2)
+        return _head(self, self.fc, self.ublock(x)).squeeze()
+
+
+class WaveGANAudioEncoder(nn.Module):
+    def __init__(self, f_maps, output_size, activ="id"):
+        super().__init__()
+        self.l1 = Conv1d(1, f_maps, 25, stride=4)
+        self.bn1 = BatchNorm1d(f_maps)
+        self.l2 = Conv1d(f_maps, f_maps * 2, 25, stride=4)
+        f_maps *= 2
+        self.bn2 = BatchNorm1d(f_maps)
+        self.l3 = Conv1d(f_maps, f_maps * 2, 25, stride=4)
+        f_maps *= 2
+        self.bn3 = BatchNorm1d(f_maps)
+        self.l4 = Conv1d(f_maps, f_maps * 2, 25, stride=4)
+        f_maps *= 2
+        self.bn4 = BatchNorm1d(f_maps)
+        self.l5 = Conv1d(f_maps, output_size, 5)
+        self.relu = nn.ReLU(True)
+        self.activ, self._head_act, self._head_tanh = head_activation(activ)
+
+    def forward(self, x):
+        for conv, bn in ((self.l1, self.bn1), (self.l2, self.bn2), (self.l3, self.bn3), (self.l4, self.bn4)):
+            x = bn(conv(x), act=ops.ACT_RELU)
+        return _head(self, self.l5, x).squeeze(-1)
+
+
+class AudioEncoder(nn.Module):
+    def __init__(self, type, f_maps, output_size, activ="id"):
+        super().__init__()
+        if type == "default":
+            self.model = DefaultAudioEncoder(f_maps, output_size, activ)
+        elif type == "unet":
+            self.model = UNetAudioEncoder(f_maps, output_size, activ)
+        elif type == "wavegan":
+            self.model = WaveGANAudioEncoder(f_maps, output_size, activ)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+# --------------------------------------------------------------------------------------- generator
+class SequenceGenerator(nn.Module):
+    """audio windows -> per-frame code (encoder) -> GRU(+ noise GRU) -> per-frame pose decoder."""
+
+    def __init__(self, window_size, input_size, latent_size, size, output_size, noise_size, n_blocks,
+                 n_cells=1, enc_type="default", activ="id", device="cpu"):
+        super().__init__()
+        self.window_size, self.input_size, self.latent_size = window_size, input_size, latent_size
+        self.size, self.noise_size, self.output_size = size, noise_size, output_size
+        self.device = device
+        self.audio_enc = AudioEncoder(enc_type, 32, input_size, activ)
+        self.audio_rnn = NoiseGen(input_size, latent_size - noise_size, n_cells)
+        self.noise_gen = NoiseGen(noise_size, noise_size, 1)
+        self.decoder = FrameDecoder(latent_size, size, output_size, n_blocks)
+        initialize_weights(self)
+        self.to(device)
+
+    def forward(self, x, lengths, noise=None):
+        # x: (batch, frames, window)
+        frames = x.size(1)
+        code = self.audio_enc(x.reshape(-1, 1, self.window_size)).view(-1, frames, self.input_size)
+        if noise is None:
+            # drawn from the HOST generator, then moved (phase3/archis/default.py:31-34)
+            noise = torch.randn(list(code.size()[:-1]) + [self.noise_size]).to(code.device)
+        ls = _descending(lengths)
+        h = self.audio_rnn(code, lengths_tensor(ls, frames, code.device))[:, :max(ls)]
+        n = self.noise_gen(noise)
+        latent = torch.cat((h, n), -1)
+        return self.decoder(latent.reshape(-1, self.decoder.latent_size))
+
+
+# --------------------------------------------------------------------------------------- critics
+class StickDiscriminator(nn.Module):
+    """Pose branch: conv(k=init_ker)+ReLU, n_blocks TemporalBlocks, full-length conv -> code."""
+
+    def __init__(self, channels_in, channels_h, output_code, seqlen, init_ker=9, n_blocks=2, activ="id"):
+        super().__init__()
+        self.conv1 = Conv1d(channels_in, channels_h, kernel_size=init_ker, padding=int((init_ker - 1) / 2))
+        self.blocks = nn.Sequential(*[TemporalBlock(channels_h, 7) for _ in range(n_blocks)])
+        self.fconv = Conv1d(channels_h, output_code, seqlen)
+        self.relu = nn.ReLU(inplace=True)
+        self.activ, self._head_act, self._head_tanh = head_activation(activ)
+
+    def forward(self, x):
+        h = self.blocks(self.conv1(x, act=ops.ACT_RELU))
+        return _head(self, self.fconv, h).squeeze(-1)
+
+
+class AudioDiscriminator(nn.Module):
+    """Raw-audio branch: five k=25 stride-4 convs + ReLU, then a k=75 conv -> code (76 800 samples only)."""
+
+    def __init__(self, output_size, activ="id"):
+        super().__init__()
+        pad = 11
+        self.l1 = Conv1d(1, 32, 25, stride=4, padding=pad)
+        self.l2 = Conv1d(32, 64, 25, stride=4, padding=pad)
+        self.l3 = Conv1d(64, 128, 25, stride=4, padding=pad)
+        self.l4 = Conv1d(128, 256, 25, stride=4, padding=pad)
+        self.l5 = Conv1d(256, 512, 25, stride=4, padding=pad)
+        self.l6 = Conv1d(512, output_size, 75)
+        self.relu = nn.ReLU(True)
+        self.activ, self._head_act, self._head_tanh = head_activation(activ)
+
+    def forward(self, x):
+        for conv in (self.l1, self.l2, self.l3, self.l4, self.l5):
+            x = conv(x, act=ops.ACT_RELU)
+        return _head(self, self.l6, x).squeeze(-1)
+
+
+class SequenceDiscriminator(nn.Module):
+    def __init__(self, channels_in, channels_h, output_code, seqlen, init_ker=9, activ="id", device="cpu"):
+        super().__init__()
+        self.stick_d = StickDiscriminator(channels_in, channels_h, output_code, seqlen, init_ker=init_ker,
+                                          activ=activ)
+        self.audio_d = AudioDiscriminator(output_code, activ)
+        self.fc1 = Linear(2 * output_code, 128)
+        self.fc2 = Linear(128, 1)
+        self.relu = nn.ReLU(True)
+        initialize_weights(self)
+        self.to(device)
+        self._share = None
+
+    @contextlib.contextmanager
+    def shared_audio(self):
+        """Within the context, repeated calls with the SAME audio tensor object reuse one
+        audio_d(audio) evaluation (and one backward through it)."""
+        prev = self._share
+        self._share = {}
+        try:
+            yield self
+        finally:
+            self._share = prev
+
+    def _audio_code(self, c):
+        if self._share is None:
+            return self.audio_d(c)
+        key = (id(c), c._version, c.requires_grad)
+        hit = self._share.get(key)
+        if hit is None:
+            hit = (c, self.audio_d(c))  # keep `c` alive so id() stays unique
+            self._share[key] = hit
+        return hit[1]
+
+    def forward(self, x, c):
+        code = torch.cat((self.stick_d(x), self._audio_code(c)), -1)
+        return self.fc2(self.fc1(code, act=ops.ACT_RELU))
+
+
+class AblatedSequenceDiscriminator(nn.Module):
+    """Pose-only critic. Like the reference it does NOT forward `init_ker` to the pose
+    branch, which therefore uses its default kernel of 9 (phase3/archis/default.py:277-278)."""
+
+    def __init__(self, channels_in, channels_h, output_code, seqlen, init_ker=9, activ="id", device="cpu"):
+        super().__init__()
+        self.stick_d = StickDiscriminator(channels_in, channels_h, output_code, seqlen, activ=activ)
+        self.fc1 = Linear(output_code, 128)
+        self.fc2 = Linear(128, 1)
+        self.relu = nn.ReLU(True)
+        initialize_weights(self)
+        self.to(device)
+
+    def forward(self, x):
+        return self.fc2(self.fc1(self.stick_d(x), act=ops.ACT_RELU))

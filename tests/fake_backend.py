@@ -1,0 +1,207 @@
+"""TEST-ONLY stand-in for music2dance_amd.kernels.HipKernels on CPU tensors.
+
+It lets the `-m "not gpu"` suite exercise the HOST logic above the kernel layer (autograd
+wiring incl. the double backward, module structure, losses, engine, data-parallel exchange)
+in a container without a GPU. It is installed explicitly by tests through
+`kernels.set_impl(FakeKernels())`; the product never imports this file and has no CPU path.
+Each method restates the contract of the corresponding C-ABI entry point (include/m2d.h)
+with plain torch ops.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _mf(mask, slope):
+    return torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, slope))
+
+
+def _act(y, act, slope):
+    if act == 1:
+        return F.relu(y)
+    if act == 2:
+        return F.leaky_relu(y, slope)
+    return y
+
+
+class FakeKernels:
+    name = "fake-cpu"
+
+    def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
+                   out_mask_slope=0.0):
+        y = _act(F.conv1d(x, w, bias, stride=stride, padding=pad), act, slope)
+        if residual is not None:
+            y = y + residual
+        if out_mask is not None:
+            y = y * _mf(out_mask, out_mask_slope)
+        return y
+
+    def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0):
+        if dy_mask is not None:
+            dy = dy * _mf(dy_mask, dy_mask_slope)
+        return torch.nn.grad.conv1d_input((dy.shape[0], w.shape[1], L), w, dy, stride=stride, padding=pad)
+
+    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0):
+        if dy_mask is not None:
+            dy = dy * _mf(dy_mask, dy_mask_slope)
+        return torch.nn.grad.conv1d_weight(x, (dy.shape[1], x.shape[1], ks), dy, stride=stride, padding=pad)
+
+    def gemm(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,
+             out_mask_slope=0.0):
+        if a_mask is not None:
+            a = a * _mf(a_mask, a_mask_slope)
+        if mode == 0:
+            c = a @ b.t()
+        elif mode == 1:
+            c = a @ b
+        else:
+            c = a.t() @ b
+        if bias is not None:
+            c = c + bias
+        c = _act(c, act, slope)
+        if out_mask is not None:
+            c = c * _mf(out_mask, out_mask_slope)
+        return c
+
+    def channel_sums(self, x, mask=None, slope=0.0):
+        if mask is not None:
+            x = x * _mf(mask, slope)
+        return x.sum(dim=(0, 2)) if x.dim() == 3 else x.sum(dim=0)
+
+    def bn_fwd(self, x, gamma, beta, running_mean, running_var, training, eps, momentum, act=0, slope=0.0,
+               residual=None):
+        dims = (0,) if x.dim() == 2 else (0, 2)
+        shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
+        if training:
+            mean = x.mean(dims)
+            var = ((x - mean.view(shape)) ** 2).mean(dims)
+            n = x.numel() // x.shape[1]
+            if running_mean is not None:
+                running_mean.mul_(1 - momentum).add_(momentum * mean)
+                running_var.mul_(1 - momentum).add_(momentum * var * (n / (n - 1) if n > 1 else 1.0))
+        else:
+            mean, var = running_mean.clone(), running_var.clone()
+        invstd = 1.0 / torch.sqrt(var + eps)
+        y = _act((x - mean.view(shape)) * invstd.view(shape) * gamma.view(shape) + beta.view(shape), act, slope)
+        if residual is not None:
+            y = y + residual
+        return y, mean, invstd
+
+    def bn_bwd(self, dy, x, gamma, beta, save_mean, save_invstd, act=0, slope=0.0):
+        dims = (0,) if x.dim() == 2 else (0, 2)
+        shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
+        xh = (x - save_mean.view(shape)) * save_invstd.view(shape)
+        z = gamma.view(shape) * xh + beta.view(shape)
+        dz = dy
+        if act == 1:
+            dz = dy * (z > 0).to(dy.dtype)
+        elif act == 2:
+            dz = dy * _mf(z, slope)
+        n = x.numel() // x.shape[1]
+        s1, s2 = dz.sum(dims), (dz * xh).sum(dims)
+        dx = gamma.view(shape) * save_invstd.view(shape) * (dz - (s1 / n).view(shape) - xh * (s2 / n).view(shape))
+        return dx, s2, s1
+
+    def gru_layer_fwd(self, gi, w_hh_t, b_hh, lengths=None, save=True):
+        B, T, H3 = gi.shape
+        H = H3 // 3
+        h = gi.new_zeros(B, H)
+        outs, rs, zs, ns, hns = [], [], [], [], []
+        for t in range(T):
+            gh = h @ w_hh_t + b_hh
+            r = torch.sigmoid(gi[:, t, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, t, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, t, 2 * H:] + r * gh[:, 2 * H:])
+            h = (1 - z) * n + z * h
+            if lengths is not None:
+                h = h * (t < lengths).to(h.dtype).view(B, 1)
+            outs.append(h)
+            rs.append(r), zs.append(z), ns.append(n), hns.append(gh[:, 2 * H:])
+        out = torch.stack(outs, 1)
+        saved = torch.stack([torch.stack(v, 1) for v in (rs, zs, ns, hns)], 0) if save else None
+        return out, saved
+
+    def gru_layer_bwd(self, dout, out, saved, w_hh, lengths=None):
+        B, T, H = out.shape
+        r_s, z_s, n_s, hn_s = saved[0], saved[1], saved[2], saved[3]
+        dgi = out.new_zeros(B, T, 3 * H)
+        dgh = out.new_zeros(B, T, 3 * H)
+        dh_next = None
+        for t in range(T - 1, -1, -1):
+            dh = dout[:, t].clone()
+            if dh_next is not None:
+                dh = dh + dh_next * z_s[:, t + 1] + dgh[:, t + 1] @ w_hh
+            if lengths is not None:
+                dh = dh * (t < lengths).to(dh.dtype).view(B, 1)
+            r, z, n, hn = r_s[:, t], z_s[:, t], n_s[:, t], hn_s[:, t]
+            hprev = out[:, t - 1] if t > 0 else torch.zeros_like(n)
+            dn = dh * (1 - z) * (1 - n * n)
+            dz = dh * (hprev - n) * z * (1 - z)
+            dr = dn * hn * r * (1 - r)
+            dgi[:, t] = torch.cat((dr, dz, dn), 1)
+            dgh[:, t] = torch.cat((dr, dz, dn * r), 1)
+            dh_next = dh
+        return dgi, dgh
+
+    def gp_interpolate(self, real, fake, alpha):
+        a = alpha.view(-1, 1)
+        return a * real + (1 - a) * fake
+
+    def gp_penalty_fwd(self, g, lp):
+        if lp:
+            norms = torch.sqrt((g * g).sum(1))
+            d = (norms - 1).clamp_min(0)
+        else:
+            norms = torch.sqrt((g * g).sum(1) + 1e-12)
+            d = norms - 1
+        return (d * d).mean(), norms
+
+    def gp_penalty_bwd(self, g, norms, gout, lp):
+        d = norms - 1
+        if lp:
+            d = d.clamp_min(0)
+        coef = torch.where(d == 0, torch.zeros_like(d), gout * 2 * d / (norms * g.shape[0]))
+        return coef.view(-1, 1) * g
+
+    def l1_mean_fwd(self, a, b):
+        return (a - b).abs().mean()
+
+    def l1_mean_bwd(self, a, b, gout):
+        return gout * torch.sign(a - b) / a.numel()
+
+    def tv_mean_fwd(self, x, B, C, T, sb, sc, st):
+        v = torch.as_strided(x, (B, C, T), (sb, sc, st))
+        return (v[:, :, 1:] - v[:, :, :-1]).abs().mean()
+
+    def tv_mean_bwd(self, x, gout, B, C, T, sb, sc, st):
+        v = torch.as_strided(x, (B, C, T), (sb, sc, st))
+        s = torch.sign(v[:, :, 1:] - v[:, :, :-1]) * (gout / (B * C * (T - 1)))
+        dx = torch.zeros_like(x)
+        dv = torch.as_strided(dx, (B, C, T), (sb, sc, st))
+        dv[:, :, 1:] += s
+        dv[:, :, :-1] -= s
+        return dx
+
+    def maxpool2_fwd(self, x):
+        return F.max_pool1d(x, 2, 2)
+
+    def maxpool2_bwd(self, x, dy):
+        xr = x.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            y = F.max_pool1d(xr, 2, 2)
+        return torch.autograd.grad(y, xr, dy)[0]
+
+    def upsample2_fwd(self, x):
+        return F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
+
+    def upsample2_bwd(self, dy):
+        B, C, Lo = dy.shape
+        xr = torch.zeros(B, C, Lo // 2, dtype=dy.dtype, requires_grad=True)
+        with torch.enable_grad():
+            y = F.interpolate(xr, scale_factor=2, mode="linear", align_corners=False)
+        return torch.autograd.grad(y, xr, dy)[0]
+
+    def prof_begin(self):
+        pass
+
+    def prof_end(self):
+        return {}

@@ -1,0 +1,309 @@
+"""Parity of the PRODUCT (music2dance_amd modules, losses and engines) with the reference's
+golden fixtures, through the same code path on two kernel layers:
+
+  * `hip`      — the real gfx950 kernels via the C-ABI (marked gpu; runs on the MI355X box)
+  * `cpu-fake` — tests/fake_backend.py on CPU: exercises the identical HOST logic (autograd
+                 wiring incl. double backward, module structure, loops) without a GPU.
+
+Tolerances as in test_oracle_golden.py: 1e-4 abs on poses / scores / penalties (the
+north_star's per-joint bound), 2e-3 rel on gradient norms, 2e-2 rel on 8-step loss traces.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from music2dance_amd import kernels
+from music2dance_amd.engine import Phase1Engine, Phase2Engine, Phase3Engine
+from music2dance_amd.losses import gradient_penalty, tv_loss
+from music2dance_amd import ops
+from music2dance_amd.phase1.archis import residual as p1
+from music2dance_amd.phase2.archis import default as p2
+from music2dance_amd.phase3.archis import default as p3
+from tests.golden import patterns as P
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(params=[pytest.param("cpu-fake"), pytest.param("hip", marks=pytest.mark.gpu)])
+def dev(request):
+    if request.param == "hip":
+        assert kernels.impl().name == "hip"
+        yield torch.device("cuda:0")
+    else:
+        from tests.fake_backend import FakeKernels
+        prev = kernels.set_impl(FakeKernels())
+        try:
+            yield torch.device("cpu")
+        finally:
+            kernels.set_impl(prev)
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def close(got, want, atol=1e-4, rtol=0.0):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    np.testing.assert_allclose(got, want, atol=atol, rtol=rtol)
+
+
+def fill(module, fx, which, seed):
+    sd = module.state_dict()
+    assert list(sd.keys()) == [str(k) for k in fx[which + "_keys"]], "state_dict keys differ from the reference"
+    assert [",".join(str(d) for d in v.shape) for v in sd.values()] == [str(s) for s in fx[which + "_shapes"]]
+    filled = P.fill_state_dict(sd, seed)
+    np.testing.assert_allclose(P.sd_checksums(filled), fx[which + "_sd_sum"], rtol=1e-12, atol=1e-12)
+    module.load_state_dict(filled)
+    return module
+
+
+def grad_norms(module):
+    return np.array([float("nan") if p.grad is None else p.grad.double().norm().item()
+                     for _, p in module.named_parameters()])
+
+
+def norms_close(got, want, rtol=2e-3):
+    assert np.array_equal(np.isnan(got), np.isnan(want)), "set of parameters without gradient differs"
+    m = ~np.isnan(want)
+    np.testing.assert_allclose(got[m], want[m], rtol=rtol, atol=1e-6 * np.nanmax(want))
+
+
+def sums_close(sd, want, rtol=2e-4, adam_lr=0.0, adam_steps=0):
+    got = P.sd_checksums({k: v.detach().cpu() for k, v in sd.items()})
+    numel = np.array([v.numel() for v in sd.values()], dtype=np.float64)
+    atol = 1e-5 + 4.0 * adam_lr * adam_steps * np.sqrt(numel)
+    err = np.abs(got - want)
+    bound = atol[:, None] + rtol * np.abs(want)
+    assert (err <= bound).all(), "checksum mismatch at %s" % [
+        (list(sd)[i], got[i].tolist(), want[i].tolist()) for i in np.nonzero((err > bound).any(1))[0][:5]]
+
+
+# ------------------------------------------------------------------------------ construction
+def test_seeded_constructors_match_reference():
+    """utils.initialize_weights + constructor RNG stream (utils.py:267-313): same seed, same weights."""
+    fx = load("init")
+
+    def check(tag, module):
+        sd = module.state_dict()
+        keys_tag = {"p3_default_gen": "p3_gen"}.get(tag, tag) + "_keys"
+        assert list(sd.keys()) == [str(k) for k in fx[keys_tag]]
+        np.testing.assert_allclose(P.sd_checksums(sd), fx[tag], rtol=1e-12, atol=1e-12)
+
+    torch.manual_seed(0)
+    g = p3.SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, "default", "id", "cpu")
+    c = p3.SequenceDiscriminator(69, 128, 100, 120, init_ker=25, activ="id", device="cpu")
+    check("p3_default_gen", g), check("p3_critic", c)
+    torch.manual_seed(0)
+    g = p3.SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, "wavegan", "tanh", "cpu")
+    c = p3.AblatedSequenceDiscriminator(69, 128, 100, 120, init_ker=25, activ="tanh", device="cpu")
+    check("p3_wavegan_gen", g), check("p3_ablated_critic", c)
+    torch.manual_seed(0)
+    check("p3_unet_gen", p3.SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, "unet", "id", "cpu"))
+    torch.manual_seed(0)
+    g = p2.SequenceGenerator(50, 50, 256, 69, 2, 3, "cpu")
+    c = p2.SequenceDiscriminator(69, 128, 120, 25, 3, "cpu")
+    check("p2_gen", g), check("p2_critic", c)
+    torch.manual_seed(0)
+    check("p1_gen", p1.Generator(10, 128, 69, 1)), check("p1_critic", p1.Discriminator(69, 128, 1))
+
+
+def test_kernels_refuse_cpu_tensors():
+    """The product has no CPU path: the HIP wrappers raise on host tensors."""
+    from music2dance_amd import _lib
+    hip = kernels.HipKernels()
+    with pytest.raises(_lib.M2dError):
+        hip.conv1d_fwd(torch.zeros(1, 1, 8), torch.zeros(1, 1, 3), None, 1, 0)
+
+
+# ------------------------------------------------------------------------------ phase 1
+def test_p1(dev):
+    fx = load("p1")
+    B = 8
+    gen = fill(p1.Generator(10, 128, 69, 1), fx, "gen", 1000).to(dev)
+    critic = fill(p1.Discriminator(69, 128, 1), fx, "critic", 2000).to(dev)
+    z = P.noise(B, 1, 10, seed=21).view(B, 10).to(dev)
+    real = P.poses(B, 1, seed=22).view(B, 23, 3).to(dev)
+    gen.eval(), critic.eval()
+    with torch.no_grad():
+        close(gen(z), fx["gen_eval"])
+        close(critic(real), fx["critic_eval"])
+    gen.train(), critic.train()
+    torch.manual_seed(5)
+    fake = gen(z)
+    gp = gradient_penalty(critic, B, real, fake, device=dev)
+    err_real, err_fake = critic(real).mean(), critic(fake.detach()).mean()
+    (err_fake - err_real + 10 * gp).backward()
+    close(fake, fx["gen_train"])
+    close(gp, fx["gp"]), close(err_real, fx["err_real"]), close(err_fake, fx["err_fake"])
+    norms_close(grad_norms(critic), fx["critic_grad_norms"])
+    sums_close({k: v for k, v in gen.state_dict().items() if "running" in k}, fx["gen_bn_after"])
+
+
+def test_p1_trace(dev):
+    fx = load("p1")
+    gen = fill(p1.Generator(10, 128, 69, 1), fx, "gen", 1000).to(dev)
+    critic = fill(p1.Discriminator(69, 128, 1), fx, "critic", 2000).to(dev)
+    real = P.poses(8, 1, seed=22).view(8, 23, 3).to(dev)
+    cfg = {"lr_gen": 1e-4, "lr_critic": 1e-4, "n_critic_steps": 5, "gamma": 10, "latent_vector_size": 10}
+    eng = Phase1Engine(gen, critic, cfg)
+    torch.manual_seed(6)
+    lc, lg = [], []
+    for _ in range(6):
+        out = eng.train_step(real)
+        lc.append(out["loss_critic"].item())
+        if "loss_gen" in out:
+            lg.append(out["loss_gen"].item())
+    eng.flush()
+    close(np.array(lc), fx["trace_loss_critic"], 1e-3, 2e-2)
+    close(np.array(lg), fx["trace_loss_gen"], 1e-3, 2e-2)
+    close(np.array(lc[:1]), fx["trace_loss_critic"][:1], 1e-4)
+    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=1e-4, adam_steps=1)
+    sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=1e-4, adam_steps=6)
+
+
+# ------------------------------------------------------------------------------ phase 2
+def test_p2(dev):
+    fx = load("p2")
+    B, T = 2, 120
+    gen = fill(p2.SequenceGenerator(50, 50, 256, 69, 2, 3, "cpu"), fx, "gen", 3000).to(dev)
+    critic = fill(p2.SequenceDiscriminator(69, 128, T, 25, 3, "cpu"), fx, "critic", 4000).to(dev)
+    noise, real = P.noise(B, T, 50, seed=31).to(dev), P.poses(B, T, seed=32).to(dev)
+    real_c = real.permute(0, 2, 1).contiguous()
+    gen.train()
+    rows = gen(noise, [T] * B)
+    close(rows, fx["gen_train"])
+    sums_close({k: v for k, v in gen.state_dict().items() if "running" in k}, fx["gen_bn_after"])
+    gen.eval()
+    with torch.no_grad():
+        close(gen(noise, [T] * B), fx["gen_eval"])
+        close(gen(noise, [T, 100]), fx["gen_eval_lengths"])
+    gen.train()
+    fake = rows.view(B, T, 69).permute(0, 2, 1).contiguous()
+    close(critic(real_c), fx["score_real"]), close(critic(fake.detach()), fx["score_fake"])
+    torch.manual_seed(7)
+    lp = gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=True, device=dev)
+    torch.manual_seed(7)
+    gp = gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=False, device=dev)
+    close(lp, fx["lp"]), close(gp, fx["gp"])
+    critic.zero_grad()
+    (critic(fake.detach()).mean() - critic(real_c).mean() + 10 * lp).backward()
+    norms_close(grad_norms(critic), fx["critic_grad_norms"])
+    fake_g = rows.view(B, T, 69).permute(0, 2, 1)
+    tv = tv_loss(fake_g)
+    err_gen = critic(real_c).mean() - critic(fake_g).mean() + 50 * tv
+    gen.zero_grad()
+    err_gen.backward()
+    close(tv, fx["tv"], 1e-6), close(err_gen, fx["err_gen"])
+    norms_close(grad_norms(gen), fx["gen_grad_norms"])
+
+
+def test_p2_trace(dev):
+    fx = load("p2")
+    gen = fill(p2.SequenceGenerator(50, 50, 256, 69, 2, 3, "cpu"), fx, "gen", 3000).to(dev)
+    critic = fill(p2.SequenceDiscriminator(69, 128, 120, 25, 3, "cpu"), fx, "critic", 4000).to(dev)
+    real = P.poses(2, 120, seed=32).to(dev)
+    cfg = {"lr_gen": 5e-4, "lr_critic": 5e-4, "n_critic_steps": 8, "gamma": 10, "eta": 50, "input_vector_size": 50}
+    eng = Phase2Engine(gen, critic, cfg)
+    torch.manual_seed(8)
+    tr = {"loss_critic": [], "gp": [], "w_dist": [], "loss_gen": []}
+    for _ in range(8):
+        out = eng.train_step(real)
+        for k in tr:
+            if k in out:
+                tr[k].append(out[k].item())
+    eng.flush()
+    for k in tr:
+        close(np.array(tr[k]), fx["trace_" + k], 1e-3, 2e-2)
+    close(np.array(tr["loss_critic"][:1]), fx["trace_loss_critic"][:1], 1e-4)
+    assert len(tr["loss_gen"]) == 1
+    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=5e-4, adam_steps=1)
+    sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=5e-4, adam_steps=8)
+
+
+# ------------------------------------------------------------------------------ phase 3
+P3_CASES = [("default", "id", False, 120, 2), ("default", "tanh", False, 120, 2), ("default", "relu", True, 120, 2),
+            ("wavegan", "id", False, 120, 2), ("wavegan", "tanh", True, 120, 2), ("unet", "id", False, 120, 2),
+            ("unet", "id", True, 120, 2), ("unet", "id", True, 300, 1)]
+
+
+def p3_name(enc, activ, ablated, T):
+    return "p3_%s_%s_%s%s" % (enc, activ, "abl" if ablated else "full", "" if T == 120 else "_T%d" % T)
+
+
+def build_p3(fx, enc, activ, ablated, T, dev):
+    gen = p3.SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, enc, activ, "cpu")
+    cls = p3.AblatedSequenceDiscriminator if ablated else p3.SequenceDiscriminator
+    critic = cls(69, 128, 100, T, init_ker=25, activ=activ, device="cpu")
+    return fill(gen, fx, "gen", 5000).to(dev), fill(critic, fx, "critic", 6000).to(dev)
+
+
+@pytest.mark.parametrize("case", P3_CASES, ids=lambda c: p3_name(*c[:4]))
+def test_p3(dev, case):
+    enc, activ, ablated, T, B = case
+    fx = load(p3_name(enc, activ, ablated, T))
+    gen, critic = build_p3(fx, enc, activ, ablated, T, dev)
+    real, aud, nz = P.poses(B, T, seed=41).to(dev), P.audio(B, T, seed=42).to(dev), P.noise(B, T, 10, seed=43).to(dev)
+    from music2dance_amd.utils import slice_audio_batch
+    sl = slice_audio_batch(aud, P.WINDOW, P.HOP, P.PAD)
+    assert torch.equal(sl.cpu(), P.slices(aud.cpu()))
+    real_c = real.permute(0, 2, 1).contiguous()
+    audio_c = aud.unsqueeze(1)
+    gen.train()
+    rows = gen(sl, [T] * B, nz)
+    close(rows, fx["gen_train"])
+    sums_close({k: v for k, v in gen.state_dict().items() if "running" in k or "tracked" in k}, fx["gen_bn_after"])
+    gen.eval()
+    with torch.no_grad():
+        close(gen(sl, [T] * B, nz), fx["gen_eval"])
+    gen.train()
+    fake = rows.view(B, T, 69).permute(0, 2, 1).contiguous()
+    D = (lambda x, a: critic(x)) if ablated else (lambda x, a: critic(x, a))
+    close(D(real_c, audio_c), fx["score_real"]), close(D(fake.detach(), audio_c), fx["score_fake"])
+    torch.manual_seed(9)
+    if ablated:
+        gp = gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=False, device=dev)
+    else:
+        gp = gradient_penalty(critic, B, real_c, fake, audio_c.clone(), is_seq=True, lp=False, device=dev)
+    close(gp, fx["gp"], 1e-4, 1e-4)
+    err_critic = D(fake.detach(), audio_c).mean() - D(real_c, audio_c).mean() + 10 * gp
+    critic.zero_grad()
+    err_critic.backward()
+    close(err_critic, fx["err_critic"], 1e-4, 1e-4)
+    norms_close(grad_norms(critic), fx["critic_grad_norms"])
+    fake_g = rows.view(B, T, 69).permute(0, 2, 1)
+    l1 = ops.l1_mean(real.reshape(B * T, 69), rows)
+    err_gen = D(real_c, audio_c).mean() - D(fake_g, audio_c).mean() + 1.0 * l1 + 0.0 * tv_loss(fake_g)
+    gen.zero_grad()
+    err_gen.backward()
+    close(l1, fx["err_l1"], 2e-5), close(err_gen, fx["err_gen"])
+    norms_close(grad_norms(gen), fx["gen_grad_norms"])
+
+
+@pytest.mark.parametrize("case", [("default", "id", False), ("wavegan", "id", False), ("unet", "id", True)],
+                         ids=lambda c: "%s_%s_%s" % c)
+def test_p3_trace(dev, case):
+    enc, activ, ablated = case
+    fx = load(p3_name(enc, activ, ablated, 120))
+    B, T = 2, 120
+    gen, critic = build_p3(fx, enc, activ, ablated, T, dev)
+    real, aud = P.poses(B, T, seed=41).to(dev), P.audio(B, T, seed=42).to(dev)
+    sl = P.slices(aud.cpu()).to(dev)
+    cfg = {"lr_gen": 2e-4, "lr_critic": 2e-4, "n_critic_steps": 8, "gamma": 10, "beta": 1, "eta": 0}
+    eng = Phase3Engine(gen, critic, cfg, ablated=ablated)
+    torch.manual_seed(10)
+    tr = {"loss_critic": [], "gp": [], "w_dist": [], "loss_gen": [], "l1_loss_train": []}
+    for _ in range(8):
+        out = eng.train_step(real, aud, sl)
+        for k in tr:
+            if k in out:
+                tr[k].append(out[k].item())
+    eng.flush()
+    for k, fk in (("loss_critic", "loss_critic"), ("gp", "gp"), ("w_dist", "w_dist"), ("loss_gen", "loss_gen"),
+                  ("l1_loss_train", "err_l1")):
+        close(np.array(tr[k]), fx["trace_" + fk], 1e-3, 2e-2)
+    close(np.array(tr["loss_critic"][:1]), fx["trace_loss_critic"][:1], 2e-4)
+    assert len(tr["loss_gen"]) == 1
+    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=2e-4, adam_steps=1)
+    sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=2e-4, adam_steps=8)
