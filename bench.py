@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Throughput of the phase-3 audio-conditioned WGAN-GP training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one loop body of phase3/train.py:186-243 on one synthetic batch already
+resident in HBM: a critic iteration (generator forward, gradient penalty with its double
+backward, real/fake critic passes, critic backward, Adam), plus a generator iteration on
+every n_critic_steps-th step (8, phase3/configs/default.yaml) — so K should be a multiple
+of 8 to time whole cycles. Workload = BASELINE.json configs[2]: default conv1d encoder,
+120-frame sequences, batch 64 per GPU (weak scaling: the global batch is 64 * N).
+
+Rank 0 prints ONE JSON line: seq/s over all GPUs, plus
+  roofline     — the implicit-GEMM engine (conv1d fwd/bwd_data/bwd_weight + linear GEMMs):
+                 sum of 2*M*N*K over its launches / sum of their HIP-event durations,
+                 measured inside the timed region on the launch stream, against the exact
+                 fp32 MFMA peak of gfx950 (157.3 TFLOP/s);
+  cpu_baseline — the oracle (a port of the reference's CPU path, oracle/m2d_oracle.py) timed
+                 on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+REF_GFLOP_PER_SEQ_CYCLE = 31.10  # reference formulation, per sequence per cycle
+
+P3_DEFAULT = {"lr_gen": 2e-4, "lr_critic": 2e-4, "n_critic_steps": 8, "gamma": 10, "beta": 1, "eta": 0,
+              "output_size": 69}
+
+
+def build_models(device, seqlen=120, enc_type="default"):
+    from music2dance_amd.phase3.archis.default import SequenceDiscriminator, SequenceGenerator
+    torch.manual_seed(0)  # phase3/train.py:35
+    gen = SequenceGenerator(3200, 250, 250, 256, 69, 10, 2, 3, enc_type, "id", device)
+    critic = SequenceDiscriminator(69, 128, 100, seqlen, init_ker=25, activ="id", device=device)
+    return gen, critic
+
+
+def cpu_baseline(sample_b=8, T=120):
+    """Oracle (CPU port of the reference path) on the host cores: 1 warm-up + 2 timed critic
+    iterations + 1 generator iteration at batch `sample_b`, extrapolated to seq/s of a
+    full 8+1 cycle (the path is linear in the batch)."""
+    from oracle import m2d_oracle as O
+    from music2dance_amd.engine import synthetic_phase3_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen, critic = build_models("cpu")
+    gsd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    dsd = {k: v.detach().clone() for k, v in critic.state_dict().items()}
+    real, audio, slices = synthetic_phase3_batch(sample_b, T, "cpu", seed=1)
+    cfg = O.P3Config(n_critic=3)
+    t0 = time.perf_counter()
+    O.p3_train_iterations(gsd, dsd, cfg, real, audio, slices, 1, 0)  # warm-up critic iteration
+    t1 = time.perf_counter()
+    O.p3_train_iterations(gsd, dsd, cfg, real, audio, slices, 2, 0)  # 2 critic iterations
+    t2 = time.perf_counter()
+    O.p3_train_iterations(gsd, dsd, cfg, real, audio, slices, 3, 0)  # 3 critic + 1 generator iteration
+    t3 = time.perf_counter()
+    t_critic = (t2 - t1) / 2.0
+    t_gen = max((t3 - t2) - 3.0 * t_critic, 0.0)
+    cycle = 8 * t_critic + t_gen
+    return {"value": round(8.0 * sample_b / cycle, 3), "unit": "seq/s", "cores": cores, "kind": "port",
+            "sample": "oracle phase-3 default-encoder step at batch %d: 5 critic + 1 generator iterations "
+                      "(%.1f s), extrapolated to one 8+1 cycle; critic %.2f s, generator %.2f s per iteration"
+                      % (sample_b, t3 - t0, t_critic, t_gen)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU (weak scaling)")
+    ap.add_argument("--frames", type=int, default=120)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel profile")
+    args = ap.parse_args()
+
+    from music2dance_amd import dp, kernels
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+
+    rank, world, local = dp.init_from_env("nccl")
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device: the product has no CPU path")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    gen, critic = build_models(device, args.frames)
+    engine = Phase3Engine(gen, critic, P3_DEFAULT)
+    real, audio, slices = synthetic_phase3_batch(args.batch, args.frames, device, seed=100 + rank)
+    gen.train(), critic.train()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    torch.manual_seed(1234 + rank)
+    for _ in range(args.warmup):
+        engine.train_step(real, audio, slices)
+    engine.flush()
+    K = kernels.impl()
+    barrier()
+    if not args.no_prof:
+        K.prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        engine.train_step(real, audio, slices)
+    engine.flush()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = None if args.no_prof else K.prof_end()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    last = {k: float(v) for k, v in engine.last.items()}
+
+    if rank == 0:
+        seqs = args.steps * args.batch * world
+        value = seqs / elapsed
+        out = {
+            "metric": "120-frame seq/sec, phase3 WGAN-GP step, batch 64 per GPU",
+            "value": round(value, 2), "unit": "seq/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "phase3/train.py WGAN-GP step, default conv1d audio encoder, %d frames, "
+                                   "batch %d per GPU (BASELINE.json configs[2]); 1 generator iteration per 8 "
+                                   "critic iterations" % (args.frames, args.batch),
+                       "global_batch": args.batch * world, "seq_len": args.frames,
+                       "parallelism": "dp%d" % world},
+            "losses_last_step": last,
+        }
+        if prof is not None:
+            g = prof["gemm"]
+            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+            out["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "m2d_gemm_kernel (separable-gather fp32 MFMA engine; conv1d fwd/bwd_data/bwd_weight + linear)",
+                "launches_per_step": round(g["launches"] / args.steps, 1),
+                "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2),
+                "gflop_per_step_executed": round(g["flops"] / args.steps / 1e9, 1),
+                "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+                # the reference's own formulation executes 31.10 GFLOP per sequence consumed
+                # (SURVEY.md 8(d)); the engine skips work the reference discards, so this is
+                # an equivalent-work rate, not a kernel rate
+                "step_tflops_reference_formulation": round(REF_GFLOP_PER_SEQ_CYCLE * 1e9 * seqs / elapsed / 1e12, 2),
+            }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is informational; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "seq/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

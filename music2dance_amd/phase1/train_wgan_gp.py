@@ -1,0 +1,72 @@
+"""Phase 1: still-pose residual-MLP WGAN-GP on MI355X.
+
+    python -m music2dance_amd.phase1.train_wgan_gp -c music2dance_amd/phase1/configs/b1l10s128.yaml -d 0 -n run --synthetic
+
+Flags -d/-n as in the reference's phase1/train_wgan-gp.py plus -c for the config file (the
+reference reads an undefined `file` variable, phase1/train_wgan-gp.py:31). The hyphenated
+script name of the reference is not importable as a module; `train_wgan-gp.py` next to this
+file forwards to it.
+"""
+import argparse
+
+import numpy as np
+import torch
+
+from .. import dp, runner
+from ..engine import Phase1Engine
+from .archis.residual import Discriminator, Generator
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-c", "--config", type=str, help="choose config file")
+    ap.add_argument("-d", "--device", type=int, help="choose gpu id")
+    ap.add_argument("-n", "--name", type=str, help="choose name of experiment")
+    ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--iterations", type=int, default=None)
+    ap.add_argument("--log-every", type=int, default=1)
+    ap.add_argument("--no-run-dir", action="store_true")
+    opts = ap.parse_args(argv)
+
+    rank, world, local = dp.init_from_env()
+    device = runner.pick_device(local if world > 1 else opts.device)
+    cfg = runner.load_config(opts.config)
+    if not opts.synthetic:
+        raise SystemExit("the Music-to-Dance dataset pipeline is outside this engine (SURVEY.md 8(f)); use --synthetic")
+    logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
+    np.random.seed(37)
+    gen = Generator(cfg["latent_vector_size"], cfg["size"], cfg["output_size"], cfg["nblocks_gen"]).to(device)
+    critic = Discriminator(cfg["output_size"], cfg["size"], cfg["nblocks_critic"]).to(device)
+    engine = Phase1Engine(gen, critic, cfg)
+    engine.host_noise = False  # phase1/train_wgan-gp.py:83 draws the noise on the device
+    log = runner.ScalarLog(logdir, opts.log_every)
+    B = cfg["batch_size"]
+    batches_per_epoch = max(cfg["num_train"] // B, 1)
+    print("Start training..")
+    done = False
+    for epoch in range(cfg["num_epochs"]):
+        gen.train()
+        for b in range(batches_per_epoch):
+            g = torch.Generator().manual_seed(1 + (epoch * batches_per_epoch + b) * world + rank)
+            real = torch.rand(B, 23, 3, generator=g).to(device)
+            out = engine.train_step(real)
+            it = engine.total_iterations
+            if "loss_gen" in out:
+                log.scalars({"loss_critic": -out["loss_critic"], "loss_gen": out["loss_gen"]}, it)
+            if opts.iterations is not None and it >= opts.iterations:
+                done = True
+                break
+        if done:
+            break
+        if logdir is not None and (epoch + 1) % 5 == 0:
+            runner.save_state(gen, logdir + "/models/gen_{}.pt".format(epoch + 1))
+            runner.save_state(critic, logdir + "/models/critic_{}.pt".format(epoch + 1))
+    engine.flush()
+    if rank == 0:
+        print("done: {} iterations, last {}".format(engine.total_iterations,
+                                                    {k: float(v) for k, v in engine.last.items()}))
+    return engine
+
+
+if __name__ == "__main__":
+    main()

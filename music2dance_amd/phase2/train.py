@@ -1,0 +1,80 @@
+"""Phase 2: unconditional sequence WGAN-GP/LP on MI355X.
+
+    python -m music2dance_amd.phase2.train -c music2dance_amd/phase2/configs/default.yaml -d 0 -n run -f wgangp --synthetic
+
+Flags -c/-d/-n/-f and YAML keys as in the reference's phase2/train.py. Only the `wgangp`
+framework is part of this engine; `gan` (BCE) is outside the WGAN-GP path and, like any
+unknown value, is rejected with the reference's error.
+"""
+import argparse
+
+import torch
+
+from .. import dp, runner
+from ..engine import Phase2Engine
+from .archis.default import SequenceDiscriminator, SequenceGenerator
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-c", "--config", type=str, help="choose config file")
+    ap.add_argument("-d", "--device", type=int, help="choose gpu id")
+    ap.add_argument("-n", "--name", type=str, help="name experiment")
+    ap.add_argument("-f", "--framework", type=str, default="wgangp", help="choose between `wgangp` and `gan`")
+    ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--iterations", type=int, default=None)
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--log-every", type=int, default=1)
+    ap.add_argument("--no-run-dir", action="store_true")
+    opts = ap.parse_args(argv)
+    if opts.framework != "wgangp":
+        raise ValueError("Please state existing framework")
+
+    rank, world, local = dp.init_from_env()
+    device = runner.pick_device(local if world > 1 else opts.device)
+    cfg = runner.load_config(opts.config)
+    torch.manual_seed(0)
+    if not opts.synthetic:
+        raise SystemExit("the Music-to-Dance dataset pipeline is outside this engine (SURVEY.md 8(f)); use --synthetic")
+    ds = cfg["dataset"]
+    stick_length = int(ds["seq_length"] * ds["video_rate"])
+    batch_size = opts.batch_size or cfg["batch_size"]
+    logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
+    gen = SequenceGenerator(cfg["input_vector_size"], cfg["latent_vector_size"], cfg["size"], cfg["output_size"],
+                            cfg["nblocks_gen"], cfg["n_cells"], device)
+    critic = SequenceDiscriminator(cfg["output_size"], cfg["channels"], stick_length, cfg["init_kernel"],
+                                   cfg["nblocks_critic"], device)
+    engine = Phase2Engine(gen, critic, cfg)
+    engine.host_noise = False  # phase2/train.py:139-140 draws the noise on the device
+    log = runner.ScalarLog(logdir, opts.log_every)
+    runner.dump_architectures(logdir, gen, critic)
+    batches_per_epoch = max(cfg["num_train"] // cfg["batch_size"], 1)
+    print("Start training..")
+    done = False
+    for epoch in range(cfg["num_epochs"]):
+        gen.train()
+        for b in range(batches_per_epoch):
+            g = torch.Generator().manual_seed(1 + (epoch * batches_per_epoch + b) * world + rank)
+            real = torch.rand(batch_size, stick_length, cfg["output_size"], generator=g).to(device)
+            out = engine.train_step(real)
+            it = engine.total_iterations
+            if "loss_gen" in out:
+                log.scalars({"loss_critic": -out["loss_critic"], "loss_gen": out["loss_gen"], "gp": out["gp"],
+                             "w_dist": -out["w_dist"]}, it)
+            if opts.iterations is not None and it >= opts.iterations:
+                done = True
+                break
+        if done:
+            break
+        if logdir is not None and (epoch + 1) % 5000 == 0:
+            runner.save_state(gen, logdir + "/models/gpgen_{}.pt".format(epoch + 1))
+            runner.save_state(critic, logdir + "/models/gpcritic_{}.pt".format(epoch + 1))
+    engine.flush()
+    if rank == 0:
+        print("done: {} iterations, last {}".format(engine.total_iterations,
+                                                    {k: float(v) for k, v in engine.last.items()}))
+    return engine
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""Phase 3: audio-conditioned sequence WGAN-GP on MI355X.
+
+    python -m music2dance_amd.phase3.train -c music2dance_amd/phase3/configs/default.yaml -d 0 -n run --synthetic
+
+Same flags (-c/-d/-n), YAML keys, seeds, scalar tags and checkpoint names as the
+reference's phase3/train.py; the loop body is engine.Phase3Engine.
+"""
+import argparse
+
+import numpy as np
+import torch
+
+from .. import dp, runner
+from ..engine import Phase3Engine, synthetic_phase3_batch
+from .archis.default import AblatedSequenceDiscriminator, SequenceDiscriminator, SequenceGenerator
+
+
+def build(cfg, device, stick_length):
+    rate = cfg["dataset"]["audio_rate"]
+    window = int(cfg["window_size"] * rate)
+    gen = SequenceGenerator(window, cfg["input_vector_size"], cfg["latent_vector_size"], cfg["size"],
+                            cfg["output_size"], cfg["noise_size"], cfg["nblocks_gen"], cfg["n_cells"],
+                            cfg["enc_type"], cfg["activ"], device)
+    cls = AblatedSequenceDiscriminator if cfg["ablated"] else SequenceDiscriminator
+    critic = cls(cfg["output_size"], cfg["channels"], cfg["code_size"], stick_length,
+                 init_ker=cfg["init_kernel"], activ=cfg["activ"], device=device)
+    return gen, critic
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-c", "--config", type=str, help="choose config file")
+    ap.add_argument("-d", "--device", type=int, help="choose gpu id")
+    ap.add_argument("-n", "--name", type=str, help="name experiment")
+    ap.add_argument("--synthetic", action="store_true", help="random poses / audio of the dataset's shapes")
+    ap.add_argument("--iterations", type=int, default=None, help="stop after this many loop bodies")
+    ap.add_argument("--batch-size", type=int, default=None, help="override batch_size (per GPU)")
+    ap.add_argument("--log-every", type=int, default=1)
+    ap.add_argument("--no-run-dir", action="store_true")
+    opts = ap.parse_args(argv)
+
+    rank, world, local = dp.init_from_env()
+    device = runner.pick_device(local if world > 1 else opts.device)
+    cfg = runner.load_config(opts.config)
+    torch.manual_seed(0)
+    if not opts.synthetic:
+        raise SystemExit("the Music-to-Dance dataset pipeline is outside this engine (SURVEY.md 8(f)); use --synthetic")
+
+    ds = cfg["dataset"]
+    stick_length = int(ds["seq_length"] * ds["video_rate"])
+    batch_size = opts.batch_size or cfg["batch_size"]
+    logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
+    gen, critic = build(cfg, device, stick_length)
+    engine = Phase3Engine(gen, critic, cfg, ablated=cfg["ablated"])
+    log = runner.ScalarLog(logdir, opts.log_every)
+    runner.dump_architectures(logdir, gen, critic)
+
+    batches_per_epoch = max(cfg["num_train"] // cfg["batch_size"], 1)
+    np.random.seed(14)
+    print("Start training..")
+    done = False
+    for epoch in range(cfg["num_epochs"]):
+        gen.train()
+        for b in range(batches_per_epoch):
+            real, audio, slices = synthetic_phase3_batch(batch_size, stick_length, device,
+                                                         seed=1 + (epoch * batches_per_epoch + b) * world + rank,
+                                                         audio_rate=ds["audio_rate"], video_rate=ds["video_rate"],
+                                                         window_s=cfg["window_size"])
+            out = engine.train_step(real, audio, slices)
+            it = engine.total_iterations
+            if "loss_gen" in out:
+                log.scalars({"loss_critic": -out["loss_critic"], "loss_gen": out["loss_gen"], "gp": out["gp"],
+                             "w_dist": -out["w_dist"], "l1_loss_train": out["l1_loss_train"]}, it)
+            if opts.iterations is not None and it >= opts.iterations:
+                done = True
+                break
+        if done:
+            break
+        if (epoch + 1) % 500 == 0 and rank == 0:
+            o = engine.last
+            print("Iteration: {} LossD : {}".format(engine.total_iterations, float(o["loss_critic"])))
+        if logdir is not None:
+            if (epoch + 1) <= 1000 and (epoch + 1) % 100 == 0:
+                runner.save_state(gen, logdir + "/models/gpgen_{}.pt".format(epoch + 1))
+            if (epoch + 1) % 5000 == 0:
+                runner.save_state(gen, logdir + "/models/gpgen_{}.pt".format(epoch + 1))
+                runner.save_state(critic, logdir + "/models/gpcritic_{}.pt".format(epoch + 1))
+    engine.flush()
+    if rank == 0:
+        print("done: {} iterations, last {}".format(engine.total_iterations,
+                                                    {k: float(v) for k, v in engine.last.items()}))
+    return engine
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+"""World-size-2 (gloo, CPU) tests of the data-parallel path: the gradient exchange itself,
+and the sharding identity the design relies on — the critic's
+global-batch gradient equals the mean of the per-rank shard gradients when every sample
+keeps its own alpha. Host logic only: kernels are the CPU stand-in of tests/fake_backend.py.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _setup(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from music2dance_amd import kernels
+    from tests.fake_backend import FakeKernels
+    kernels.set_impl(FakeKernels())
+
+
+def _exchange_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    from music2dance_amd.dp import GradExchange
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),
+              torch.nn.Parameter(torch.zeros(2, 2))]
+    params[0].grad = torch.full((5, 3), float(rank + 1))
+    params[1].grad = torch.arange(7.0) * (rank + 1)
+    params[2].grad = None  # dead parameter: stays without gradient
+    ex = GradExchange(params, bucket_mb=1e-5)  # force several buckets
+    assert ex.active and len(ex.buckets) >= 2
+    ex.start()
+    ex.finish()
+    q.put((rank, params[0].grad.numpy().copy(), params[1].grad.numpy().copy(), params[2].grad is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_exchange_averages():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in range(world)]
+    [p.join(60) for p in procs]
+    for rank, g0, g1, dead in res:
+        assert torch.allclose(torch.from_numpy(g0), torch.full((5, 3), 1.5))
+        assert torch.allclose(torch.from_numpy(g1), torch.arange(7.0) * 1.5)
+        assert dead
+
+
+def _make_p2(seed=0):
+    from music2dance_amd.phase2.archis.default import SequenceDiscriminator, SequenceGenerator
+    torch.manual_seed(seed)
+    gen = SequenceGenerator(8, 8, 16, 69, 1, 1, "cpu")
+    critic = SequenceDiscriminator(69, 8, 24, 5, 1, "cpu")
+    return gen, critic
+
+
+CFG = {"lr_gen": 1e-3, "lr_critic": 1e-3, "n_critic_steps": 100, "gamma": 10, "eta": 50, "input_vector_size": 8}
+
+
+def _critic_grads_full(B, T, alpha, noise, real):
+    """single process, global batch"""
+    import music2dance_amd.losses as L
+    from music2dance_amd.engine import Phase2Engine
+    gen, critic = _make_p2()
+    eng = Phase2Engine(gen, critic, CFG, data_parallel=False)
+    eng._noise = lambda b, t, d: noise
+    orig = L.torch.rand
+    L.torch.rand = lambda *a, **k: alpha.clone()
+    try:
+        gen.eval()  # no BatchNorm coupling between samples: the generator output shards exactly
+        eng.critic_iteration(real)
+    finally:
+        L.torch.rand = orig
+    return [p.grad.clone() for p in critic.parameters()], [p.detach().clone() for p in critic.parameters()]
+
+
+def _shard_worker(rank, world, port, q, B, T, alpha, noise, real):
+    _setup(rank, world, port)
+    import music2dance_amd.losses as L
+    from music2dance_amd.engine import Phase2Engine
+    gen, critic = _make_p2()
+    eng = Phase2Engine(gen, critic, CFG, data_parallel=True)
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    eng._noise = lambda b, t, d: noise[lo:hi]
+    L.torch.rand = lambda *a, **k: alpha[lo:hi].clone()
+    gen.eval()
+    eng.critic_iteration(real[lo:hi])
+    assert eng._critic_step_pending  # the optimiser step is deferred behind the exchange
+    eng.x_critic.finish()
+    grads = [p.grad.clone() for p in critic.parameters()]
+    eng.optim_critic.step()
+    eng._critic_step_pending = False
+    q.put((rank, [g.numpy().copy() for g in grads], [p.detach().numpy().copy() for p in critic.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_critic_gradient_equals_global_batch():
+    from music2dance_amd import kernels
+    from tests.fake_backend import FakeKernels
+    B, T = 4, 24
+    g = torch.Generator().manual_seed(3)
+    alpha = torch.rand(B, 1, generator=g)
+    noise = torch.randn(B, T, 8, generator=g)
+    real = torch.rand(B, T, 69, generator=g)
+    prev = kernels.set_impl(FakeKernels())
+    try:
+        full_grads, full_params = _critic_grads_full(B, T, alpha, noise, real)
+    finally:
+        kernels.set_impl(prev)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q, B, T, alpha, noise, real))
+             for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(world)]
+    [p.join(60) for p in procs]
+    for rank, grads, params in res:
+        for a, b in zip(grads, full_grads):
+            a = torch.from_numpy(a)
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (rank, (a - b).abs().max())
+    # both ranks hold identical parameters after the step
+    for a, b in zip(res[0][2], res[1][2]):
+        assert (a == b).all()
