@@ -14,7 +14,8 @@ _S = _c.c_size_t
 _f = _c.c_float
 _L = _c.c_long
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libm2d_hip.so")
+LIB_PATH = os.environ.get("M2D_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                      "libm2d_hip.so")
 
 # name -> (restype, argtypes); mirrors include/m2d.h line by line
 SIGNATURES = {

@@ -27,11 +27,12 @@ static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, float* y,
   p.K = Cin * ks;
   p.phases = 1;
   // A(m = co, k = (ci,kk)) = W[co*Cin*ks + k]
-  m2d_operand_plain(p.A, w, Cout, Cin * ks, 1);
+  m2d_operand_plain(p.A, w, Cout, Cin * ks, 1, (long long)Cout * Cin * ks);
   // B(k = (ci,kk), col = (n,l)) = x[n*Cin*L + ci*L + l*s - p + kk]
   M2dOperand& b = p.B;
   memset(&b, 0, sizeof(b));
   b.base = x;
+  b.nbytes = m2d_extent_bytes((long long)B * Cin * L);
   b.nrows = p.N;
   b.rdiv = Lout;
   b.rdiv_inv = 1.f / (float)Lout;
@@ -103,10 +104,10 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
     p.N = Cin * ks;
     p.K = Cout;
     p.phases = 1;
-    m2d_operand_plain(p.A, dy, B, Cout, 1);
+    m2d_operand_plain(p.A, dy, B, Cout, 1, (long long)B * Cout);
     p.A.mask = dy_mask;
     p.A.mask_slope = dy_mask_slope;
-    m2d_operand_plain(p.B, w, p.N, 1, Cin * ks);
+    m2d_operand_plain(p.B, w, p.N, 1, Cin * ks, (long long)Cout * Cin * ks);
     m2d_outmap_plain(p.O, dx, Cin * ks, 1);
     return m2d_gemm_launch(p, true, false, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }
@@ -133,6 +134,7 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
   // A(m = ci, k = (co,t)) = W[co*Cin*ks + ci*ks + r + s*t]  (r added per phase on device)
   M2dOperand& a = p.A;
   a.base = w;
+  a.nbytes = m2d_extent_bytes((long long)Cout * Cin * ks);
   a.nrows = Cin;
   a.rdiv = 1;
   a.rdiv_inv = 1.f;
@@ -144,6 +146,7 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
   // B(k = (co,t), col = (n,q)) = dy[n*Cout*Lout + co*Lout + q - t], valid iff 0 <= q - t < Lout
   M2dOperand& b = p.B;
   b.base = dy;
+  b.nbytes = m2d_extent_bytes((long long)B * Cout * Lout);
   b.mask = dy_mask;
   b.mask_slope = dy_mask_slope;
   b.nrows = p.N;
@@ -187,6 +190,7 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
   // A(m = co, k = (n,l)) = dy[n*Cout*Lout + co*Lout + l]
   M2dOperand& a = p.A;
   a.base = dy;
+  a.nbytes = m2d_extent_bytes((long long)B * Cout * Lout);
   a.mask = dy_mask;
   a.mask_slope = dy_mask_slope;
   a.nrows = Cout;
@@ -200,6 +204,7 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
   // B(k = (n,l), col = (ci,kk)) = x[n*Cin*L + ci*L + l*s - pad + kk]
   M2dOperand& b = p.B;
   b.base = x;
+  b.nbytes = m2d_extent_bytes((long long)B * Cin * L);
   b.nrows = p.N;
   b.rdiv = ks;
   b.rdiv_inv = 1.f / (float)ks;
@@ -251,18 +256,18 @@ int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float*
   p.phases = 1;
   bool akf = true, bkf = true;
   if (mode == 0) {
-    m2d_operand_plain(p.A, a, M, K, 1);
-    m2d_operand_plain(p.B, b, N, K, 1);
+    m2d_operand_plain(p.A, a, M, K, 1, (long long)M * K);
+    m2d_operand_plain(p.B, b, N, K, 1, (long long)N * K);
     akf = true;
     bkf = true;
   } else if (mode == 1) {
-    m2d_operand_plain(p.A, a, M, K, 1);
-    m2d_operand_plain(p.B, b, N, 1, N);
+    m2d_operand_plain(p.A, a, M, K, 1, (long long)M * K);
+    m2d_operand_plain(p.B, b, N, 1, N, (long long)N * K);
     akf = true;
     bkf = false;
   } else {
-    m2d_operand_plain(p.A, a, M, 1, M);
-    m2d_operand_plain(p.B, b, N, 1, N);
+    m2d_operand_plain(p.A, a, M, 1, M, (long long)M * K);
+    m2d_operand_plain(p.B, b, N, 1, N, (long long)N * K);
     akf = false;
     bkf = false;
   }

@@ -21,12 +21,17 @@
 #pragma once
 #include "m2d_common.h"
 
+#ifndef M2D_BK
 #define M2D_BK 16
+#endif
+#define M2D_LDPAD (M2D_BK == 16 ? 2 : 1)
 
 struct M2dOperand {
   const float* base;
   const float* mask;  // optional, same addressing: value *= (mask > 0 ? 1 : mask_slope)
   float mask_slope;
+  unsigned nbytes;    // extent of `base` (and `mask`) in bytes, <= 0xFFFFFFF0: the staging loads are
+                      // raw buffer loads whose hardware range check returns 0 for padding / tails
   int nrows;
   int rdiv;
   float rdiv_inv;
@@ -79,10 +84,16 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split);
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what);
 
+static inline unsigned m2d_extent_bytes(long long elements) {
+  const long long b = elements * 4;
+  return b > 0xFFFFFFF0LL ? 0u : (unsigned)b;  // 0 = too large for buffer addressing (launch refuses)
+}
+
 static inline void m2d_operand_plain(M2dOperand& o, const float* base, int nrows, int row_stride,
-                                     int k_stride) {
+                                     int k_stride, long long elements) {
   memset(&o, 0, sizeof(o));
   o.base = base;
+  o.nbytes = m2d_extent_bytes(elements);
   o.nrows = nrows;
   o.rdiv = 1;
   o.rdiv_inv = 1.f;

@@ -20,22 +20,35 @@ __device__ __forceinline__ void m2d_divmod(int n, int d, float inv, int& q, int&
   }
 }
 
-__device__ __forceinline__ float m2d_fetch(const M2dOperand& op, int off) {
-  float x = op.base[off];
-  if (op.mask) x *= (op.mask[off] > 0.f ? 1.f : op.mask_slope);
-  return x;
+// Staging loads are raw buffer loads: an element that is padding, past the K tail or past the
+// last row gets the byte offset M2D_OOB, which the hardware range check (num_records =
+// operand extent) turns into 0.0f. No select, no divergent branch, and nothing that forces
+// a wait on the load before the LDS store that consumes it.
+#define M2D_OOB 0xFFFFFFF0u
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t m2d_rsrc(const float* p, unsigned nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)nbytes, 0x00020000);
 }
 
-// Per-thread row bookkeeping for one operand tile of BR rows x M2D_BK k-values.
-//   k-fast map : thread owns ONE k (tid % BK) and NE rows (tid / BK + i * 256 / BK)
-//   row-fast map: thread owns ONE row (tid % BR) and NE k's (tid / BR + i * 256 / BR)
-template <bool KF, int BR>
+__device__ __forceinline__ float m2d_bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+// Per-thread bookkeeping for one operand tile of BR rows x M2D_BK k-values.
+//   k-fast map  : thread owns ONE k (tid % BK) and NE rows (tid / BK + i * 256 / BK)
+//                 (operands whose K index is the contiguous one: weights, dy in bwd_weight)
+//   row-fast map: thread owns ONE row (tid % BR) and NE CONSECUTIVE k's starting at
+//                 (tid / BR) * NE: one divmod per chunk, the rest by stepping.
+template <bool KF, int BR, bool MASKED>
 struct TileMap {
   static constexpr int NE = BR * M2D_BK / 256;
   static constexpr int NR = KF ? NE : 1;
+  static constexpr int NM = MASKED ? NE : 1;
   int off[NR];
   int pos[NR];
   bool rv[NR];
+  float v[NE];   // staged values
+  float mv[NM];  // staged mask values (MASKED only)
 
   __device__ __forceinline__ void prep(const M2dOperand& op, int row0, int tid) {
 #pragma unroll
@@ -50,8 +63,15 @@ struct TileMap {
     }
   }
 
-  __device__ __forceinline__ void load(const M2dOperand& op, int k0, int kend, int tid,
-                                       float (&v)[NE]) const {
+  __device__ __forceinline__ void fetch(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs,
+                                        __amdgpu_buffer_rsrc_t rm, int i, int o, bool ok) {
+    const unsigned b = ok ? ((unsigned)o << 2) : M2D_OOB;
+    v[i] = m2d_bload(rs, b);
+    if constexpr (MASKED) mv[i] = op.mask ? m2d_bload(rm, b) : 1.f;
+  }
+
+  __device__ __forceinline__ void load(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs,
+                                       __amdgpu_buffer_rsrc_t rm, int k0, int kend, int tid) {
     if constexpr (KF) {
       const int k = k0 + (tid % M2D_BK);
       const bool kv = k < kend;
@@ -63,20 +83,30 @@ struct TileMap {
       for (int i = 0; i < NE; ++i) {
         bool ok = kv && rv[i];
         if (op.lim > 0) ok = ok && ((unsigned)(pos[i] + kpos) < (unsigned)op.lim);
-        v[i] = ok ? m2d_fetch(op, off[i] + koff) : 0.f;
+        fetch(op, rs, rm, i, off[i] + koff, ok);
       }
     } else {
+      int k = k0 + (tid / BR) * NE;
+      int hi, lo;
+      m2d_divmod(k < kend ? k : 0, op.kdiv, op.kdiv_inv, hi, lo);
+      int koff = hi * op.k_hi_stride + lo * op.k_lo_stride;
+      int kpos = lo * op.k_pos_mul;
+      const int wrap_off = op.k_hi_stride - op.kdiv * op.k_lo_stride;
+      const int wrap_pos = op.kdiv * op.k_pos_mul;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        const int k = k0 + tid / BR + i * (256 / BR);
-        const bool kv = k < kend;
-        int hi, lo;
-        m2d_divmod(kv ? k : 0, op.kdiv, op.kdiv_inv, hi, lo);
-        const int koff = hi * op.k_hi_stride + lo * op.k_lo_stride;
-        const int kpos = lo * op.k_pos_mul;
-        bool ok = kv && rv[0];
+        bool ok = (k < kend) && rv[0];
         if (op.lim > 0) ok = ok && ((unsigned)(pos[0] + kpos) < (unsigned)op.lim);
-        v[i] = ok ? m2d_fetch(op, off[0] + koff) : 0.f;
+        fetch(op, rs, rm, i, off[0] + koff, ok);
+        ++k;
+        ++lo;
+        koff += op.k_lo_stride;
+        kpos += op.k_pos_mul;
+        if (lo == op.kdiv) {
+          lo = 0;
+          koff += wrap_off;
+          kpos -= wrap_pos;
+        }
       }
     }
   }
@@ -84,12 +114,14 @@ struct TileMap {
   // LDS image is [k][row] with leading dimension LD (LD % 32 == 2 keeps the k-fast
   // writes conflict-free; row-fast writes and fragment reads are conflict-free anyway).
   template <int LD>
-  __device__ __forceinline__ void store(float* s, int tid, const float (&v)[NE]) const {
+  __device__ __forceinline__ void store(const M2dOperand& op, float* s, int tid) const {
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-      const int kl = KF ? (tid % M2D_BK) : (tid / BR + i * (256 / BR));
+      const int kl = KF ? (tid % M2D_BK) : ((tid / BR) * NE + i);
       const int rl = KF ? (tid / M2D_BK + i * (256 / M2D_BK)) : (tid % BR);
-      s[kl * LD + rl] = v[i];
+      float x = v[i];
+      if constexpr (MASKED) x *= (mv[i] > 0.f ? 1.f : op.mask_slope);
+      s[kl * LD + rl] = x;
     }
   }
 };
@@ -104,10 +136,10 @@ __device__ __forceinline__ float m2d_epilogue(const M2dOutMap& o, float v, int r
   return v;
 }
 
-template <int BM, int BN, bool AKF, bool BKF>
+template <int BM, int BN, bool AKF, bool BKF, bool MASKED>
 __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p) {
-  constexpr int LDA = BM + 2;
-  constexpr int LDB = BN + 2;
+  constexpr int LDA = BM + M2D_LDPAD;
+  constexpr int LDB = BN + M2D_LDPAD;
   constexpr int WM = BM >= 64 ? 2 : 1;
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (32 * WM);
@@ -163,10 +195,14 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   const int m0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
 
-  TileMap<AKF, BM> ta;
-  TileMap<BKF, BN> tb;
+  TileMap<AKF, BM, MASKED> ta;
+  TileMap<BKF, BN, MASKED> tb;
   ta.prep(A, m0, tid);
   tb.prep(B, n0, tid);
+  const __amdgpu_buffer_rsrc_t ra = m2d_rsrc(A.base, A.nbytes);
+  const __amdgpu_buffer_rsrc_t rb = m2d_rsrc(B.base, B.nbytes);
+  const __amdgpu_buffer_rsrc_t rma = m2d_rsrc(A.mask ? A.mask : A.base, A.nbytes);
+  const __amdgpu_buffer_rsrc_t rmb = m2d_rsrc(B.mask ? B.mask : B.base, B.nbytes);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -181,41 +217,54 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   const int c0 = split * cps;
   const int c1 = (c0 + cps < nchunks) ? (c0 + cps) : nchunks;
 
-  float va[TileMap<AKF, BM>::NE];
-  float vb[TileMap<BKF, BN>::NE];
-
   if (c0 < c1) {
-    ta.load(A, c0 * M2D_BK, K, tid, va);
-    tb.load(B, c0 * M2D_BK, K, tid, vb);
-    ta.template store<LDA>(smem, tid, va);
-    tb.template store<LDB>(smem + M2D_BK * LDA, tid, vb);
+    ta.load(A, ra, rma, c0 * M2D_BK, K, tid);
+    tb.load(B, rb, rmb, c0 * M2D_BK, K, tid);
+    ta.template store<LDA>(A, smem, tid);
+    tb.template store<LDB>(B, smem + M2D_BK * LDA, tid);
     __syncthreads();
     for (int c = c0; c < c1; ++c) {
       const int cur = (c - c0) & 1;
       const bool more = (c + 1) < c1;
+      // 1) issue the next chunk's global loads (they stay in flight under the MFMAs)
       if (more) {
-        ta.load(A, (c + 1) * M2D_BK, K, tid, va);
-        tb.load(B, (c + 1) * M2D_BK, K, tid, vb);
+        ta.load(A, ra, rma, (c + 1) * M2D_BK, K, tid);
+        tb.load(B, rb, rmb, (c + 1) * M2D_BK, K, tid);
       }
+      // 2) all fragment reads of this chunk, then the MFMAs: the compiler's counted
+      //    lgkmcnt lets the first MFMAs start while later fragments are still arriving
       const float* as = smem + cur * STAGE + wm * (TM * 32) + l31;
       const float* bs = smem + cur * STAGE + M2D_BK * LDA + wn * (TN * 32) + l31;
+      float fa[M2D_BK / 2][TM], fb[M2D_BK / 2][TN];
 #pragma unroll
       for (int kk = 0; kk < M2D_BK / 2; ++kk) {
-        float a[TM], b[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + lh) * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) fa[kk][i] = as[(2 * kk + lh) * LDA + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + lh) * LDB + j * 32];
+        for (int j = 0; j < TN; ++j) fb[kk][j] = bs[(2 * kk + lh) * LDB + j * 32];
+      }
+#pragma unroll
+      for (int kk = 0; kk < M2D_BK / 2; ++kk)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+      // pin the software pipeline: fragments of k-steps kk+2 are read while the MFMAs of
+      // k-step kk execute (hipcc otherwise re-sinks every read right in front of its use
+      // and exposes the LDS latency eight times per chunk)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int kk = 0; kk < M2D_BK / 2 - 2; ++kk) {
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+      // 3) land the prefetched chunk in the other LDS buffer
       if (more) {
         float* nxt = smem + (cur ^ 1) * STAGE;
-        ta.template store<LDA>(nxt, tid, va);
-        tb.template store<LDB>(nxt + M2D_BK * LDA, tid, vb);
+        ta.template store<LDA>(A, nxt, tid);
+        tb.template store<LDB>(B, nxt + M2D_BK * LDA, tid);
       }
       __syncthreads();
     }
@@ -303,7 +352,10 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split) {
 
 template <int BM, bool AKF, bool BKF>
 static void launch_tile(const M2dGemmParams& p, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF>), grid, dim3(256), 0, stream, p);
+  if (p.A.mask || p.B.mask)
+    hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, true>), grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, false>), grid, dim3(256), 0, stream, p);
 }
 
 template <int BM>
@@ -311,13 +363,15 @@ static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hi
   if (akf && !bkf) launch_tile<BM, true, false>(p, grid, stream);
   else if (!akf && !bkf) launch_tile<BM, false, false>(p, grid, stream);
   else if (akf && bkf) launch_tile<BM, true, true>(p, grid, stream);
-  else launch_tile<BM, false, true>(p, grid, stream);
+  else return -1;
   return 0;
 }
 
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what) {
   if (p.M <= 0 || p.N <= 0) return M2D_OK;
+  if (p.A.nbytes == 0 || p.B.nbytes == 0)
+    M2D_FAIL(M2D_ERR_RANGE, "%s: operand larger than 4 GiB (buffer addressing) or empty", what);
   if (p.phases < 1) p.phases = 1;
   const M2dGemmPlan pl = m2d_gemm_plan(p.M, p.N, p.K, p.bwd_data ? 2 : 1, allow_split);
   p.splits = pl.splits;
@@ -345,9 +399,11 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
   }
   {
     M2dProfScope prof(M2D_FAM_GEMM, stream, flops, 0.0);
-    if (pl.bm == 32) launch_maps<32>(p, a_kfast, b_kfast, grid, stream);
-    else if (pl.bm == 64) launch_maps<64>(p, a_kfast, b_kfast, grid, stream);
-    else launch_maps<128>(p, a_kfast, b_kfast, grid, stream);
+    int lrc;
+    if (pl.bm == 32) lrc = launch_maps<32>(p, a_kfast, b_kfast, grid, stream);
+    else if (pl.bm == 64) lrc = launch_maps<64>(p, a_kfast, b_kfast, grid, stream);
+    else lrc = launch_maps<128>(p, a_kfast, b_kfast, grid, stream);
+    if (lrc) M2D_FAIL(M2D_ERR_ARG, "%s: unsupported operand map combination", what);
     M2D_CHECK_LAUNCH(what);
     if (pl.splits > 1) {
       const size_t total = (size_t)p.M * p.N;

@@ -35,6 +35,11 @@ def timeit(fn, iters=5):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
 
+for n in (4096,):
+    a = torch.randn(n, n, device=dev); b = torch.randn(n, n, device=dev)
+    for mode in (0, 1, 2):
+        t = timeit(lambda: K.gemm(mode, a, b))
+        print("gemm mode %d %d^3: %.3f ms %.1f TF/s" % (mode, n, t, 2.0 * n ** 3 / t / 1e9))
 tot = {"fwd": 0, "bwd_data": 0, "bwd_weight": 0}
 print("%-14s %9s | %8s %7s | %8s %7s | %8s %7s" % ("layer", "GF", "fwd ms", "TF/s", "bwdD ms", "TF/s", "bwdW ms", "TF/s"))
 for name, b, cin, L, cout, ks, s, p in CASES:

@@ -1,0 +1,34 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+print("cpus", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)), "torch threads", torch.get_num_threads(), flush=True)
+from music2dance_amd import kernels
+from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+import bench
+B = int(os.environ.get("B", 64))
+dev = torch.device("cuda:0")
+gen, critic = bench.build_models(dev)
+eng = Phase3Engine(gen, critic, bench.P3_DEFAULT)
+real, audio, slices = synthetic_phase3_batch(B, 120, dev, seed=1)
+print("built", flush=True)
+def T(name, fn):
+    torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+    print("%-28s %8.1f ms" % (name, 1e3 * (time.perf_counter() - t)), flush=True); return r
+with torch.no_grad():
+    T("gen fwd nograd", lambda: gen(slices, [120] * B))
+    T("gen fwd nograd 2", lambda: gen(slices, [120] * B))
+T("critic iter 1", lambda: eng.critic_iteration(real, audio, slices))
+T("critic iter 2", lambda: eng.critic_iteration(real, audio, slices))
+T("critic iter 3", lambda: eng.critic_iteration(real, audio, slices))
+T("gen iter 1", lambda: eng.generator_iteration(real, audio, slices))
+T("gen iter 2", lambda: eng.generator_iteration(real, audio, slices))
+K = kernels.impl()
+K.prof_begin()
+T("critic iter prof", lambda: eng.critic_iteration(real, audio, slices))
+eng.flush()
+p = K.prof_end()
+print({k: (round(v["ms"], 2), v["launches"], round(v["flops"] / 1e9, 1)) for k, v in p.items()}, flush=True)
+K.prof_begin()
+T("gen iter prof", lambda: eng.generator_iteration(real, audio, slices))
+p = K.prof_end()
+print({k: (round(v["ms"], 2), v["launches"], round(v["flops"] / 1e9, 1)) for k, v in p.items()}, flush=True)
