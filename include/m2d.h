@@ -40,6 +40,8 @@ int m2d_version(void);
  * Families: 0 gemm engine, 1 batch-norm, 2 gru, 3 pointwise, 4 reductions. */
 int m2d_prof_begin(void);
 int m2d_prof_end(double* out, int n_out /* >= 20 */);
+/* per-launch CSV "family,tag,d0,d1,d2,ms,flops" of the current session; call before m2d_prof_end */
+int m2d_prof_dump(char* buf, int cap);
 
 /* ---- conv1d: nn.Conv1d forward and both halves of its backward -------------------------
  * reference: phase3/archis/default.py:64-70 (DefaultAudioEncoder), :90-97,216 (U-Net),

@@ -167,6 +167,29 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
   p.O.c_lo_stride = stride;
   p.O.c_pos_mul = stride;
   p.O.c_lim = L;
+  if (stride == 1) {
+    // single phase: resolve the phase parameters here (r = 0, taps = ks, q in [pad, L-1+pad]) so the
+    // launch is an ordinary GEMM and may be split along K (the TCN critic's small grids need it)
+    p.bwd_data = 0;
+    p.phases = 1;
+    p.N = B * L;
+    p.K = Cout * ks;
+    a.kdiv = ks;
+    a.kdiv_inv = 1.f / (float)ks;
+    b.kdiv = ks;
+    b.kdiv_inv = a.kdiv_inv;
+    b.nrows = p.N;
+    b.rdiv = L;
+    b.rdiv_inv = 1.f / (float)L;
+    b.r_off = pad;
+    b.r_pos_off = pad;
+    p.O.cdiv = L;
+    p.O.cdiv_inv = b.rdiv_inv;
+    p.O.c_off = 0;
+    p.O.c_pos_off = 0;
+    return m2d_gemm_launch(p, /*a_kfast=*/false, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
+                           (hipStream_t)stream, "m2d_conv1d_bwd_data");
+  }
   return m2d_gemm_launch(p, /*a_kfast=*/false, /*b_kfast=*/false, /*allow_split=*/false, ws, ws_bytes,
                          (hipStream_t)stream, "m2d_conv1d_bwd_data");
 }
@@ -231,6 +254,7 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
   if (which == 0) return m2d_gemm_plan(Cout, B * Lout, Cin * ks, 1, true).ws_bytes;
   if (which == 1) {
     if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(B, Cin * ks, Cout, 1, true).ws_bytes;
+    if (stride == 1) return m2d_gemm_plan(Cin, B * L, Cout * ks, 1, true).ws_bytes;
     return 0;
   }
   return m2d_gemm_plan(Cout, Cin * ks, B * Lout, 1, true).ws_bytes;

@@ -320,8 +320,8 @@ __global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmPar
 
 M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split) {
   M2dGemmPlan pl;
-  // pick the M tile that wastes the fewest padded rows; small tiles carry a penalty
-  // because their waves re-read the B tile more often per flop.
+  // 1) the M tile that wastes the fewest padded rows; small tiles carry a penalty because
+  //    their waves re-read the B tile more often per flop.
   const int cands[3] = {32, 64, 128};
   const double pen[3] = {1.4, 1.1, 1.0};
   double best = 1e30;
@@ -333,18 +333,33 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split) {
       pl.bm = cands[i];
     }
   }
+  // 2) fill the chip (256 CUs x 2-4 resident blocks): split K first while every split keeps
+  //    >= 32 chunks (cheap: one slab pass), then trade tile height for block count (short-K
+  //    problems such as the TCN critic's N = B*T = 7680 columns), then split again down to
+  //    >= 8 chunks per split.
+  const long long nt = m2d_ceil_div(N, 128);
+  const int ph = phases > 1 ? phases : 1;
+  const int nchunks = m2d_ceil_div(K, M2D_BK);
+  const bool can_split = allow_split && phases <= 1;
   pl.splits = 1;
   pl.ws_bytes = 0;
-  if (allow_split && phases <= 1) {
-    const long long base = (long long)m2d_ceil_div(M, pl.bm) * m2d_ceil_div(N, 128);
-    const int nchunks = m2d_ceil_div(K, M2D_BK);
-    if (base < 256 && nchunks >= 8) {
-      long long s = m2d_ceil_div64(512, base);
-      if (s > nchunks / 4) s = nchunks / 4;
-      if (s > 128) s = 128;
-      if (s < 1) s = 1;
-      pl.splits = (int)s;
-    }
+  long long blocks = (long long)m2d_ceil_div(M, pl.bm) * nt * ph;
+  if (can_split && blocks < 384 && nchunks >= 64) {
+    long long s = m2d_ceil_div64(512, blocks);
+    if (s > nchunks / 32) s = nchunks / 32;
+    if (s > 128) s = 128;
+    if (s > 1) pl.splits = (int)s;
+  }
+  while (pl.bm > 32 && blocks * pl.splits < 384 &&
+         (long long)m2d_ceil_div(M, pl.bm / 2) * nt * ph * pl.splits <= 1024) {
+    pl.bm /= 2;
+    blocks = (long long)m2d_ceil_div(M, pl.bm) * nt * ph;
+  }
+  if (can_split && pl.splits == 1 && blocks < 384 && nchunks >= 16) {
+    long long s = m2d_ceil_div64(512, blocks);
+    if (s > nchunks / 8) s = nchunks / 8;
+    if (s > 128) s = 128;
+    if (s > 1) pl.splits = (int)s;
   }
   if (pl.splits > 1) pl.ws_bytes = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
   return pl;
@@ -398,7 +413,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
     }
   }
   {
-    M2dProfScope prof(M2D_FAM_GEMM, stream, flops, 0.0);
+    M2dProfScope prof(M2D_FAM_GEMM, stream, flops, 0.0, what, p.M, p.N, p.K);
     int lrc;
     if (pl.bm == 32) lrc = launch_maps<32>(p, a_kfast, b_kfast, grid, stream);
     else if (pl.bm == 64) lrc = launch_maps<64>(p, a_kfast, b_kfast, grid, stream);

@@ -42,7 +42,8 @@ struct M2dProfScope {
   int fam;
   hipStream_t stream;
   int slot;
-  M2dProfScope(int family, hipStream_t s, double flops, double bytes);
+  M2dProfScope(int family, hipStream_t s, double flops, double bytes, const char* tag = nullptr, int d0 = 0,
+               int d1 = 0, int d2 = 0);
   ~M2dProfScope();
 };
 

@@ -20,6 +20,8 @@ struct ProfRec {
   hipEvent_t a, b;
   int fam;
   double flops, bytes;
+  char tag[40];
+  int d[3];
 };
 
 static std::mutex g_prof_mu;
@@ -27,7 +29,8 @@ static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_recs;      // used records of the current session
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;  // recycled events
 
-M2dProfScope::M2dProfScope(int family, hipStream_t s, double flops, double bytes)
+M2dProfScope::M2dProfScope(int family, hipStream_t s, double flops, double bytes, const char* tag, int d0, int d1,
+                           int d2)
     : fam(family), stream(s), slot(-1) {
   if (!g_prof_on) return;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -44,6 +47,10 @@ M2dProfScope::M2dProfScope(int family, hipStream_t s, double flops, double bytes
   r.fam = family;
   r.flops = flops;
   r.bytes = bytes;
+  snprintf(r.tag, sizeof(r.tag), "%s", tag ? tag : "");
+  r.d[0] = d0;
+  r.d[1] = d1;
+  r.d[2] = d2;
   hipEventRecord(r.a, s);
   g_prof_recs.push_back(r);
   slot = (int)g_prof_recs.size() - 1;
@@ -69,6 +76,21 @@ int m2d_prof_begin(void) {
   g_prof_recs.clear();
   g_prof_on = true;
   return M2D_OK;
+}
+
+// Per-launch dump of the records collected since m2d_prof_begin (call BEFORE m2d_prof_end):
+// one line "family,tag,d0,d1,d2,ms,flops" per launch. Returns the number of bytes written.
+int m2d_prof_dump(char* buf, int cap) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = 0;
+  for (auto& r : g_prof_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    if (cap - n < 160) break;
+    n += snprintf(buf + n, cap - n, "%d,%s,%d,%d,%d,%.6f,%.0f\n", r.fam, r.tag, r.d[0], r.d[1], r.d[2], ms, r.flops);
+  }
+  return n;
 }
 
 // Stop collecting; out[f*4 + {0,1,2,3}] = {total ms, launches, algorithmic flops,

@@ -319,6 +319,17 @@ class HipKernels:
     def prof_begin(self):
         _lib.check(_lib.lib().m2d_prof_begin(), "m2d_prof_begin")
 
+    def prof_dump(self):
+        """[(family, tag, d0, d1, d2, ms, flops)] per launch of the current profiling session."""
+        cap = 1 << 22
+        buf = ctypes.create_string_buffer(cap)
+        n = _lib.lib().m2d_prof_dump(buf, cap)
+        rows = []
+        for line in buf.raw[:n].decode().splitlines():
+            f = line.split(",")
+            rows.append((int(f[0]), f[1], int(f[2]), int(f[3]), int(f[4]), float(f[5]), float(f[6])))
+        return rows
+
     def prof_end(self):
         buf = (ctypes.c_double * 20)()
         _lib.check(_lib.lib().m2d_prof_end(buf, 20), "m2d_prof_end")

@@ -32,3 +32,15 @@ K.prof_begin()
 T("gen iter prof", lambda: eng.generator_iteration(real, audio, slices))
 p = K.prof_end()
 print({k: (round(v["ms"], 2), v["launches"], round(v["flops"] / 1e9, 1)) for k, v in p.items()}, flush=True)
+import collections
+for name, fn in (("critic", lambda: eng.critic_iteration(real, audio, slices)), ("gen", lambda: eng.generator_iteration(real, audio, slices))):
+    K.prof_begin(); fn(); eng.flush(); torch.cuda.synchronize()
+    rows = K.prof_dump(); K.prof_end()
+    agg = collections.OrderedDict()
+    for fam, tag, d0, d1, d2, ms, fl in rows:
+        if fam != 0: continue
+        k = (tag, d0, d1, d2)
+        a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
+    print("==== %s iteration: engine launches by shape (tag M N K: count, ms, TF/s)" % name)
+    for k, (c, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("%-24s %6d %8d %7d : %3d %8.3f ms %6.1f TF/s" % (k[0], k[1], k[2], k[3], c, ms, fl / ms / 1e9 if ms else 0))
