@@ -19,6 +19,18 @@ static inline int conv_out_len(int L, int ks, int stride, int pad) {
 
 static inline bool fits_i32(long long v) { return v >= 0 && v < 2147483647LL; }
 
+// conv1d_thin.hip: vector-ALU kernels for Cin = 1, k = 25, stride 4 (HBM-bound layers)
+bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride);
+size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout);
+int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
+                 int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
+                 hipStream_t stream);
+int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, int Cout, int ks, int stride,
+                      int pad, int Lout, const float* dy_mask, float dy_mask_slope, hipStream_t stream);
+int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L, int Cout, int ks, int stride,
+                        int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes,
+                        hipStream_t stream);
+
 static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, float* y, int B, int Cin,
                      int L, int Cout, int ks, int stride, int pad, int Lout) {
   memset(&p, 0, sizeof(p));
@@ -71,6 +83,9 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, 
   if (Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd: empty output (L=%d k=%d s=%d p=%d)", L, ks, stride, pad);
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd: tensor exceeds 2^31 elements");
+  if (!residual && m2d_thin_applicable(Cin, Cout, ks, stride))
+    return m2d_thin_fwd(x, w, bias, y, B, L, Cout, ks, stride, pad, Lout, act, slope, out_mask, out_mask_slope,
+                        (hipStream_t)stream);
   M2dGemmParams p;
   fill_fwd(p, x, w, y, B, Cin, L, Cout, ks, stride, pad, Lout);
   p.O.bias = bias;
@@ -96,6 +111,9 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout) ||
       !fits_i32((long long)Cout * Cin * ks))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_bwd_data: tensor exceeds 2^31 elements");
+  if (m2d_thin_applicable(Cin, Cout, ks, stride))
+    return m2d_thin_bwd_data(dy, w, dx, B, L, Cout, ks, stride, pad, Lout, dy_mask, dy_mask_slope,
+                             (hipStream_t)stream);
   M2dGemmParams p;
   memset(&p, 0, sizeof(p));
   if (Lout == 1 && pad == 0 && L == ks) {
@@ -204,6 +222,9 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight: bad shape");
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_bwd_weight: tensor exceeds 2^31 elements");
+  if (m2d_thin_applicable(Cin, Cout, ks, stride))
+    return m2d_thin_bwd_weight(x, dy, dw, B, L, Cout, ks, stride, pad, Lout, dy_mask, dy_mask_slope, ws, ws_bytes,
+                               (hipStream_t)stream);
   M2dGemmParams p;
   memset(&p, 0, sizeof(p));
   p.M = Cout;
@@ -251,6 +272,7 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
 size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, int ks, int stride, int pad) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (Lout <= 0) return 0;
+  if (m2d_thin_applicable(Cin, Cout, ks, stride)) return which == 2 ? m2d_thin_bwd_weight_ws(B, Cout, ks, Lout) : 0;
   if (which == 0) return m2d_gemm_plan(Cout, B * Lout, Cin * ks, 1, true).ws_bytes;
   if (which == 1) {
     if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(B, Cin * ks, Cout, 1, true).ws_bytes;

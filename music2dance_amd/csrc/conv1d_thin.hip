@@ -1,0 +1,269 @@
+// "Thin" conv1d kernels for single-input-channel layers with short kernels
+// (AudioDiscriminator.l1, phase3/archis/default.py:298, and WaveGAN l1, :117:
+// Conv1d(1, 32, 25, stride=4)). With Cin = 1 the contraction length is only k = 25, the
+// arithmetic intensity is ~11 flop/B and the op is HBM-bound: the 157 MB
+// activation / gradient tensor must be streamed once, everything else fits in cache. A
+// 32x32 MFMA tile would be >80 % padding here, so these use the vector ALU:
+//   forward        : thread = one output position l, all Cout channels from ONE window
+//   backward-data  : thread = one q, the `stride` outputs j = s*q + r - pad of that q
+//   backward-weight: thread = one l per step, 4 channels x k taps of register partials,
+//                    block-reduced, deterministic two-stage sum (no atomics)
+// Weights sit in LDS and are read as broadcasts. Masks (activation derivative) follow the
+// convention of gemm_engine.h: value *= (mask > 0 ? 1 : slope).
+#include "m2d_common.h"
+
+#define THIN_MAX_K 32
+#define THIN_MAX_W 2048  // Cout * k floats of LDS
+
+struct ThinArgs {
+  const float* x;      // (B, 1, L)
+  const float* w;      // (Cout, 1, ks)
+  const float* bias;   // fwd only, may be NULL
+  const float* dy;     // (B, Cout, Lout)   bwd
+  const float* mask;   // optional
+  float* out;          // fwd: y; bwd_data: dx; bwd_weight: partial slabs
+  int B, L, Cout, ks, stride, pad, Lout;
+  int act;
+  float slope, mask_slope;
+  int chunk;           // bwd_weight: positions per block
+};
+
+// Register blocking: every thread owns P CONSECUTIVE output positions, so that one weight
+// read (an LDS broadcast) feeds P FMAs and the input windows of neighbouring positions,
+// which overlap by k - stride samples, are loaded once.
+template <int KS, int S, int P>
+__global__ void __launch_bounds__(256) thin_fwd_kernel(const ThinArgs a) {
+  __shared__ float wl[THIN_MAX_W];
+  for (int i = threadIdx.x; i < a.Cout * KS; i += 256) wl[i] = a.w[i];
+  __syncthreads();
+  constexpr int XW = KS + S * (P - 1);
+  const int n = blockIdx.y;
+  const int l0 = (blockIdx.x * 256 + threadIdx.x) * P;
+  if (l0 >= a.Lout) return;
+  const float* xr = a.x + (size_t)n * a.L;
+  float xw[XW];
+  const int base = l0 * S - a.pad;
+#pragma unroll
+  for (int k = 0; k < XW; ++k) {
+    const int pos = base + k;
+    xw[k] = (pos >= 0 && pos < a.L) ? xr[pos] : 0.f;
+  }
+  const size_t orow = (size_t)n * a.Cout * a.Lout + l0;
+  const bool vec = (P == 4) && (a.Lout % 4 == 0);
+  for (int co = 0; co < a.Cout; ++co) {
+    float acc[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const float wv = wl[co * KS + k];
+#pragma unroll
+      for (int j = 0; j < P; ++j) acc[j] += wv * xw[k + S * j];
+    }
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    const size_t o = orow + (size_t)co * a.Lout;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float v = acc[j] + bv;
+      if (a.act == 1) v = v > 0.f ? v : 0.f;
+      else if (a.act == 2) v = v > 0.f ? v : v * a.slope;
+      if (a.mask && l0 + j < a.Lout) v *= (a.mask[o + j] > 0.f ? 1.f : a.mask_slope);
+      acc[j] = v;
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(a.out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+        if (l0 + j < a.Lout) a.out[o + j] = acc[j];
+    }
+  }
+}
+
+// dx[n, s*q + r - pad] = sum_co sum_t W[co, r + s*t] * dy[n, co, q - t]; thread = P consecutive q
+template <int KS, int S, int P>
+__global__ void __launch_bounds__(256) thin_bwd_data_kernel(const ThinArgs a) {
+  __shared__ float wl[THIN_MAX_W];
+  for (int i = threadIdx.x; i < a.Cout * KS; i += 256) wl[i] = a.w[i];
+  __syncthreads();
+  constexpr int T = (KS + S - 1) / S;
+  constexpr int DW = T + P - 1;  // dy window: l in [q0 - (T-1), q0 + P - 1]
+  const int n = blockIdx.y;
+  const int q0 = (blockIdx.x * 256 + threadIdx.x) * P;
+  const int nq = (a.L - 1 + a.pad) / S + 1;
+  if (q0 >= nq) return;
+  float acc[P][S];
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int r = 0; r < S; ++r) acc[j][r] = 0.f;
+  const float* dyn = a.dy + (size_t)n * a.Cout * a.Lout;
+  const float* mkn = a.mask ? a.mask + (size_t)n * a.Cout * a.Lout : nullptr;
+  for (int co = 0; co < a.Cout; ++co) {
+    float v[DW];
+#pragma unroll
+    for (int i = 0; i < DW; ++i) {
+      const int l = q0 - (T - 1) + i;
+      float d = 0.f;
+      if (l >= 0 && l < a.Lout) {
+        d = dyn[(size_t)co * a.Lout + l];
+        if (mkn) d *= (mkn[(size_t)co * a.Lout + l] > 0.f ? 1.f : a.mask_slope);
+      }
+      v[i] = d;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < S; ++r)
+        if (r + S * t < KS) {
+          const float wv = wl[co * KS + r + S * t];
+#pragma unroll
+          for (int j = 0; j < P; ++j) acc[j][r] += wv * v[(T - 1) + j - t];  // l = q0 + j - t
+        }
+  }
+  float* dxn = a.out + (size_t)n * a.L;
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+      const int jj = S * (q0 + j) + r - a.pad;
+      if (jj >= 0 && jj < a.L) dxn[jj] = acc[j][r];
+    }
+}
+
+// partial[block][co_local][k] = sum over the block's positions of dy[n,co,l] * x[n, l*s - pad + k];
+// thread = P consecutive positions per step (dy read as contiguous runs, x window slid in registers)
+template <int KS, int S, int P>
+__global__ void __launch_bounds__(256) thin_bwd_weight_kernel(const ThinArgs a) {
+  __shared__ float red[4][4 * KS];
+  constexpr int XW = KS + S * (P - 1);
+  const int n = blockIdx.y;
+  const int cg = blockIdx.z;  // group of 4 output channels
+  const int l0 = blockIdx.x * a.chunk;
+  int l1 = l0 + a.chunk;
+  if (l1 > a.Lout) l1 = a.Lout;
+  float acc[4][KS];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc[c][k] = 0.f;
+  const float* xr = a.x + (size_t)n * a.L;
+  const float* dyn = a.dy + ((size_t)n * a.Cout + cg * 4) * a.Lout;
+  const float* mkn = a.mask ? a.mask + ((size_t)n * a.Cout + cg * 4) * a.Lout : nullptr;
+  for (int l = l0 + threadIdx.x * P; l < l1; l += 256 * P) {
+    float xw[XW];
+    const int base = l * S - a.pad;
+#pragma unroll
+    for (int k = 0; k < XW; ++k) {
+      const int pos = base + k;
+      xw[k] = (pos >= 0 && pos < a.L) ? xr[pos] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float d[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        float v = 0.f;
+        if (l + j < l1) {
+          v = dyn[(size_t)c * a.Lout + l + j];
+          if (mkn) v *= (mkn[(size_t)c * a.Lout + l + j] > 0.f ? 1.f : a.mask_slope);
+        }
+        d[j] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int j = 0; j < P; ++j) acc[c][k] += d[j] * xw[k + S * j];
+    }
+  }
+  // wave reduction (64 lanes), then the 4 waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      float v = acc[c][k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wave][c * KS + k] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 4 * KS) {
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;  // (n, chunk)
+    const int c = threadIdx.x / KS, k = threadIdx.x % KS;
+    a.out[(blk * a.Cout + cg * 4 + c) * KS + k] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) thin_sum_partials_kernel(const float* partial, float* dw, int nblk, int n_out) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_out) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * n_out + o];
+  dw[o] = (float)s;
+}
+
+static bool thin_ok(int Cin, int Cout, int ks, int stride) {
+  return Cin == 1 && (ks == 25) && (stride == 4) && Cout % 4 == 0 && Cout * ks <= THIN_MAX_W;
+}
+
+bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride) { return thin_ok(Cin, Cout, ks, stride); }
+
+static const int THIN_BW_CHUNK = 32768;
+
+size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout) {
+  const size_t nblk = (size_t)B * m2d_ceil_div(Lout, THIN_BW_CHUNK);
+  return nblk * Cout * ks * sizeof(float);
+}
+
+int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
+                 int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
+                 hipStream_t stream) {
+  ThinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.bias = bias; a.mask = out_mask; a.out = y;
+  a.B = B; a.L = L; a.Cout = Cout; a.ks = ks; a.stride = stride; a.pad = pad; a.Lout = Lout;
+  a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
+                    4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
+  hipLaunchKernelGGL((thin_fwd_kernel<25, 4, 4>), dim3(m2d_ceil_div(Lout, 1024), B), dim3(256), 0, stream, a);
+  M2D_CHECK_LAUNCH("thin_fwd_kernel");
+  return M2D_OK;
+}
+
+int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, int Cout, int ks, int stride,
+                      int pad, int Lout, const float* dy_mask, float dy_mask_slope, hipStream_t stream) {
+  ThinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = dy; a.w = w; a.mask = dy_mask; a.out = dx;
+  a.B = B; a.L = L; a.Cout = Cout; a.ks = ks; a.stride = stride; a.pad = pad; a.Lout = Lout;
+  a.mask_slope = dy_mask_slope;
+  const int nq = (L - 1 + pad) / stride + 1;
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
+                    4.0 * B * ((double)L + (double)Cout * Lout * (dy_mask ? 2 : 1)), "thin_conv_bwd_data", 1, B * L, Cout * ks);
+  hipLaunchKernelGGL((thin_bwd_data_kernel<25, 4, 4>), dim3(m2d_ceil_div(nq, 1024), B), dim3(256), 0, stream, a);
+  M2D_CHECK_LAUNCH("thin_bwd_data_kernel");
+  return M2D_OK;
+}
+
+int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L, int Cout, int ks, int stride,
+                        int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes,
+                        hipStream_t stream) {
+  if (!ws || ws_bytes < m2d_thin_bwd_weight_ws(B, Cout, ks, Lout))
+    M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_bwd_weight (thin): workspace too small");
+  ThinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.dy = dy; a.mask = dy_mask; a.out = (float*)ws;
+  a.B = B; a.L = L; a.Cout = Cout; a.ks = ks; a.stride = stride; a.pad = pad; a.Lout = Lout;
+  a.mask_slope = dy_mask_slope;
+  a.chunk = THIN_BW_CHUNK;
+  const int nchunk = m2d_ceil_div(Lout, THIN_BW_CHUNK);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
+                    4.0 * B * ((double)L + (double)Cout * Lout * (dy_mask ? 2 : 1)), "thin_conv_bwd_weight", Cout, ks, B * Lout);
+  hipLaunchKernelGGL((thin_bwd_weight_kernel<25, 4, 8>), dim3(nchunk, B, Cout / 4), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(thin_sum_partials_kernel, dim3(m2d_ceil_div(Cout * ks, 256)), dim3(256), 0, stream,
+                     (const float*)ws, dw, nchunk * B, Cout * ks);
+  M2D_CHECK_LAUNCH("thin_bwd_weight_kernel");
+  return M2D_OK;
+}

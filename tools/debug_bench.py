@@ -38,7 +38,7 @@ for name, fn in (("critic", lambda: eng.critic_iteration(real, audio, slices)), 
     rows = K.prof_dump(); K.prof_end()
     agg = collections.OrderedDict()
     for fam, tag, d0, d1, d2, ms, fl in rows:
-        if fam != 0: continue
+        if fam != 0 and not tag.startswith('thin'): continue
         k = (tag, d0, d1, d2)
         a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
     print("==== %s iteration: engine launches by shape (tag M N K: count, ms, TF/s)" % name)
