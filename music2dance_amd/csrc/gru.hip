@@ -15,6 +15,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#define GRU_UNROLL 16
+
 __device__ __forceinline__ float gru_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 struct GruFwdArgs {
@@ -49,18 +51,27 @@ __global__ void __launch_bounds__(256) m2d_gru_fwd_step_kernel(const GruFwdArgs 
     const bool cok = bcol < H;
     const float* hp = a.out + ((size_t)arow * T + (t - 1)) * H;
     const int nsteps = (H + 3) / 4;
-#pragma unroll 4
-    for (int s = wave; s < nsteps; s += 4) {
-      const int k = 4 * s + (lane >> 4);
-      const bool kok = k < H;
-      const float av = (rok && kok) ? hp[k] : 0.f;
-      const float* wrow = a.w_hh_t + (size_t)k * 3 * H + bcol;
-      const float b0v = (kok && cok) ? wrow[0] : 0.f;
-      const float b1v = (kok && cok) ? wrow[H] : 0.f;
-      const float b2v = (kok && cok) ? wrow[2 * H] : 0.f;
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0v, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2v, acc[2], 0, 0, 0);
+    // the step is pure latency: issue every operand load of a batch of GRU_UNROLL k-steps
+    // before the first MFMA so the batch costs one memory round trip
+    for (int s0 = wave; s0 < nsteps; s0 += 4 * GRU_UNROLL) {
+      float av[GRU_UNROLL], bv[GRU_UNROLL][3];
+#pragma unroll
+      for (int i = 0; i < GRU_UNROLL; ++i) {
+        const int k = 4 * (s0 + 4 * i) + (lane >> 4);
+        const bool kok = (s0 + 4 * i) < nsteps && k < H;
+        av[i] = (rok && kok) ? hp[k] : 0.f;
+        const float* wrow = a.w_hh_t + (size_t)(kok ? k : 0) * 3 * H + (cok ? bcol : 0);
+        const bool ok = kok && cok;
+        bv[i][0] = ok ? wrow[0] : 0.f;
+        bv[i][1] = ok ? wrow[H] : 0.f;
+        bv[i][2] = ok ? wrow[2 * H] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < GRU_UNROLL; ++i) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][1], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][2], acc[2], 0, 0, 0);
+      }
     }
   }
   // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -127,13 +138,17 @@ __global__ void __launch_bounds__(256) m2d_gru_bwd_step_kernel(const GruBwdArgs 
     const float* dg = a.dgh + ((size_t)arow * T + (t + 1)) * 3 * H;
     const int K = 3 * H;
     const int nsteps = (K + 3) / 4;
-#pragma unroll 4
-    for (int s = wave; s < nsteps; s += 4) {
-      const int k = 4 * s + (lane >> 4);
-      const bool kok = k < K;
-      const float av = (rok && kok) ? dg[k] : 0.f;
-      const float bv = (kok && cok) ? a.w_hh[(size_t)k * H + bcol] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    for (int s0 = wave; s0 < nsteps; s0 += 4 * GRU_UNROLL) {
+      float av[GRU_UNROLL], bv[GRU_UNROLL];
+#pragma unroll
+      for (int i = 0; i < GRU_UNROLL; ++i) {
+        const int k = 4 * (s0 + 4 * i) + (lane >> 4);
+        const bool kok = (s0 + 4 * i) < nsteps && k < K;
+        av[i] = (rok && kok) ? dg[k] : 0.f;
+        bv[i] = (kok && cok) ? a.w_hh[(size_t)k * H + bcol] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < GRU_UNROLL; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
     }
   }
 #pragma unroll
