@@ -39,6 +39,12 @@ __device__ __forceinline__ float m2d_bload(__amdgpu_buffer_rsrc_t r, unsigned by
 //                 (operands whose K index is the contiguous one: weights, dy in bwd_weight)
 //   row-fast map: thread owns ONE row (tid % BR) and NE CONSECUTIVE k's starting at
 //                 (tid / BR) * NE: one divmod per chunk, the rest by stepping.
+// Validity is folded into ONE unsigned window test per element: pos_row + pos_k < lim_eff.
+// Rows past the extent get pos_row = M2D_BAD, k's past the tail get pos_k = M2D_BAD, operands
+// without a window use lim_eff = M2D_BAD - 1 with all positions 0. (Booleans combined with
+// && / ?: made hipcc materialise 0/1 integers: ~7 VALU per element instead of 4.)
+#define M2D_BAD 0x40000000
+
 template <bool KF, int BR, bool MASKED>
 struct TileMap {
   static constexpr int NE = BR * M2D_BK / 256;
@@ -46,67 +52,85 @@ struct TileMap {
   static constexpr int NM = MASKED ? NE : 1;
   int off[NR];
   int pos[NR];
-  bool rv[NR];
   float v[NE];   // staged values
   float mv[NM];  // staged mask values (MASKED only)
+  int kbase, khi, klo;  // row-fast maps: k decomposition of the chunk's first element
+  unsigned lim_eff;
 
   __device__ __forceinline__ void prep(const M2dOperand& op, int row0, int tid) {
+    lim_eff = op.lim > 0 ? (unsigned)op.lim : (unsigned)(M2D_BAD - 1);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int rl = KF ? (tid / M2D_BK + i * (256 / M2D_BK)) : (tid % BR);
       const int g = row0 + rl;
-      rv[i] = g < op.nrows;
+      const bool rv = g < op.nrows;
       int hi, lo;
-      m2d_divmod(rv[i] ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
+      m2d_divmod(rv ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
       off[i] = hi * op.r_hi_stride + lo * op.r_lo_stride + op.r_off;
-      pos[i] = lo * op.r_pos_mul + op.r_pos_off;
+      pos[i] = rv ? (op.lim > 0 ? lo * op.r_pos_mul + op.r_pos_off : 0) : M2D_BAD;
     }
   }
 
   __device__ __forceinline__ void fetch(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs,
-                                        __amdgpu_buffer_rsrc_t rm, int i, int o, bool ok) {
-    const unsigned b = ok ? ((unsigned)o << 2) : M2D_OOB;
+                                        __amdgpu_buffer_rsrc_t rm, int i, int o, int p) {
+    const unsigned b = ((unsigned)p < lim_eff) ? ((unsigned)o << 2) : M2D_OOB;
     v[i] = m2d_bload(rs, b);
     if constexpr (MASKED) mv[i] = op.mask ? m2d_bload(rm, b) : 1.f;
   }
 
   __device__ __forceinline__ void load(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs,
                                        __amdgpu_buffer_rsrc_t rm, int k0, int kend, int tid) {
+    const int pmul = op.lim > 0 ? op.k_pos_mul : 0;
     if constexpr (KF) {
       const int k = k0 + (tid % M2D_BK);
       const bool kv = k < kend;
       int hi, lo;
       m2d_divmod(kv ? k : 0, op.kdiv, op.kdiv_inv, hi, lo);
       const int koff = hi * op.k_hi_stride + lo * op.k_lo_stride;
-      const int kpos = lo * op.k_pos_mul;
+      const int kpos = kv ? lo * pmul : M2D_BAD;
 #pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        bool ok = kv && rv[i];
-        if (op.lim > 0) ok = ok && ((unsigned)(pos[i] + kpos) < (unsigned)op.lim);
-        fetch(op, rs, rm, i, off[i] + koff, ok);
-      }
+      for (int i = 0; i < NE; ++i) fetch(op, rs, rm, i, off[i] + koff, pos[i] + kpos);
     } else {
-      int k = k0 + (tid / BR) * NE;
-      int hi, lo;
-      m2d_divmod(k < kend ? k : 0, op.kdiv, op.kdiv_inv, hi, lo);
-      int koff = hi * op.k_hi_stride + lo * op.k_lo_stride;
-      int kpos = lo * op.k_pos_mul;
+      // (tid / BR) is wave-uniform when BR >= 64 (a wave is 64 consecutive threads), so the
+      // whole k decomposition below lives in SGPRs / the scalar ALU and costs no VALU issue:
+      // per element the vector side only adds the offset, tests the window and selects OOB.
+      int k = k0 + kbase;
+      int lo = klo;
+      int koff = khi * op.k_hi_stride + klo * op.k_lo_stride;
+      int kpos = klo * pmul;
       const int wrap_off = op.k_hi_stride - op.kdiv * op.k_lo_stride;
-      const int wrap_pos = op.kdiv * op.k_pos_mul;
+      const int wrap_pos = op.kdiv * pmul;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        bool ok = (k < kend) && rv[0];
-        if (op.lim > 0) ok = ok && ((unsigned)(pos[0] + kpos) < (unsigned)op.lim);
-        fetch(op, rs, rm, i, off[0] + koff, ok);
+        fetch(op, rs, rm, i, off[0] + koff, pos[0] + (k < kend ? kpos : M2D_BAD));
         ++k;
         ++lo;
         koff += op.k_lo_stride;
-        kpos += op.k_pos_mul;
+        kpos += pmul;
         if (lo == op.kdiv) {
           lo = 0;
           koff += wrap_off;
           kpos -= wrap_pos;
         }
+      }
+      // advance the chunk-start state by BK
+      klo += M2D_BK;
+      while (klo >= op.kdiv) {
+        klo -= op.kdiv;
+        ++khi;
+      }
+    }
+  }
+
+  // row-fast maps: position the wave-uniform k state on the first chunk of this block
+  __device__ __forceinline__ void begin(const M2dOperand& op, int k0, int tid) {
+    if constexpr (!KF) {
+      const int kb = (tid / BR) * NE;
+      kbase = BR >= 64 ? __builtin_amdgcn_readfirstlane(kb) : kb;
+      m2d_divmod(k0 + kbase, op.kdiv, op.kdiv_inv, khi, klo);
+      if (BR >= 64) {
+        khi = __builtin_amdgcn_readfirstlane(khi);
+        klo = __builtin_amdgcn_readfirstlane(klo);
       }
     }
   }
@@ -218,6 +242,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   const int c1 = (c0 + cps < nchunks) ? (c0 + cps) : nchunks;
 
   if (c0 < c1) {
+    ta.begin(A, c0 * M2D_BK, tid);
+    tb.begin(B, c0 * M2D_BK, tid);
     ta.load(A, ra, rma, c0 * M2D_BK, K, tid);
     tb.load(B, rb, rmb, c0 * M2D_BK, K, tid);
     ta.template store<LDA>(A, smem, tid);
