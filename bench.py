@@ -47,6 +47,19 @@ def build_models(device, seqlen=120, enc_type="default"):
     return gen, critic
 
 
+def pmc_traffic():
+    """HBM bytes per engine launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this same command, profiles/*_pmc_traffic.json);
+    PMC counters cannot be read from inside the process, so this is the recorded value."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get("hbm_bytes_per_launch_uncorrected"), os.path.basename(files[-1])
+
+
 def cpu_baseline(sample_b=16, T=120, threads=None):
     """Oracle (CPU port of the reference path) on the host cores: 1 warm-up + 2 timed critic
     iterations + 1 generator iteration at batch `sample_b`, extrapolated to seq/s of a
@@ -153,9 +166,10 @@ def main():
         if prof is not None:
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+            traffic, traffic_src = pmc_traffic()
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "m2d_gemm_kernel (separable-gather fp32 MFMA engine; conv1d fwd/bwd_data/bwd_weight + linear)",
                 "launches_per_step": round(g["launches"] / args.steps, 1),
                 "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2),

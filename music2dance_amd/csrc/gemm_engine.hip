@@ -55,6 +55,7 @@ struct TileMap {
   float v[NE];   // staged values
   float mv[NM];  // staged mask values (MASKED only)
   int kbase, khi, klo;  // row-fast maps: k decomposition of the chunk's first element
+  int bk_div, bk_mod;   // M2D_BK = bk_div * kdiv + bk_mod
   unsigned lim_eff;
 
   __device__ __forceinline__ void prep(const M2dOperand& op, int row0, int tid) {
@@ -113,12 +114,12 @@ struct TileMap {
           kpos -= wrap_pos;
         }
       }
-      // advance the chunk-start state by BK
-      klo += M2D_BK;
-      while (klo >= op.kdiv) {
-        klo -= op.kdiv;
-        ++khi;
-      }
+      // advance the chunk-start state by BK (branch-free: BK = bk_div * kdiv + bk_mod)
+      klo += bk_mod;
+      khi += bk_div;
+      const bool carry = klo >= op.kdiv;
+      klo -= carry ? op.kdiv : 0;
+      khi += carry ? 1 : 0;
     }
   }
 
@@ -128,6 +129,8 @@ struct TileMap {
       const int kb = (tid / BR) * NE;
       kbase = BR >= 64 ? __builtin_amdgcn_readfirstlane(kb) : kb;
       m2d_divmod(k0 + kbase, op.kdiv, op.kdiv_inv, khi, klo);
+      bk_div = M2D_BK / op.kdiv;
+      bk_mod = M2D_BK - bk_div * op.kdiv;
       if (BR >= 64) {
         khi = __builtin_amdgcn_readfirstlane(khi);
         klo = __builtin_amdgcn_readfirstlane(klo);
@@ -251,14 +254,12 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
     __syncthreads();
     for (int c = c0; c < c1; ++c) {
       const int cur = (c - c0) & 1;
-      const bool more = (c + 1) < c1;
-      // 1) issue the next chunk's global loads (they stay in flight under the MFMAs)
-      if (more) {
-        ta.load(A, ra, rma, (c + 1) * M2D_BK, K, tid);
-        tb.load(B, rb, rmb, (c + 1) * M2D_BK, K, tid);
-      }
-      // 2) all fragment reads of this chunk, then the MFMAs: the compiler's counted
-      //    lgkmcnt lets the first MFMAs start while later fragments are still arriving
+      // The loop body is ONE basic block (no `if (more)`: the loads of the chunk after the
+      // last one are all past kend, i.e. OOB -> zeros, and their LDS store is harmless), so
+      // the scheduler may interleave the next chunk's address math + buffer loads with this
+      // chunk's MFMAs; the sched_group_barrier sequence below pins that interleave.
+      ta.load(A, ra, rma, (c + 1) * M2D_BK, K, tid);
+      tb.load(B, rb, rmb, (c + 1) * M2D_BK, K, tid);
       const float* as = smem + cur * STAGE + wm * (TM * 32) + l31;
       const float* bs = smem + cur * STAGE + M2D_BK * LDA + wn * (TN * 32) + l31;
       float fa[M2D_BK / 2][TM], fb[M2D_BK / 2][TN];
@@ -276,21 +277,20 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-      // pin the software pipeline: fragments of k-steps kk+2 are read while the MFMAs of
-      // k-step kk execute (hipcc otherwise re-sinks every read right in front of its use
-      // and exposes the LDS latency eight times per chunk)
+      float* nxt = smem + (cur ^ 1) * STAGE;
+      ta.template store<LDA>(A, nxt, tid);
+      tb.template store<LDB>(B, nxt + M2D_BK * LDA, tid);
+      // software pipeline: fragments of k-step kk+2 and 1/8 of the next chunk's staging
+      // loads are issued under the MFMAs of k-step kk
+      constexpr int NLD = (TileMap<AKF, BM, MASKED>::NE + TileMap<BKF, BN, MASKED>::NE) * (MASKED ? 2 : 1);
+      constexpr int LPK = (NLD + 3) / 4;  // all loads issued under the first 4 k-steps: the
+                                          // remaining MFMAs cover their latency
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int kk = 0; kk < M2D_BK / 2 - 2; ++kk) {
+      for (int kk = 0; kk < M2D_BK / 2; ++kk) {
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
-      // 3) land the prefetched chunk in the other LDS buffer
-      if (more) {
-        float* nxt = smem + (cur ^ 1) * STAGE;
-        ta.template store<LDA>(A, nxt, tid);
-        tb.template store<LDB>(B, nxt + M2D_BK * LDA, tid);
+        if (kk < M2D_BK / 2 - 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (kk < 4) __builtin_amdgcn_sched_group_barrier(0x020, LPK, 0);
       }
       __syncthreads();
     }
