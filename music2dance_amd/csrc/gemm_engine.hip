@@ -76,7 +76,7 @@ struct TileMap {
                                         __amdgpu_buffer_rsrc_t rm, int i, int o, int p) {
     const unsigned b = ((unsigned)p < lim_eff) ? ((unsigned)o << 2) : M2D_OOB;
     v[i] = m2d_bload(rs, b);
-    if constexpr (MASKED) mv[i] = op.mask ? m2d_bload(rm, b) : 1.f;
+    if constexpr (MASKED) mv[i] = m2d_bload(rm, b);  // rm has 0 records when the operand has no mask
   }
 
   __device__ __forceinline__ void load(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs,
@@ -228,8 +228,12 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   tb.prep(B, n0, tid);
   const __amdgpu_buffer_rsrc_t ra = m2d_rsrc(A.base, A.nbytes);
   const __amdgpu_buffer_rsrc_t rb = m2d_rsrc(B.base, B.nbytes);
-  const __amdgpu_buffer_rsrc_t rma = m2d_rsrc(A.mask ? A.mask : A.base, A.nbytes);
-  const __amdgpu_buffer_rsrc_t rmb = m2d_rsrc(B.mask ? B.mask : B.base, B.nbytes);
+  // an operand without a mask reads its "mask" through a 0-record descriptor (always 0.0f)
+  // and uses slope 1, so the masked kernel needs no per-element branch
+  const __amdgpu_buffer_rsrc_t rma = m2d_rsrc(A.mask ? A.mask : A.base, A.mask ? A.nbytes : 0u);
+  const __amdgpu_buffer_rsrc_t rmb = m2d_rsrc(B.mask ? B.mask : B.base, B.mask ? B.nbytes : 0u);
+  if (!A.mask) A.mask_slope = 1.f;
+  if (!B.mask) B.mask_slope = 1.f;
 
   f32x16 acc[TM][TN];
 #pragma unroll

@@ -114,16 +114,16 @@ class Phase3Engine(WganGpEngine):
         audio_c = audio.unsqueeze(1)
         if self.ablated:
             gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=False, device=real.device)
-            err_real = self.critic(real_c).mean()
-            err_fake = self.critic(fake).mean()
+            s_real, s_fake = self.critic.score_pair(real_c, fake)
+            err_real, err_fake = s_real.mean(), s_fake.mean()
             err_critic = err_fake - err_real + self.gamma * gp
             err_critic.backward()
         else:
             with self.critic.shared_audio():
                 gp = gradient_penalty(self.critic, B, real_c, fake, audio_c, is_seq=True, lp=False,
                                       device=real.device)
-                err_real = self.critic(real_c, audio_c).mean()
-                err_fake = self.critic(fake, audio_c).mean()
+                s_real, s_fake = self.critic.score_pair(real_c, fake, audio_c)
+                err_real, err_fake = s_real.mean(), s_fake.mean()
                 err_critic = err_fake - err_real + self.gamma * gp
                 with ops.no_input_grad_for(audio_c):
                     err_critic.backward()
@@ -189,8 +189,8 @@ class Phase2Engine(WganGpEngine):
         fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=True, device=real.device)
-        err_real = self.critic(real_c).mean()
-        err_fake = self.critic(fake).mean()
+        s_real, s_fake = self.critic.score_pair(real_c, fake)
+        err_real, err_fake = s_real.mean(), s_fake.mean()
         err_critic = err_fake - err_real + self.gamma * gp
         err_critic.backward()
         self._begin_critic_step()

@@ -118,3 +118,9 @@ class SequenceDiscriminator(nn.Module):
     def forward(self, x):
         h = self.blocks(self.conv1(x, act=ops.ACT_RELU))
         return self.lastconv(h).squeeze(1)
+
+    def score_pair(self, x_a, x_b):
+        """critic(x_a), critic(x_b) from one pass over the concatenated batch."""
+        n = x_a.size(0)
+        s = self.forward(torch.cat((x_a, x_b), 0))
+        return s[:n], s[n:]

@@ -322,6 +322,17 @@ class SequenceDiscriminator(nn.Module):
         code = torch.cat((self.stick_d(x), self._audio_code(c)), -1)
         return self.fc2(self.fc1(code, act=ops.ACT_RELU))
 
+    def score_pair(self, x_a, x_b, c):
+        """critic(x_a, c), critic(x_b, c) from ONE pass over the concatenated poses (the critic
+        has no cross-sample coupling, so the scores are the per-call ones; twice the columns
+        per launch fill the chip better) and one evaluation of the audio branch."""
+        n = x_a.size(0)
+        stick = self.stick_d(torch.cat((x_a, x_b), 0))
+        acode = self._audio_code(c)
+        code = torch.cat((stick, torch.cat((acode, acode), 0)), -1)
+        s = self.fc2(self.fc1(code, act=ops.ACT_RELU))
+        return s[:n], s[n:]
+
 
 class AblatedSequenceDiscriminator(nn.Module):
     """Pose-only critic. Like the reference it does NOT forward `init_ker` to the pose
@@ -338,3 +349,8 @@ class AblatedSequenceDiscriminator(nn.Module):
 
     def forward(self, x):
         return self.fc2(self.fc1(self.stick_d(x), act=ops.ACT_RELU))
+
+    def score_pair(self, x_a, x_b):
+        n = x_a.size(0)
+        s = self.forward(torch.cat((x_a, x_b), 0))
+        return s[:n], s[n:]
