@@ -39,11 +39,13 @@ P3_DEFAULT = {"lr_gen": 2e-4, "lr_critic": 2e-4, "n_critic_steps": 8, "gamma": 1
               "output_size": 69}
 
 
-def build_models(device, seqlen=120, enc_type="default"):
-    from music2dance_amd.phase3.archis.default import SequenceDiscriminator, SequenceGenerator
+def build_models(device, seqlen=120, enc_type="default", ablated=False):
+    from music2dance_amd.phase3.archis.default import (AblatedSequenceDiscriminator, SequenceDiscriminator,
+                                                       SequenceGenerator)
     torch.manual_seed(0)  # phase3/train.py:35
     gen = SequenceGenerator(3200, 250, 250, 256, 69, 10, 2, 3, enc_type, "id", device)
-    critic = SequenceDiscriminator(69, 128, 100, seqlen, init_ker=25, activ="id", device=device)
+    cls = AblatedSequenceDiscriminator if ablated else SequenceDiscriminator
+    critic = cls(69, 128, 100, seqlen, init_ker=25, activ="id", device=device)
     return gen, critic
 
 
@@ -100,6 +102,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU (weak scaling)")
     ap.add_argument("--frames", type=int, default=120)
+    ap.add_argument("--enc-type", default="default", choices=["default", "unet", "wavegan"],
+                    help="audio encoder (BASELINE.json configs[3]/[4] use wavegan / unet)")
+    ap.add_argument("--ablated", action="store_true", help="pose-only critic (required for --frames != 120)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel profile")
     args = ap.parse_args()
@@ -116,8 +121,11 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    gen, critic = build_models(device, args.frames)
-    engine = Phase3Engine(gen, critic, P3_DEFAULT)
+    if args.frames != 120 and not args.ablated:
+        sys.exit("the audio critic only accepts 76 800-sample (120-frame) audio: use --ablated with --frames %d"
+                 % args.frames)
+    gen, critic = build_models(device, args.frames, args.enc_type, args.ablated)
+    engine = Phase3Engine(gen, critic, P3_DEFAULT, ablated=args.ablated)
     real, audio, slices = synthetic_phase3_batch(args.batch, args.frames, device, seed=100 + rank)
     gen.train(), critic.train()
 
@@ -156,9 +164,12 @@ def main():
             "value": round(value, 2), "unit": "seq/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "phase3/train.py WGAN-GP step, default conv1d audio encoder, %d frames, "
-                                   "batch %d per GPU (BASELINE.json configs[2]); 1 generator iteration per 8 "
-                                   "critic iterations" % (args.frames, args.batch),
+            "config": {"workload": "phase3/train.py WGAN-GP step, %s audio encoder%s, %d frames, "
+                                   "batch %d per GPU%s; 1 generator iteration per 8 critic iterations"
+                                   % (args.enc_type, ", ablated critic" if args.ablated else "", args.frames, args.batch,
+                                      " (BASELINE.json configs[2])" if (args.enc_type, args.frames, args.batch,
+                                                                         args.ablated) == ("default", 120, 64, False)
+                                      else ""),
                        "global_batch": args.batch * world, "seq_len": args.frames,
                        "parallelism": "dp%d" % world},
             "losses_last_step": last,
@@ -180,7 +191,8 @@ def main():
                 # an equivalent-work rate, not a kernel rate
                 "step_tflops_reference_formulation": round(REF_GFLOP_PER_SEQ_CYCLE * 1e9 * seqs / elapsed / 1e12, 2),
             }
-        if not args.no_cpu_baseline and world == 1:
+        default_cfg = (args.enc_type, args.frames, args.ablated) == ("default", 120, False)
+        if not args.no_cpu_baseline and world == 1 and default_cfg:
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is informational; never lose the GPU line over it

@@ -90,6 +90,16 @@ int m2d_gru_layer_bwd(const float* dout, const float* out, const float* r_s, con
                       const float* hn_s, const float* w_hh, const int* lengths, float* dgi, float* dgh,
                       float* dh_buf, int B, int T, int H, void* stream);
 
+/* Whole L-layer stack (L <= 4, equal hidden sizes) on the (layer, t) diagonal: T + L - 1 launches
+ * instead of L * T. Pointer arrays have L entries; w_ih_t[0] / b_ih[0] / w_ih[0] are ignored (layer 0's
+ * projection gi0 comes from m2d_gemm). saved[l]: (4, B, T, H) = r, z, n, W_hn h + b_hn (or saved == NULL). */
+int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float* const* b_ih,
+                      const float* const* w_hh_t, const float* const* b_hh, float* const* out, float* const* saved,
+                      const int* lengths, int B, int T, int H, int L, void* stream);
+int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* const* saved,
+                      const float* const* w_hh, const float* const* w_ih, float* const* dgi, float* const* dgh,
+                      float* const* dh_buf, const int* lengths, int B, int T, int H, int L, void* stream);
+
 /* ---- gradient penalty (losses.py:5-60) ----------------------------------------------------- */
 int m2d_gp_interpolate(const float* real, const float* fake, const float* alpha, float* out, int B, int n,
                        void* stream);

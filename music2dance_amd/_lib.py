@@ -36,6 +36,8 @@ SIGNATURES = {
     "m2d_channel_sums": (_I, [_F, _F, _f, _F, _I, _I, _I, _F, _S, _F]),
     "m2d_gru_layer_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
     "m2d_gru_layer_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
+    "m2d_gru_stack_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F]),
+    "m2d_gru_stack_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F]),
     "m2d_gp_interpolate": (_I, [_F, _F, _F, _F, _I, _I, _F]),
     "m2d_gp_penalty_fwd": (_I, [_F, _F, _F, _I, _I, _I, _F]),
     "m2d_gp_penalty_bwd": (_I, [_F, _F, _F, _F, _I, _I, _I, _F]),

@@ -233,3 +233,240 @@ int m2d_gru_layer_bwd(const float* dout, const float* out, const float* r_s, con
 }
 
 }  // extern "C"
+
+// =========================================================================================
+// Stacked GRU on the (layer, t) diagonal: launch d runs layer l at time t = d - l for every
+// layer at once (grid.z = layer), so a whole L-layer forward is T + L - 1 dependent launches
+// instead of L * T. Layer l >= 1 needs h_{l-1}[t] (written by launch d - 1) and computes its
+// input projection in the step: r and z accumulate W_ih x + W_hh h in one accumulator, the n
+// gate keeps the two halves apart (n = tanh(gi_n + r * gh_n)). The backward runs the
+// anti-diagonal e = (L-1-l) + (T-1-t) and folds dL/dh_l[t] = dgi_{l+1}[t] W_ih_{l+1} (upper
+// layer) + dgh_l[t+1] W_hh_l (next step) into one K = 6H contraction.
+#define GRU_MAX_LAYERS 4
+
+struct GruStackFwdArgs {
+  const float* gi0;                       // (B, T, 3H): layer-0 input projection incl. b_ih
+  const float* w_ih_t[GRU_MAX_LAYERS];    // (H, 3H) = W_ih^T of layers >= 1 ([0] unused)
+  const float* b_ih[GRU_MAX_LAYERS];      // (3H) of layers >= 1
+  const float* w_hh_t[GRU_MAX_LAYERS];    // (H, 3H)
+  const float* b_hh[GRU_MAX_LAYERS];
+  float* out[GRU_MAX_LAYERS];             // (B, T, H)
+  float* saved[GRU_MAX_LAYERS];           // (4, B, T, H): r, z, n, hn; NULL when not saving
+  const int* lengths;
+  int B, T, H, L, d;
+};
+
+template <int NB>
+__device__ __forceinline__ void gru_mac(const float* arow, bool rok, const float* wt, int H, int ncol, int bcol,
+                                        bool cok, int wave, int lane, f32x4 (&acc)[NB], const int (&col_of)[NB]) {
+  // acc[j] += A[16 rows, K = H] * W^T[:, col_of[j] * H + bcol]; this wave takes k-steps wave, wave+4, ...
+  const int nsteps = (H + 3) / 4;
+  for (int s0 = wave; s0 < nsteps; s0 += 4 * GRU_UNROLL) {
+    float av[GRU_UNROLL], bv[GRU_UNROLL][NB];
+#pragma unroll
+    for (int i = 0; i < GRU_UNROLL; ++i) {
+      const int k = 4 * (s0 + 4 * i) + (lane >> 4);
+      const bool kok = (s0 + 4 * i) < nsteps && k < H;
+      av[i] = (rok && kok) ? arow[k] : 0.f;
+      const float* wrow = wt + (size_t)(kok ? k : 0) * ncol + (cok ? bcol : 0);
+      const bool ok = kok && cok;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bv[i][j] = ok ? wrow[col_of[j] * H] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < GRU_UNROLL; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][j], acc[j], 0, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256) m2d_gru_stack_fwd_kernel(const GruStackFwdArgs a) {
+  __shared__ float red[4][4][256];
+  const int l = blockIdx.z;
+  const int t = a.d - l;
+  if (t < 0 || t >= a.T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int H = a.H, T = a.T;
+  // accumulators: 0 = r (input + hidden), 1 = z (input + hidden), 2 = gh_n, 3 = gi_n
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int arow = b0 + (lane & 15);
+  const int bcol = u0 + (lane & 15);
+  const bool rok = arow < a.B, cok = bcol < H;
+  if (t > 0) {
+    f32x4 h3[3] = {acc[0], acc[1], acc[2]};
+    const int cols[3] = {0, 1, 2};
+    gru_mac<3>(a.out[l] + ((size_t)arow * T + (t - 1)) * H, rok, a.w_hh_t[l], H, 3 * H, bcol, cok, wave, lane, h3, cols);
+    acc[0] = h3[0]; acc[1] = h3[1]; acc[2] = h3[2];
+  }
+  if (l > 0) {
+    f32x4 i3[3] = {acc[0], acc[1], acc[3]};
+    const int cols[3] = {0, 1, 2};
+    gru_mac<3>(a.out[l - 1] + ((size_t)arow * T + t) * H, rok, a.w_ih_t[l], H, 3 * H, bcol, cok, wave, lane, i3, cols);
+    acc[0] = i3[0]; acc[1] = i3[1]; acc[3] = i3[2];
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][g][((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[g][r];
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15;
+  const int b = b0 + row, u = u0 + col;
+  if (b >= a.B || u >= H) return;
+  float s[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) s[g] = red[0][g][tid] + red[1][g][tid] + red[2][g][tid] + red[3][g][tid];
+  const size_t bt = (size_t)b * T + t;
+  float gir, giz, gin;
+  if (l == 0) {
+    const float* gi = a.gi0 + bt * 3 * H;
+    gir = gi[u]; giz = gi[H + u]; gin = gi[2 * H + u];
+  } else {
+    gir = a.b_ih[l][u]; giz = a.b_ih[l][H + u]; gin = s[3] + a.b_ih[l][2 * H + u];
+  }
+  const float* bh = a.b_hh[l];
+  const float hn = s[2] + bh[2 * H + u];
+  const float r = gru_sigmoid(gir + s[0] + bh[u]);
+  const float z = gru_sigmoid(giz + s[1] + bh[H + u]);
+  const float n = tanhf(gin + r * hn);
+  const float hprev = t > 0 ? a.out[l][(bt - 1) * H + u] : 0.f;
+  float h = (1.f - z) * n + z * hprev;
+  if (a.lengths && t >= a.lengths[b]) h = 0.f;
+  a.out[l][bt * H + u] = h;
+  if (a.saved[l]) {
+    const size_t plane = (size_t)a.B * T * H;
+    float* sv = a.saved[l];
+    sv[bt * H + u] = r;
+    sv[plane + bt * H + u] = z;
+    sv[2 * plane + bt * H + u] = n;
+    sv[3 * plane + bt * H + u] = hn;
+  }
+}
+
+struct GruStackBwdArgs {
+  const float* dout;                      // (B, T, H): gradient w.r.t. the TOP layer's output
+  const float* out[GRU_MAX_LAYERS];
+  const float* saved[GRU_MAX_LAYERS];     // (4, B, T, H)
+  const float* w_hh[GRU_MAX_LAYERS];      // (3H, H)
+  const float* w_ih[GRU_MAX_LAYERS];      // (3H, H) of layers >= 1 ([0] unused)
+  float* dgi[GRU_MAX_LAYERS];             // (B, T, 3H)
+  float* dgh[GRU_MAX_LAYERS];             // (B, T, 3H)
+  float* dh_buf[GRU_MAX_LAYERS];          // (2, B, H)
+  const int* lengths;
+  int B, T, H, L, e;
+};
+
+__device__ __forceinline__ void gru_mac1(const float* arow, bool rok, const float* w, int K, int H, int bcol, bool cok,
+                                         int wave, int lane, f32x4& acc) {
+  // acc += A[16 rows, K] * W[K, H][:, bcol]
+  const int nsteps = (K + 3) / 4;
+  for (int s0 = wave; s0 < nsteps; s0 += 4 * GRU_UNROLL) {
+    float av[GRU_UNROLL], bv[GRU_UNROLL];
+#pragma unroll
+    for (int i = 0; i < GRU_UNROLL; ++i) {
+      const int k = 4 * (s0 + 4 * i) + (lane >> 4);
+      const bool kok = (s0 + 4 * i) < nsteps && k < K;
+      av[i] = (rok && kok) ? arow[k] : 0.f;
+      bv[i] = (kok && cok) ? w[(size_t)k * H + bcol] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < GRU_UNROLL; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256) m2d_gru_stack_bwd_kernel(const GruStackBwdArgs a) {
+  __shared__ float red[4][256];
+  const int l = a.L - 1 - (int)blockIdx.z;
+  const int t = a.T - 1 - (a.e - (int)blockIdx.z);
+  if (t < 0 || t >= a.T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int H = a.H, T = a.T;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int arow = b0 + (lane & 15);
+  const int bcol = u0 + (lane & 15);
+  const bool rok = arow < a.B, cok = bcol < H;
+  const bool has_next = (t + 1) < T;
+  const bool has_up = (l + 1) < a.L;
+  if (has_next) gru_mac1(a.dgh[l] + ((size_t)arow * T + (t + 1)) * 3 * H, rok, a.w_hh[l], 3 * H, H, bcol, cok, wave, lane, acc);
+  if (has_up) gru_mac1(a.dgi[l + 1] + ((size_t)arow * T + t) * 3 * H, rok, a.w_ih[l + 1], 3 * H, H, bcol, cok, wave, lane, acc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15;
+  const int b = b0 + row, u = u0 + col;
+  if (b >= a.B || u >= H) return;
+  const size_t bt = (size_t)b * T + t;
+  const size_t plane = (size_t)a.B * T * H;
+  const float* sv = a.saved[l];
+  float dh = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (!has_up) dh += a.dout[bt * H + u];
+  if (has_next) dh += a.dh_buf[l][((size_t)((t + 1) & 1) * a.B + b) * H + u] * sv[plane + (bt + 1) * H + u];
+  if (a.lengths && t >= a.lengths[b]) dh = 0.f;
+  const float r = sv[bt * H + u], z = sv[plane + bt * H + u], n = sv[2 * plane + bt * H + u], hn = sv[3 * plane + bt * H + u];
+  const float hprev = t > 0 ? a.out[l][(bt - 1) * H + u] : 0.f;
+  const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+  const float dz_pre = dh * (hprev - n) * z * (1.f - z);
+  const float dr_pre = dn_pre * hn * r * (1.f - r);
+  float* gi = a.dgi[l] + bt * 3 * H;
+  float* gh = a.dgh[l] + bt * 3 * H;
+  gi[u] = dr_pre; gi[H + u] = dz_pre; gi[2 * H + u] = dn_pre;
+  gh[u] = dr_pre; gh[H + u] = dz_pre; gh[2 * H + u] = dn_pre * r;
+  a.dh_buf[l][((size_t)(t & 1) * a.B + b) * H + u] = dh;
+}
+
+extern "C" {
+
+// L-layer GRU forward on the (layer, t) diagonal. Pointer arrays have L entries; entry 0 of
+// w_ih_t / b_ih is ignored (layer 0's projection gi0 is precomputed by m2d_gemm).
+// saved[l]: (4, B, T, H) or all NULL.
+int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float* const* b_ih,
+                      const float* const* w_hh_t, const float* const* b_hh, float* const* out, float* const* saved,
+                      const int* lengths, int B, int T, int H, int L, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || T <= 0 || H <= 0 || L <= 0 || L > GRU_MAX_LAYERS) M2D_FAIL(M2D_ERR_ARG, "m2d_gru_stack_fwd: bad shape");
+  GruStackFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gi0 = gi0; a.lengths = lengths;
+  for (int l = 0; l < L; ++l) {
+    a.w_ih_t[l] = w_ih_t[l]; a.b_ih[l] = b_ih[l]; a.w_hh_t[l] = w_hh_t[l]; a.b_hh[l] = b_hh[l];
+    a.out[l] = out[l]; a.saved[l] = saved ? saved[l] : nullptr;
+  }
+  a.B = B; a.T = T; a.H = H; a.L = L;
+  dim3 grid(m2d_ceil_div(H, 16), m2d_ceil_div(B, 16), L);
+  M2dProfScope prof(M2D_FAM_GRU, stream, 2.0 * B * 3.0 * H * H * (double)T * (2 * L - 1), 0.0, "gru_stack_fwd", B, T, H);
+  for (int d = 0; d < T + L - 1; ++d) {
+    a.d = d;
+    hipLaunchKernelGGL(m2d_gru_stack_fwd_kernel, grid, dim3(256), 0, stream, a);
+  }
+  M2D_CHECK_LAUNCH("m2d_gru_stack_fwd_kernel");
+  return M2D_OK;
+}
+
+// BPTT for the whole stack on the anti-diagonal. dgi[l], dgh[l]: (B, T, 3H); dh_buf[l]: 2*B*H floats.
+int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* const* saved,
+                      const float* const* w_hh, const float* const* w_ih, float* const* dgi, float* const* dgh,
+                      float* const* dh_buf, const int* lengths, int B, int T, int H, int L, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || T <= 0 || H <= 0 || L <= 0 || L > GRU_MAX_LAYERS) M2D_FAIL(M2D_ERR_ARG, "m2d_gru_stack_bwd: bad shape");
+  GruStackBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dout = dout; a.lengths = lengths;
+  for (int l = 0; l < L; ++l) {
+    a.out[l] = out[l]; a.saved[l] = saved[l]; a.w_hh[l] = w_hh[l]; a.w_ih[l] = w_ih[l];
+    a.dgi[l] = dgi[l]; a.dgh[l] = dgh[l]; a.dh_buf[l] = dh_buf[l];
+  }
+  a.B = B; a.T = T; a.H = H; a.L = L;
+  dim3 grid(m2d_ceil_div(H, 16), m2d_ceil_div(B, 16), L);
+  M2dProfScope prof(M2D_FAM_GRU, stream, 2.0 * B * 3.0 * H * H * (double)T * (2 * L - 1), 0.0, "gru_stack_bwd", B, T, H);
+  for (int e = 0; e < T + L - 1; ++e) {
+    a.e = e;
+    hipLaunchKernelGGL(m2d_gru_stack_bwd_kernel, grid, dim3(256), 0, stream, a);
+  }
+  M2D_CHECK_LAUNCH("m2d_gru_stack_bwd_kernel");
+  return M2D_OK;
+}
+
+}  // extern "C"

@@ -209,6 +209,43 @@ class HipKernels:
         _lib.check(rc, "m2d_gru_layer_bwd")
         return dgi, dgh
 
+    @staticmethod
+    def _ptr_array(tensors):
+        arr = (ctypes.c_void_p * len(tensors))(*[_ptr(t) for t in tensors])
+        return arr, ctypes.cast(arr, ctypes.c_void_p)
+
+    def gru_stack_fwd(self, gi0, w_ih_t, b_ih, w_hh_t, b_hh, lengths=None, save=True):
+        """L-layer GRU on the (layer, t) diagonal. Lists have L entries (entry 0 of w_ih_t / b_ih may
+        be None). Returns ([out_l (B,T,H)], [saved_l (4,B,T,H)] or None)."""
+        L = len(w_hh_t)
+        dev = _chk(gi0, *[t for t in list(w_ih_t) + list(b_ih) + list(w_hh_t) + list(b_hh) if t is not None])
+        B, T, H3 = gi0.shape
+        H = H3 // 3
+        outs = [torch.empty((B, T, H), dtype=torch.float32, device=dev) for _ in range(L)]
+        saved = [torch.empty((4, B, T, H), dtype=torch.float32, device=dev) for _ in range(L)] if save else None
+        keep = [self._ptr_array(v) for v in (w_ih_t, b_ih, w_hh_t, b_hh, outs)]
+        sv = self._ptr_array(saved) if save else (None, None)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_gru_stack_fwd(_ptr(gi0), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
+                                              sv[1], _ptr(lengths), B, T, H, L, _stream(dev))
+        _lib.check(rc, "m2d_gru_stack_fwd")
+        return outs, saved
+
+    def gru_stack_bwd(self, dout, outs, saved, w_hh, w_ih, lengths=None):
+        """BPTT of the stack; returns ([dgi_l (B,T,3H)], [dgh_l (B,T,3H)])."""
+        L = len(outs)
+        dev = _chk(dout, *outs, *saved, *w_hh, *[t for t in w_ih if t is not None])
+        B, T, H = outs[0].shape
+        dgi = [torch.empty((B, T, 3 * H), dtype=torch.float32, device=dev) for _ in range(L)]
+        dgh = [torch.empty((B, T, 3 * H), dtype=torch.float32, device=dev) for _ in range(L)]
+        dhb = [torch.empty((2, B, H), dtype=torch.float32, device=dev) for _ in range(L)]
+        keep = [self._ptr_array(v) for v in (outs, saved, w_hh, w_ih, dgi, dgh, dhb)]
+        with torch.cuda.device(dev):
+            rc = _lib.lib().m2d_gru_stack_bwd(_ptr(dout), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
+                                              keep[5][1], keep[6][1], _ptr(lengths), B, T, H, L, _stream(dev))
+        _lib.check(rc, "m2d_gru_stack_bwd")
+        return dgi, dgh
+
     # ---------------------------------------------------------------- gradient penalty
     def gp_interpolate(self, real, fake, alpha):
         """real, fake: (B, n); alpha: (B,) -> alpha*real + (1-alpha)*fake."""

@@ -56,10 +56,16 @@ class GRU(nn.GRU):
     def forward(self, x, lengths=None):
         if not self.batch_first or self.bidirectional or self.dropout != 0.0 or not self.bias:
             raise NotImplementedError("m2d GRU: only batch_first / unidirectional / no-dropout is supported")
+        params = []
+        for layer in range(self.num_layers):
+            params += [getattr(self, "weight_ih_l%d" % layer), getattr(self, "weight_hh_l%d" % layer),
+                       getattr(self, "bias_ih_l%d" % layer), getattr(self, "bias_hh_l%d" % layer)]
+        if self.num_layers <= 4:
+            # every layer on the (layer, t) diagonal: T + L - 1 dependent launches instead of L * T
+            return ops.gru_stack(x, params, lengths), None
         out = x
         for layer in range(self.num_layers):
-            out = ops.gru_layer(out, getattr(self, "weight_ih_l%d" % layer), getattr(self, "weight_hh_l%d" % layer),
-                                getattr(self, "bias_ih_l%d" % layer), getattr(self, "bias_hh_l%d" % layer), lengths)
+            out = ops.gru_layer(out, *params[4 * layer:4 * layer + 4], lengths)
         return out, None
 
 

@@ -323,6 +323,57 @@ class _GRULayer(Function):
         return dx, dw_ih, dw_hh, db_ih, db_hh, None, None
 
 
+class _GRUStack(Function):
+    """All layers of an nn.GRU at once on the (layer, t) diagonal (T + L - 1 step launches)."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, save, *params):
+        L = len(params) // 4
+        w_ih = [_c(params[4 * l]) for l in range(L)]
+        w_hh = [_c(params[4 * l + 1]) for l in range(L)]
+        b_ih = [_c(params[4 * l + 2]) for l in range(L)]
+        b_hh = [_c(params[4 * l + 3]) for l in range(L)]
+        x = _c(x)
+        B, T, I = x.shape
+        H = w_hh[0].shape[1]
+        k = K()
+        gi0 = k.gemm(0, x.view(B * T, I), w_ih[0], b_ih[0]).view(B, T, 3 * H)
+        outs, saved = k.gru_stack_fwd(gi0, [None] + [w.t().contiguous() for w in w_ih[1:]], [None] + b_ih[1:],
+                                      [w.t().contiguous() for w in w_hh], b_hh, lengths, save)
+        if save:
+            ctx.save_for_backward(x, lengths, *w_ih, *w_hh, *outs, *saved)
+            ctx.L = L
+        return outs[-1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        L = ctx.L
+        t = ctx.saved_tensors
+        x, lengths = t[0], t[1]
+        w_ih, w_hh = list(t[2:2 + L]), list(t[2 + L:2 + 2 * L])
+        outs, saved = list(t[2 + 2 * L:2 + 3 * L]), list(t[2 + 3 * L:2 + 4 * L])
+        B, T, I = x.shape
+        H = w_hh[0].shape[1]
+        k = K()
+        dgi, dgh = k.gru_stack_bwd(_c(dout), outs, saved, w_hh, [None] + w_ih[1:], lengths)
+        grads = []
+        for l in range(L):
+            dgi2, dgh2 = dgi[l].view(B * T, 3 * H), dgh[l].view(B * T, 3 * H)
+            inp = x.view(B * T, I) if l == 0 else outs[l - 1].view(B * T, H)
+            hprev = torch.cat((outs[l].new_zeros(B, 1, H), outs[l][:, :-1]), 1).contiguous().view(B * T, H)
+            grads += [k.gemm(2, dgi2, inp), k.gemm(2, dgh2, hprev), k.channel_sums(dgi2.view(B * T, 3 * H, 1)),
+                      k.channel_sums(dgh2.view(B * T, 3 * H, 1))]
+        dx = k.gemm(1, dgi[0].view(B * T, 3 * H), w_ih[0]).view(B, T, I) if ctx.needs_input_grad[0] else None
+        return (dx, None, None) + tuple(grads)
+
+
+def gru_stack(x, params, lengths=None):
+    """nn.GRU(batch_first, h0 = 0) with len(params) // 4 layers; params = [w_ih, w_hh, b_ih, b_hh] per layer."""
+    save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    return _GRUStack.apply(x, lengths, save, *params)
+
+
 def gru_layer(x, w_ih, w_hh, b_ih, b_hh, lengths=None):
     """One nn.GRU layer (batch_first, h0 = 0) over a whole (B, T, in) sequence."""
     save = torch.is_grad_enabled() and any(t.requires_grad for t in (x, w_ih, w_hh, b_ih, b_hh))

@@ -142,6 +142,24 @@ class FakeKernels:
             dh_next = dh
         return dgi, dgh
 
+    def gru_stack_fwd(self, gi0, w_ih_t, b_ih, w_hh_t, b_hh, lengths=None, save=True):
+        outs, saved = [], []
+        for l in range(len(w_hh_t)):
+            gi = gi0 if l == 0 else outs[-1] @ w_ih_t[l] + b_ih[l]
+            o, s = self.gru_layer_fwd(gi, w_hh_t[l], b_hh[l], lengths, save)
+            outs.append(o), saved.append(s)
+        return outs, (saved if save else None)
+
+    def gru_stack_bwd(self, dout, outs, saved, w_hh, w_ih, lengths=None):
+        L = len(outs)
+        dgi, dgh = [None] * L, [None] * L
+        d = dout
+        for l in range(L - 1, -1, -1):
+            dgi[l], dgh[l] = self.gru_layer_bwd(d, outs[l], saved[l], w_hh[l], lengths)
+            if l > 0:
+                d = dgi[l] @ w_ih[l]
+        return dgi, dgh
+
     def gp_interpolate(self, real, fake, alpha):
         a = alpha.view(-1, 1)
         return a * real + (1 - a) * fake

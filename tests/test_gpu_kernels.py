@@ -367,3 +367,45 @@ def test_profiler_counts_gemm_launches():
     assert stats["gemm"]["launches"] == 2
     assert stats["gemm"]["flops"] == 2 * (2.0 * 16 * (2 * 64) * (8 * 3))
     assert stats["gemm"]["ms"] > 0
+
+
+@pytest.mark.parametrize("dims", [(5, 7, 250, 240, 3), (32, 9, 50, 50, 3), (3, 12, 10, 10, 1), (17, 5, 33, 21, 2)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_gru_stack_fwd_bwd(dims):
+    """Diagonal (layer, t) schedule of a multi-layer GRU vs nn.GRU, through the autograd op."""
+    from music2dance_amd import ops
+    B, T, I, H, L = dims
+    rnn = torch.nn.GRU(I, H, L, batch_first=True).double()
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for p in rnn.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.1 if p.dim() == 1 else 1.0 / math.sqrt(p.shape[1])))
+    x = gen(B, T, I, seed=1)
+    x64 = x.double().requires_grad_(True)
+    ref, _ = rnn(x64)
+    names = [n for l in range(L) for n in ("weight_ih_l%d" % l, "weight_hh_l%d" % l, "bias_ih_l%d" % l, "bias_hh_l%d" % l)]
+    params = [getattr(rnn, n).detach().float().to(DEV).requires_grad_(True) for n in names]
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.gru_stack(xd, params)
+    assert rel_err(out, ref) < 1e-5
+    dout = gen(B, T, H, seed=6)
+    gref = torch.autograd.grad(ref, [x64] + [getattr(rnn, n) for n in names], dout.double())
+    got = torch.autograd.grad(out, [xd] + params, dout.to(DEV))
+    for a, b, n in zip(got, gref, ["x"] + names):
+        assert rel_err(a, b) < 3e-5, n
+
+
+def test_gru_stack_lengths():
+    from music2dance_amd import ops
+    B, T, I, H, L = 4, 6, 8, 16, 2
+    lengths = [6, 5, 3, 1]
+    rnn = torch.nn.GRU(I, H, L, batch_first=True).double()
+    x = gen(B, T, I, seed=1)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x.double(), lengths, batch_first=True)
+    ref, _ = torch.nn.utils.rnn.pad_packed_sequence(rnn(packed)[0], batch_first=True)
+    names = [n for l in range(L) for n in ("weight_ih_l%d" % l, "weight_hh_l%d" % l, "bias_ih_l%d" % l, "bias_hh_l%d" % l)]
+    params = [getattr(rnn, n).detach().float().to(DEV) for n in names]
+    lens = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        out = ops.gru_stack(x.to(DEV), params, lens)
+    assert rel_err(out, ref) < 1e-5
