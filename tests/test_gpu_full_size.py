@@ -1,0 +1,177 @@
+"""Parity at BASELINE.json's full sizes (batch 64 x 120 frames = 7 680 windows), where the CPU
+oracle is too slow to run inside a test: size-independent properties of the path instead.
+
+  * shard identity   — the critic has no cross-sample coupling: scores, and the gradient of
+                       (E[D(fake)] - E[D(real)] + gamma * GP), on the full batch equal the
+                       concatenation / mean over two half batches with the same per-sample alpha
+                       (SURVEY.md A.6); this drives every conv / linear kernel incl. the double
+                       backward at full size and through different tile / split-K plans;
+  * linearity        — conv1d is linear in its input at the audio critic's largest layers;
+  * eval-mode shards — the generator in eval mode (running BatchNorm statistics) is per-window:
+                       7 680 windows at once equal two runs of 3 840;
+  * bit-exact ops    — audio slicing equals the oracle's unfold, the interpolation equals the
+                       reference's three-rounding expression.
+Tolerances: 2e-5 relative to the tensor's max (fp32 contraction noise between tilings) for
+forward quantities. Gradients are compared in relative L2 norm: with ~2 M ReLU inputs per
+layer, one pre-activation within fp32 rounding of zero (|pre| ~ 2e-7, measured) takes a
+different sign under a different tiling / split-K plan, and that single flipped mask changes
+the max-norm of a gradient by ~1 % while leaving its L2 norm unchanged to 1e-5.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+B, T = 64, 120
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / max(1e-30, b.abs().max().item())
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).norm().item() / max(1e-30, b.norm().item())
+
+
+@pytest.fixture(scope="module")
+def models():
+    import bench
+    gen, critic = bench.build_models(torch.device(DEV), T)
+    return gen, critic
+
+
+@pytest.fixture(scope="module")
+def batch():
+    from music2dance_amd.engine import synthetic_phase3_batch
+    return synthetic_phase3_batch(B, T, torch.device(DEV), seed=5)
+
+
+def test_slicing_and_interpolation_bit_exact(batch):
+    from oracle import m2d_oracle as O
+    from music2dance_amd import kernels
+    real, audio, slices = batch
+    assert torch.equal(slices.cpu(), O.slice_audio(audio.cpu(), 3200, 640, 2560))
+    fake = torch.rand(B, T * 69, device=DEV)
+    alpha = torch.rand(B, device=DEV)
+    got = kernels.impl().gp_interpolate(real.view(B, -1).contiguous(), fake, alpha)
+    a = alpha.view(B, 1).cpu()
+    want = a * real.view(B, -1).cpu() + (1 - a) * fake.cpu()
+    assert torch.equal(got.cpu(), want)
+
+
+def test_critic_scores_shard_identity(models, batch):
+    _, critic = models
+    real, audio, _ = batch
+    x = real.permute(0, 2, 1).contiguous()
+    a = audio.unsqueeze(1)
+    with torch.no_grad():
+        full = critic(x, a)
+        halves = torch.cat((critic(x[:B // 2], a[:B // 2]), critic(x[B // 2:], a[B // 2:])), 0)
+    assert full.shape == (B, 1)
+    assert rel(full, halves) < 2e-5
+    assert torch.isfinite(full).all()
+
+
+def test_conv_linearity_full_size():
+    from music2dance_amd import kernels
+    K = kernels.impl()
+    g = torch.Generator().manual_seed(3)
+    for (cin, L, cout) in ((32, 19200, 64), (64, 4800, 128), (256, 300, 512)):
+        x = torch.randn(B, cin, L, generator=g).to(DEV)
+        y = torch.randn(B, cin, L, generator=g).to(DEV)
+        w = (torch.randn(cout, cin, 25, generator=g) / math.sqrt(cin * 25)).to(DEV)
+        lhs = K.conv1d_fwd(2.5 * x + y, w, None, 4, 11)
+        rhs = 2.5 * K.conv1d_fwd(x, w, None, 4, 11) + K.conv1d_fwd(y, w, None, 4, 11)
+        assert rel(lhs, rhs) < 2e-5, (cin, L, cout)
+        # <dy, conv(x)> == <bwd_data(dy), x> == <bwd_weight(x, dy), w>   (adjoint identities)
+        dy = torch.randn(lhs.shape, generator=g).to(DEV)
+        fwd = K.conv1d_fwd(x, w, None, 4, 11)
+        s0 = (dy.double() * fwd.double()).sum().item()
+        s1 = (K.conv1d_bwd_data(dy, w, L, 4, 11).double() * x.double()).sum().item()
+        s2 = (K.conv1d_bwd_weight(x, dy, 25, 4, 11).double() * w.double()).sum().item()
+        scale = dy.double().norm().item() * fwd.double().norm().item()
+        assert abs(s0 - s1) < 1e-5 * scale and abs(s0 - s2) < 1e-5 * scale, (cin, L, cout)
+
+
+def _critic_loss_grads(critic, x_real, x_fake, audio, alpha):
+    import music2dance_amd.losses as L
+    from music2dance_amd import ops
+    n = x_real.size(0)
+    orig = L.torch.rand
+    L.torch.rand = lambda *a, **k: alpha.cpu().clone()
+    try:
+        critic.zero_grad(set_to_none=True)
+        a = audio.clone()
+        with critic.shared_audio():
+            gp = L.gradient_penalty(critic, n, x_real, x_fake, a, is_seq=True, lp=False, device=x_real.device)
+            s_real, s_fake = critic.score_pair(x_real, x_fake, a)
+            loss = s_fake.mean() - s_real.mean() + 10.0 * gp
+            with ops.no_input_grad_for(a):
+                loss.backward()
+    finally:
+        L.torch.rand = orig
+    return loss.detach(), [p.grad.detach().clone() for p in critic.parameters()]
+
+
+def test_critic_gradient_shard_identity(models, batch):
+    """full-batch gradient == mean of two half-batch gradients (same alpha per sample)"""
+    _, critic = models
+    real, audio, _ = batch
+    g = torch.Generator().manual_seed(9)
+    x_real = real.permute(0, 2, 1).contiguous()
+    x_fake = torch.rand(B, 69, T, generator=g).to(DEV)
+    a = audio.unsqueeze(1)
+    alpha = torch.rand(B, 1, generator=g)
+    h = B // 2
+    loss, full = _critic_loss_grads(critic, x_real, x_fake, a, alpha)
+    l1, g1 = _critic_loss_grads(critic, x_real[:h].contiguous(), x_fake[:h].contiguous(), a[:h].contiguous(), alpha[:h])
+    l2, g2 = _critic_loss_grads(critic, x_real[h:].contiguous(), x_fake[h:].contiguous(), a[h:].contiguous(), alpha[h:])
+    assert abs(loss.item() - 0.5 * (l1.item() + l2.item())) < 1e-4 * max(1.0, abs(loss.item()))
+    worst = 0.0
+    for f, p, q in zip(full, g1, g2):
+        worst = max(worst, rel_l2(f, 0.5 * (p + q)))
+    flat_full = torch.cat([f.reshape(-1) for f in full])
+    flat_mean = torch.cat([(0.5 * (p + q)).reshape(-1) for p, q in zip(g1, g2)])
+    assert rel_l2(flat_full, flat_mean) < 1e-3  # the whole gradient
+    assert worst < 1e-2, worst                   # every tensor (small audio-branch biases see single flips)
+
+
+def test_generator_eval_shard_identity(models, batch):
+    gen, _ = models
+    _, _, slices = batch
+    gen.eval()
+    try:
+        noise = torch.randn(B, T, 10, generator=torch.Generator().manual_seed(1)).to(DEV)
+        with torch.no_grad():
+            full = gen(slices, [T] * B, noise)
+            h = B // 2
+            halves = torch.cat((gen(slices[:h].contiguous(), [T] * h, noise[:h].contiguous()),
+                                gen(slices[h:].contiguous(), [T] * h, noise[h:].contiguous())), 0)
+    finally:
+        gen.train()
+    assert full.shape == (B * T, 69)
+    assert torch.isfinite(full).all()
+    assert rel(full, halves) < 2e-5
+
+
+def test_train_step_is_finite_and_updates(models, batch):
+    """8 loop bodies at full size (one generator iteration): finite losses, parameters move."""
+    import bench
+    from music2dance_amd.engine import Phase3Engine
+    gen, critic = bench.build_models(torch.device(DEV), T)
+    eng = Phase3Engine(gen, critic, bench.P3_DEFAULT)
+    before = [p.detach().clone() for p in critic.parameters()][:3] + [p.detach().clone() for p in gen.parameters()][:3]
+    real, audio, slices = batch
+    torch.manual_seed(3)
+    for _ in range(8):
+        out = eng.train_step(real, audio, slices)
+    eng.flush()
+    assert set(out) == {"loss_critic", "gp", "w_dist", "loss_gen", "l1_loss_train"}
+    assert all(math.isfinite(float(v)) for v in out.values())
+    after = [p.detach() for p in critic.parameters()][:3] + [p.detach() for p in gen.parameters()][:3]
+    assert all(not torch.equal(a, b) for a, b in zip(after, before))
