@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--enc-type", default="default", choices=["default", "unet", "wavegan"],
                     help="audio encoder (BASELINE.json configs[3]/[4] use wavegan / unet)")
     ap.add_argument("--ablated", action="store_true", help="pose-only critic (required for --frames != 120)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-GPU dry runs)")
+    ap.add_argument("--same-device", action="store_true", help="debug: all ranks on cuda:0 (with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel profile")
     args = ap.parse_args()
@@ -112,7 +114,9 @@ def main():
     from music2dance_amd import dp, kernels
     from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
 
-    rank, world, local = dp.init_from_env("nccl")
+    rank, world, local = dp.init_from_env(args.backend)
+    if args.same_device:
+        local = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
@@ -160,7 +164,7 @@ def main():
         seqs = args.steps * args.batch * world
         value = seqs / elapsed
         out = {
-            "metric": "120-frame seq/sec, phase3 WGAN-GP step, batch 64 per GPU",
+            "metric": "120-frame seq/sec, phase3 WGAN-GP step, batch %d per GPU" % args.batch,
             "value": round(value, 2), "unit": "seq/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
