@@ -232,6 +232,15 @@ class SequenceGenerator(nn.Module):
         initialize_weights(self)
         self.to(device)
 
+    def _side_stream(self, device):
+        if device.type != "cuda" or not self.overlap_noise_gru:
+            return None
+        if getattr(self, "_noise_stream", None) is None:
+            self._noise_stream = torch.cuda.Stream(device=device)
+        return self._noise_stream
+
+    overlap_noise_gru = True
+
     def forward(self, x, lengths, noise=None):
         # x: (batch, frames, window)
         frames = x.size(1)
@@ -240,8 +249,20 @@ class SequenceGenerator(nn.Module):
             # drawn from the HOST generator, then moved (phase3/archis/default.py:31-34)
             noise = torch.randn(list(code.size()[:-1]) + [self.noise_size]).to(code.device)
         ls = _descending(lengths)
-        h = self.audio_rnn(code, lengths_tensor(ls, frames, code.device))[:, :max(ls)]
-        n = self.noise_gen(noise)
+        # the two recurrences are independent and latency-bound (a few dozen blocks per step):
+        # the 1-layer noise GRU runs on a side stream under the 3-layer audio GRU
+        side = self._side_stream(code.device)
+        if side is not None:
+            cur = torch.cuda.current_stream(code.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                n = self.noise_gen(noise)
+            h = self.audio_rnn(code, lengths_tensor(ls, frames, code.device))[:, :max(ls)]
+            cur.wait_stream(side)
+            n.record_stream(cur)
+        else:
+            h = self.audio_rnn(code, lengths_tensor(ls, frames, code.device))[:, :max(ls)]
+            n = self.noise_gen(noise)
         latent = torch.cat((h, n), -1)
         return self.decoder(latent.reshape(-1, self.decoder.latent_size))
 
