@@ -33,9 +33,10 @@ struct ThinArgs {
 // which overlap by k - stride samples, are loaded once.
 template <int KS, int S, int P>
 __global__ void __launch_bounds__(256) thin_fwd_kernel(const ThinArgs a) {
-  __shared__ float wl[THIN_MAX_W];
-  for (int i = threadIdx.x; i < a.Cout * KS; i += 256) wl[i] = a.w[i];
-  __syncthreads();
+  // weights are read with wave-uniform indices straight from global memory: hipcc turns
+  // them into scalar (s_load) loads served by the scalar cache, so the FMAs take the weight
+  // as an SGPR operand and no LDS or vector-memory issue slot is spent on them
+  const float* __restrict__ wl = a.w;
   constexpr int XW = KS + S * (P - 1);
   const int n = blockIdx.y;
   const int l0 = (blockIdx.x * 256 + threadIdx.x) * P;
@@ -83,9 +84,7 @@ __global__ void __launch_bounds__(256) thin_fwd_kernel(const ThinArgs a) {
 // dx[n, s*q + r - pad] = sum_co sum_t W[co, r + s*t] * dy[n, co, q - t]; thread = P consecutive q
 template <int KS, int S, int P>
 __global__ void __launch_bounds__(256) thin_bwd_data_kernel(const ThinArgs a) {
-  __shared__ float wl[THIN_MAX_W];
-  for (int i = threadIdx.x; i < a.Cout * KS; i += 256) wl[i] = a.w[i];
-  __syncthreads();
+  const float* __restrict__ wl = a.w;  // wave-uniform indices -> scalar loads (see thin_fwd_kernel)
   constexpr int T = (KS + S - 1) / S;
   constexpr int DW = T + P - 1;  // dy window: l in [q0 - (T-1), q0 + P - 1]
   const int n = blockIdx.y;

