@@ -195,6 +195,99 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_kernel(const ThinArgs a) 
   }
 }
 
+// Backward-weight on the matrix pipe for Cout == 32: dW^T[kk, co] = sum_l x[n, s*l - pad + kk] * dy[n, co, l]
+// is a 32 x 32 (25 valid rows) tile accumulated over a very long K = l, i.e. one
+// v_mfma_f32_32x32x2_f32 per two positions with NO cross-lane reduction. Each wave streams its own
+// 64-position tiles: the (32 co x 64 l) slice of dy (times the activation mask) goes through a
+// wave-private LDS image with coalesced 16-B loads, the x windows are read straight from
+// global memory (lanes 0-31 read 32 consecutive samples). HBM-bound: dy (+ mask) is read once.
+typedef float thin_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KS, int S>
+__global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArgs a) {
+  constexpr int LD = 65;  // [co][l] image, odd stride: fragment reads (lanes along co) are conflict-free
+  __shared__ float tile[4][32 * LD];
+  __shared__ float red[4][32 * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int l0 = blockIdx.x * a.chunk;
+  int l1 = l0 + a.chunk;
+  if (l1 > a.Lout) l1 = a.Lout;
+  const float* xr = a.x + (size_t)n * a.L;
+  const float* dyn = a.dy + (size_t)n * 32 * a.Lout;
+  const float* mkn = a.mask ? a.mask + (size_t)n * 32 * a.Lout : nullptr;
+  float* tl = tile[wave];
+  thin_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int i31 = lane & 31, h = lane >> 5;
+  const int lq = 4 * (lane & 15);
+  const bool vec = (a.Lout % 4) == 0;
+  float4 dv[8], mv[8];
+  // fetch(lt): this lane's 8 x float4 of the dy tile (and mask) starting at position lt
+  auto fetch = [&](int lt) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int co = (lane >> 4) + 4 * i;
+      const size_t g = (size_t)co * a.Lout + lt + lq;
+      if (vec && lt + lq + 3 < l1) {
+        dv[i] = *reinterpret_cast<const float4*>(dyn + g);
+        mv[i] = mkn ? *reinterpret_cast<const float4*>(mkn + g) : make_float4(1.f, 1.f, 1.f, 1.f);
+      } else {
+        float d[4], m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = lt + lq + j < l1;
+          d[j] = ok ? dyn[g + j] : 0.f;
+          m[j] = (ok && mkn) ? mkn[g + j] : 1.f;
+        }
+        dv[i] = make_float4(d[0], d[1], d[2], d[3]);
+        mv[i] = make_float4(m[0], m[1], m[2], m[3]);
+      }
+    }
+  };
+  int lt = l0 + wave * 64;
+  if (lt < l1) fetch(lt);
+  for (; lt < l1; lt += 256) {
+    // land the prefetched tile in the wave-private LDS image (mask applied here)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int co = (lane >> 4) + 4 * i;
+      const float ms = a.mask_slope;
+      tl[co * LD + lq + 0] = dv[i].x * (mv[i].x > 0.f ? 1.f : ms);
+      tl[co * LD + lq + 1] = dv[i].y * (mv[i].y > 0.f ? 1.f : ms);
+      tl[co * LD + lq + 2] = dv[i].z * (mv[i].z > 0.f ? 1.f : ms);
+      tl[co * LD + lq + 3] = dv[i].w * (mv[i].w > 0.f ? 1.f : ms);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lt + 256 < l1) fetch(lt + 256);  // next tile's loads fly under this tile's MFMAs
+    float av[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int l = lt + 2 * j + h;
+      const int pos = l * S - a.pad + i31;
+      av[j] = (i31 < KS && l < l1 && pos >= 0 && pos < a.L) ? xr[pos] : 0.f;  // A[kk = i31][k = h]
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float bv = tl[i31 * LD + 2 * j + h];  // B[k = h][co = i31]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // C[i = kk][j = co]: col = lane & 31 (co), row = (r & 3) + 8 * (r >> 2) + 4 * h (kk)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i31] = acc[r];
+  __syncthreads();
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  for (int o = threadIdx.x; o < 32 * KS; o += 256) {
+    const int co = o / KS, kk = o % KS;
+    const int idx = kk * 32 + co;
+    a.out[blk * 32 * KS + o] = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+  }
+}
+
 __global__ void __launch_bounds__(256) thin_sum_partials_kernel(const float* partial, float* dw, int nblk, int n_out) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= n_out) return;
@@ -209,7 +302,7 @@ static bool thin_ok(int Cin, int Cout, int ks, int stride) {
 
 bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride) { return thin_ok(Cin, Cout, ks, stride); }
 
-static const int THIN_BW_CHUNK = 32768;
+static const int THIN_BW_CHUNK = 4096;
 
 size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout) {
   const size_t nblk = (size_t)B * m2d_ceil_div(Lout, THIN_BW_CHUNK);
@@ -260,7 +353,10 @@ int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L
   const int nchunk = m2d_ceil_div(Lout, THIN_BW_CHUNK);
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (dy_mask ? 2 : 1)), "thin_conv_bwd_weight", Cout, ks, B * Lout);
-  hipLaunchKernelGGL((thin_bwd_weight_kernel<25, 4, 8>), dim3(nchunk, B, Cout / 4), dim3(256), 0, stream, a);
+  if (Cout == 32)
+    hipLaunchKernelGGL((thin_bwd_weight_mfma_kernel<25, 4>), dim3(nchunk, B), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((thin_bwd_weight_kernel<25, 4, 8>), dim3(nchunk, B, Cout / 4), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(thin_sum_partials_kernel, dim3(m2d_ceil_div(Cout * ks, 256)), dim3(256), 0, stream,
                      (const float*)ws, dw, nchunk * B, Cout * ks);
   M2D_CHECK_LAUNCH("thin_bwd_weight_kernel");
