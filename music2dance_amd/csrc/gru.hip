@@ -295,17 +295,61 @@ __global__ void __launch_bounds__(256) m2d_gru_stack_fwd_kernel(const GruStackFw
   const int arow = b0 + (lane & 15);
   const int bcol = u0 + (lane & 15);
   const bool rok = arow < a.B, cok = bcol < H;
-  if (t > 0) {
-    f32x4 h3[3] = {acc[0], acc[1], acc[2]};
-    const int cols[3] = {0, 1, 2};
-    gru_mac<3>(a.out[l] + ((size_t)arow * T + (t - 1)) * H, rok, a.w_hh_t[l], H, 3 * H, bcol, cok, wave, lane, h3, cols);
-    acc[0] = h3[0]; acc[1] = h3[1]; acc[2] = h3[2];
-  }
-  if (l > 0) {
-    f32x4 i3[3] = {acc[0], acc[1], acc[3]};
-    const int cols[3] = {0, 1, 2};
-    gru_mac<3>(a.out[l - 1] + ((size_t)arow * T + t) * H, rok, a.w_ih_t[l], H, 3 * H, bcol, cok, wave, lane, i3, cols);
-    acc[0] = i3[0]; acc[1] = i3[1]; acc[3] = i3[2];
+  // Both contractions (hidden: h_l[t-1] W_hh^T, input: h_{l-1}[t] W_ih^T) have K = H. When a
+  // wave's share fits one batch (H <= 4 * 4 * GRU_UNROLL = 256) ALL operand loads of both are
+  // issued before the first MFMA: one memory round trip per step instead of two.
+  const int nsteps = (H + 3) / 4;
+  const bool use_h = t > 0, use_i = l > 0;
+  if (nsteps <= 4 * GRU_UNROLL) {
+    float ah[GRU_UNROLL], bh[GRU_UNROLL][3], ai[GRU_UNROLL], bi[GRU_UNROLL][3];
+    const float* hrow = a.out[l] + ((size_t)arow * T + (use_h ? t - 1 : 0)) * H;
+    const float* irow = a.out[use_i ? l - 1 : 0] + ((size_t)arow * T + t) * H;
+    const float* wh = a.w_hh_t[l];
+    const float* wi = a.w_ih_t[use_i ? l : 0];
+#pragma unroll
+    for (int i = 0; i < GRU_UNROLL; ++i) {
+      const int st = wave + 4 * i;
+      const int k = 4 * st + (lane >> 4);
+      const bool kok = st < nsteps && k < H;
+      const size_t wo = (size_t)(kok ? k : 0) * 3 * H + (cok ? bcol : 0);
+      const bool okh = use_h && kok, oki = use_i && kok;
+      ah[i] = (okh && rok) ? hrow[k] : 0.f;
+      ai[i] = (oki && rok) ? irow[k] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        bh[i][j] = (okh && cok) ? wh[wo + j * H] : 0.f;
+        bi[i][j] = (oki && cok) ? wi[wo + j * H] : 0.f;
+      }
+    }
+    if (use_h) {
+#pragma unroll
+      for (int i = 0; i < GRU_UNROLL; ++i) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][1], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][2], acc[2], 0, 0, 0);
+      }
+    }
+    if (use_i) {
+#pragma unroll
+      for (int i = 0; i < GRU_UNROLL; ++i) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][1], acc[1], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][2], acc[3], 0, 0, 0);
+      }
+    }
+  } else {
+    if (use_h) {
+      f32x4 h3[3] = {acc[0], acc[1], acc[2]};
+      const int cols[3] = {0, 1, 2};
+      gru_mac<3>(a.out[l] + ((size_t)arow * T + (t - 1)) * H, rok, a.w_hh_t[l], H, 3 * H, bcol, cok, wave, lane, h3, cols);
+      acc[0] = h3[0]; acc[1] = h3[1]; acc[2] = h3[2];
+    }
+    if (use_i) {
+      f32x4 i3[3] = {acc[0], acc[1], acc[3]};
+      const int cols[3] = {0, 1, 2};
+      gru_mac<3>(a.out[l - 1] + ((size_t)arow * T + t) * H, rok, a.w_ih_t[l], H, 3 * H, bcol, cok, wave, lane, i3, cols);
+      acc[0] = i3[0]; acc[1] = i3[1]; acc[3] = i3[2];
+    }
   }
 #pragma unroll
   for (int g = 0; g < 4; ++g)
