@@ -103,7 +103,9 @@ int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* c
 /* ---- gradient penalty (losses.py:5-60) ----------------------------------------------------- */
 int m2d_gp_interpolate(const float* real, const float* fake, const float* alpha, float* out, int B, int n,
                        void* stream);
-int m2d_gp_penalty_fwd(const float* g, float* norms, float* penalty, int B, int n, int lp, void* stream);
+size_t m2d_gp_penalty_workspace_bytes(int B);
+int m2d_gp_penalty_fwd(const float* g, float* norms, float* penalty, int B, int n, int lp, void* ws, size_t ws_bytes,
+                       void* stream);
 int m2d_gp_penalty_bwd(const float* g, const float* norms, const float* gout, float* dg, int B, int n, int lp,
                        void* stream);
 

@@ -39,7 +39,8 @@ SIGNATURES = {
     "m2d_gru_stack_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F]),
     "m2d_gru_stack_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F]),
     "m2d_gp_interpolate": (_I, [_F, _F, _F, _F, _I, _I, _F]),
-    "m2d_gp_penalty_fwd": (_I, [_F, _F, _F, _I, _I, _I, _F]),
+    "m2d_gp_penalty_workspace_bytes": (_S, [_I]),
+    "m2d_gp_penalty_fwd": (_I, [_F, _F, _F, _I, _I, _I, _F, _S, _F]),
     "m2d_gp_penalty_bwd": (_I, [_F, _F, _F, _F, _I, _I, _I, _F]),
     "m2d_reduce_workspace_bytes": (_S, []),
     "m2d_l1_mean_fwd": (_I, [_F, _F, _F, _S, _F, _S, _F]),

@@ -49,34 +49,57 @@ __global__ void __launch_bounds__(256) m2d_gp_interpolate_kernel(const float* re
 
 // ---------------------------------------------------------------- GP norm penalty
 // norms[b] = sqrt(sum_i g[b,i]^2 + eps)   (eps = 1e-12 for GP, 0 for LP; losses.py:47-54)
-__global__ void __launch_bounds__(256) m2d_gp_norm_kernel(const float* g, float* norms, int n, float eps) {
+// Stage 1: GP_SPLIT blocks per sample (a 76 800-element audio gradient is 307 KB: one block per
+// sample would leave 3/4 of the CUs idle and be latency-bound), float4 loads, fp32 partials
+// flushed to fp64 every 16 terms; partial[b][s] is written without atomics (deterministic).
+#define GP_SPLIT 16
+__global__ void __launch_bounds__(256) m2d_gp_norm_partial_kernel(const float* g, double* partial, int n) {
   __shared__ double sh[256];
-  const int b = blockIdx.x;
+  const int b = blockIdx.y, sp = blockIdx.x;
   const float* row = g + (size_t)b * n;
-  float s = 0.f;
+  const int per = ((n + GP_SPLIT - 1) / GP_SPLIT + 3) & ~3;
+  const int i0 = sp * per;
+  int i1 = i0 + per;
+  if (i1 > n) i1 = n;
   double acc = 0.0;
-  int cnt = 0;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = row[i];
-    s += v * v;
-    if (++cnt == 64) {  // flush the fp32 partial regularly: keeps the sum accurate for 76 800 terms
-      acc += (double)s;
-      s = 0.f;
-      cnt = 0;
+  const bool vec = (((size_t)row) & 15) == 0 && (n % 4) == 0;
+  if (vec) {
+    for (int i = i0 + 4 * threadIdx.x; i + 3 < i1; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(row + i);
+      acc += (double)(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
     }
+    const int tail = i0 + ((i1 - i0) & ~3);
+    for (int i = tail + threadIdx.x; i < i1; i += 256) acc += (double)(row[i] * row[i]);
+  } else {
+    float s = 0.f;
+    int cnt = 0;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+      const float v = row[i];
+      s += v * v;
+      if (++cnt == 16) {
+        acc += (double)s;
+        s = 0.f;
+        cnt = 0;
+      }
+    }
+    acc += (double)s;
   }
-  acc += (double)s;
   acc = block_sum_256(acc, sh);
-  if (threadIdx.x == 0) norms[b] = sqrtf((float)acc + eps);
+  if (threadIdx.x == 0) partial[(size_t)b * GP_SPLIT + sp] = acc;
 }
 
-// penalty = mean_b (norm_b - 1)^2            (lp == 0)
-//         = mean_b max(0, norm_b - 1)^2      (lp != 0)
-__global__ void __launch_bounds__(256) m2d_gp_penalty_kernel(const float* norms, int B, int lp, float* out) {
+// Stage 2 (one block): norms[b] = sqrt(sum_s partial[b][s] + eps); penalty = mean_b (norm_b - 1)^2
+// (lp == 0) or mean_b max(0, norm_b - 1)^2 (lp != 0)
+__global__ void __launch_bounds__(256) m2d_gp_penalty_kernel(const double* partial, float* norms, int B, int lp,
+                                                             float eps, float* out) {
   __shared__ double sh[256];
   double s = 0.0;
   for (int b = threadIdx.x; b < B; b += 256) {
-    float d = norms[b] - 1.0f;
+    double q = 0.0;
+    for (int k = 0; k < GP_SPLIT; ++k) q += partial[(size_t)b * GP_SPLIT + k];
+    const float nb = sqrtf((float)q + eps);
+    norms[b] = nb;
+    float d = nb - 1.0f;
     if (lp && d < 0.f) d = 0.f;
     s += (double)(d * d);
   }
@@ -257,12 +280,17 @@ int m2d_gp_interpolate(const float* real, const float* fake, const float* alpha,
 
 // losses.py:47-60 — per-sample L2 norm of the critic's input gradient and the penalty.
 // norms: B floats (saved for the backward), penalty: 1 float.
-int m2d_gp_penalty_fwd(const float* g, float* norms, float* penalty, int B, int n, int lp, void* stream_) {
+size_t m2d_gp_penalty_workspace_bytes(int B) { return (size_t)B * GP_SPLIT * sizeof(double); }
+
+int m2d_gp_penalty_fwd(const float* g, float* norms, float* penalty, int B, int n, int lp, void* ws,
+                       size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || n <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_gp_penalty_fwd: bad shape");
-  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 4.0 * B * (double)n);
-  hipLaunchKernelGGL(m2d_gp_norm_kernel, dim3(B), dim3(256), 0, stream, g, norms, n, lp ? 0.0f : 1e-12f);
-  hipLaunchKernelGGL(m2d_gp_penalty_kernel, dim3(1), dim3(256), 0, stream, (const float*)norms, B, lp, penalty);
+  if (!ws || ws_bytes < m2d_gp_penalty_workspace_bytes(B)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_gp_penalty_fwd: workspace");
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 4.0 * B * (double)n, "gp_norm_penalty", B, n, 0);
+  hipLaunchKernelGGL(m2d_gp_norm_partial_kernel, dim3(GP_SPLIT, B), dim3(256), 0, stream, g, (double*)ws, n);
+  hipLaunchKernelGGL(m2d_gp_penalty_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, norms, B, lp,
+                     lp ? 0.0f : 1e-12f, penalty);
   M2D_CHECK_LAUNCH("m2d_gp_penalty_kernel");
   return M2D_OK;
 }

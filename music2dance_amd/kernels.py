@@ -262,8 +262,11 @@ class HipKernels:
         B, n = g.shape
         norms = torch.empty((B,), dtype=torch.float32, device=dev)
         pen = torch.empty((), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(h.m2d_gp_penalty_workspace_bytes(B), dev)
         with torch.cuda.device(dev):
-            rc = _lib.lib().m2d_gp_penalty_fwd(_ptr(g), _ptr(norms), _ptr(pen), B, n, 1 if lp else 0, _stream(dev))
+            rc = h.m2d_gp_penalty_fwd(_ptr(g), _ptr(norms), _ptr(pen), B, n, 1 if lp else 0, _ptr(ws),
+                                      ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_gp_penalty_fwd")
         return pen, norms
 
