@@ -44,3 +44,10 @@ for name, fn in (("critic", lambda: eng.critic_iteration(real, audio, slices)), 
     print("==== %s iteration: engine launches by shape (tag M N K: count, ms, TF/s)" % name)
     for k, (c, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-24s %6d %8d %7d : %3d %8.3f ms %6.1f TF/s" % (k[0], k[1], k[2], k[3], c, ms, fl / ms / 1e9 if ms else 0))
+# host enqueue time vs device time
+import time
+torch.cuda.synchronize()
+for name, fn in (("critic", lambda: eng.critic_iteration(real, audio, slices)), ("gen", lambda: eng.generator_iteration(real, audio, slices))):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); fn(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("%s: host enqueue %.1f ms, until device idle %.1f ms" % (name, 1e3 * (t1 - t0), 1e3 * (t2 - t0)))
