@@ -47,16 +47,22 @@ int m2d_prof_dump(char* buf, int cap);
  * reference: phase3/archis/default.py:64-70 (DefaultAudioEncoder), :90-97,216 (U-Net),
  * :117-128 (WaveGAN), :201-204 (TemporalBlock), :298-303 (AudioDiscriminator),
  * :326-333 (StickDiscriminator); phase2/archis/default.py:31-38,154-157. */
-int m2d_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int L,
-                   int Cout, int ks, int stride, int pad, int act, float slope, const float* residual,
-                   const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream);
-int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int L, int Cout, int ks,
-                        int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
+int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
+                   int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
+                   const float* residual, const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes,
+                   void* stream);
+int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
+                        int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
                         size_t ws_bytes, void* stream);
 int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int L, int Cout,
                           int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
                           size_t ws_bytes, void* stream);
-/* which: 0 forward, 1 backward-data, 2 backward-weight */
+/* The GEMMs behind forward / backward-data contract over (tap, channel) and read the weights
+ * through packed images: w_fwd (Cout, ks, Cin) and w_bwd (Cin, ks, Cout) of w (Cout, Cin, ks).
+ * `w_packed` above is the matching image, or NULL: the call then packs into its workspace.
+ * Callers that reuse weights across calls pack once per weight update (either output may be NULL). */
+int m2d_conv1d_pack_weights(const float* w, float* w_fwd, float* w_bwd, int Cout, int Cin, int ks, void* stream);
+/* which: 0 forward, 1 backward-data, 2 backward-weight (includes the room to pack the weights) */
 size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, int ks, int stride, int pad);
 
 /* ---- dense GEMMs behind nn.Linear and the GRU input projection --------------------------

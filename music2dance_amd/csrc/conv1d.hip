@@ -31,18 +31,21 @@ int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L
                         int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes,
                         hipStream_t stream);
 
-static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, float* y, int B, int Cin,
+// Forward conv as a GEMM. Cin >= 16: K ordered (tap, channel) - hi = tap, lo = ci - over the
+// packed weights wp (Cout, ks, Cin): every 16-chunk sits on one tap, so the padding window is
+// chunk-uniform. Narrow inputs (the encoders' first layer, Cin = 1, k = 250) keep the
+// natural order (channel, tap) over w itself.
+static inline bool conv_uses_packed(int Cin) { return Cin >= M2D_BK; }
+
+static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, const float* wp, float* y, int B, int Cin,
                      int L, int Cout, int ks, int stride, int pad, int Lout) {
   memset(&p, 0, sizeof(p));
   p.M = Cout;
   p.N = B * Lout;
   p.K = Cin * ks;
   p.phases = 1;
-  // A(m = co, k = (ci,kk)) = W[co*Cin*ks + k]
-  m2d_operand_plain(p.A, w, Cout, Cin * ks, 1, (long long)Cout * Cin * ks);
-  // B(k = (ci,kk), col = (n,l)) = x[n*Cin*L + ci*L + l*s - p + kk]
+  const bool packed = conv_uses_packed(Cin);
   M2dOperand& b = p.B;
-  memset(&b, 0, sizeof(b));
   b.base = x;
   b.nbytes = m2d_extent_bytes((long long)B * Cin * L);
   b.nrows = p.N;
@@ -53,12 +56,35 @@ static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, float* y,
   b.r_off = -pad;
   b.r_pos_mul = stride;
   b.r_pos_off = -pad;
-  b.kdiv = ks;
-  b.kdiv_inv = 1.f / (float)ks;
-  b.k_hi_stride = L;
-  b.k_lo_stride = 1;
-  b.k_pos_mul = 1;
   b.lim = L;
+  if (packed) {
+    p.nhi = ks;
+    p.kdiv = Cin;
+    p.lo_outer = 1;
+    // A(m = co, k = (kk,ci)) = wp[co*ks*Cin + kk*Cin + ci]
+    m2d_operand_plain(p.A, wp, Cout, Cin * ks, 1, (long long)Cout * Cin * ks);
+    p.A.k_hi_stride = Cin;
+    // B(k = (kk,ci), col = (n,l)) = x[n*Cin*L + ci*L + l*s - p + kk]
+    b.k_hi_stride = 1;
+    b.k_lo_stride = L;
+    b.k_pos_hi = 1;
+    b.k_pos_lo = 0;
+    b.k_safe_lo = 0;
+    b.k_safe_hi = 0x7fffffff;
+  } else {
+    p.nhi = Cin;
+    p.kdiv = ks;
+    // A(m = co, k = (ci,kk)) = w[co*Cin*ks + ci*ks + kk]
+    m2d_operand_plain(p.A, w, Cout, Cin * ks, 1, (long long)Cout * Cin * ks);
+    p.A.k_hi_stride = ks;
+    b.k_hi_stride = L;
+    b.k_lo_stride = 1;
+    b.k_pos_hi = 0;
+    b.k_pos_lo = 1;
+    // taps kk whose position l*s - pad + kk lies in [0, L) for every l
+    b.k_safe_lo = pad;
+    b.k_safe_hi = L - (Lout - 1) * stride + pad;
+  }
   // out(m = co, col = (n,l)) = y[n*Cout*Lout + co*Lout + l]
   m2d_outmap_plain(p.O, y, Lout, 1);
   p.O.cdiv = Lout;
@@ -67,15 +93,57 @@ static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, float* y,
   p.O.c_lo_stride = 1;
 }
 
+// wf[co][kk][ci] = wb[ci][kk][co] = w[co][ci][kk]
+__global__ void __launch_bounds__(256) m2d_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                                 float* __restrict__ wb, int Cout, int Cin, int ks) {
+  const size_t total = (size_t)Cout * Cin * ks;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    // idx enumerates the forward image (co, kk, ci): coalesced writes of wf, strided reads of w
+    const int ci = (int)(idx % Cin);
+    const size_t t = idx / Cin;
+    const int kk = (int)(t % ks);
+    const int co = (int)(t / ks);
+    const float v = w[((size_t)co * Cin + ci) * ks + kk];
+    if (wf) wf[idx] = v;
+    if (wb) wb[((size_t)ci * ks + kk) * Cout + co] = v;
+  }
+}
+
+static int pack_weights(const float* w, float* wf, float* wb, int Cout, int Cin, int ks, hipStream_t stream) {
+  const size_t total = (size_t)Cout * Cin * ks;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(m2d_pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, wf, wb, Cout, Cin, ks);
+  M2D_CHECK_LAUNCH("m2d_pack_weights_kernel");
+  return M2D_OK;
+}
+
+static inline size_t pack_bytes(int Cout, int Cin, int ks) {
+  return (((size_t)Cout * Cin * ks * sizeof(float)) + 255) & ~(size_t)255;
+}
+
 extern "C" {
+
+// Packed weight images the forward (wf: (Cout, ks, Cin)) and backward-data (wb: (Cin, ks, Cout))
+// GEMMs read; either pointer may be NULL. Callers that keep them across calls (and refresh
+// them when the weights change) pass them as `w_packed`; otherwise each call packs into its
+// workspace.
+int m2d_conv1d_pack_weights(const float* w, float* w_fwd, float* w_bwd, int Cout, int Cin, int ks, void* stream) {
+  if (Cout <= 0 || Cin <= 0 || ks <= 0 || !w) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_pack_weights: bad arguments");
+  if (!fits_i32((long long)Cout * Cin * ks)) M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_pack_weights: too large");
+  if (!w_fwd && !w_bwd) return M2D_OK;
+  return pack_weights(w, w_fwd, w_bwd, Cout, Cin, ks, (hipStream_t)stream);
+}
 
 // Replaces nn.Conv1d forward (+ fused bias / ReLU / LeakyReLU / residual add):
 // phase3/archis/default.py:78-82,137-143,207-210,312-319,342-346.
+// `w_packed` (optional): the (Cout, ks, Cin) image of w from m2d_conv1d_pack_weights.
 // `out_mask` (optional, shape of y) multiplies the result by (mask>0 ? 1 : out_mask_slope):
 // it is the d/d(dy) branch of backward-data's derivative (double backward of the GP).
-int m2d_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int L,
-                   int Cout, int ks, int stride, int pad, int act, float slope, const float* residual,
-                   const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream) {
+int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
+                   int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
+                   const float* residual, const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes,
+                   void* stream) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || ks <= 0 || stride <= 0 || pad < 0 || L <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd: bad shape B=%d Cin=%d L=%d Cout=%d k=%d s=%d p=%d", B, Cin, L,
              Cout, ks, stride, pad);
@@ -86,8 +154,40 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, 
   if (!residual && m2d_thin_applicable(Cin, Cout, ks, stride))
     return m2d_thin_fwd(x, w, bias, y, B, L, Cout, ks, stride, pad, Lout, act, slope, out_mask, out_mask_slope,
                         (hipStream_t)stream);
+  if (Lout == 1 && pad == 0 && L == ks) {
+    // full-length kernel (fconv / l6 / last encoder conv): y[n,co] = b[co] + sum_k x[n,k] W[co,k], k = (ci,kk):
+    // a plain NT GEMM over the natural layouts (both operands contiguous in k)
+    M2dGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = Cout;
+    p.N = B;
+    p.K = Cin * ks;
+    p.nhi = 1;
+    p.kdiv = p.K;
+    p.phases = 1;
+    m2d_operand_plain(p.A, w, Cout, p.K, 1, (long long)Cout * p.K);
+    m2d_operand_plain(p.B, x, B, p.K, 1, (long long)B * p.K);
+    m2d_outmap_plain(p.O, y, 1, Cout);
+    p.O.bias = bias;
+    p.O.bias_mode = bias ? 1 : 0;
+    p.O.act = act;
+    p.O.slope = slope;
+    p.O.residual = residual;
+    p.O.mask = out_mask;
+    p.O.mask_slope = out_mask_slope;
+    return m2d_gemm_launch(p, true, true, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_fwd");
+  }
+  if (conv_uses_packed(Cin) && !w_packed) {
+    const size_t pb = pack_bytes(Cout, Cin, ks);
+    if (!ws || ws_bytes < pb) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd: workspace too small to pack the weights");
+    const int rc = pack_weights(w, (float*)ws, nullptr, Cout, Cin, ks, (hipStream_t)stream);
+    if (rc) return rc;
+    w_packed = (const float*)ws;
+    ws = (char*)ws + pb;
+    ws_bytes -= pb;
+  }
   M2dGemmParams p;
-  fill_fwd(p, x, w, y, B, Cin, L, Cout, ks, stride, pad, Lout);
+  fill_fwd(p, x, w, w_packed, y, B, Cin, L, Cout, ks, stride, pad, Lout);
   p.O.bias = bias;
   p.O.bias_mode = bias ? 1 : 0;
   p.O.act = act;
@@ -101,9 +201,10 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, 
 
 // Replaces the input-gradient half of convolution_backward (autograd of nn.Conv1d), the
 // op the gradient penalty differentiates a second time (losses.py:40-44).
+// `w_packed` (optional): the (Cin, ks, Cout) image of w from m2d_conv1d_pack_weights.
 // `dy_mask` (optional, shape of dy): dy is read as dy * (mask>0 ? 1 : dy_mask_slope).
-int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int L, int Cout,
-                        int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
+int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
+                        int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
                         size_t ws_bytes, void* stream) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0)
@@ -121,6 +222,8 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
     p.M = B;
     p.N = Cin * ks;
     p.K = Cout;
+    p.nhi = 1;
+    p.kdiv = Cout;
     p.phases = 1;
     m2d_operand_plain(p.A, dy, B, Cout, 1, (long long)B * Cout);
     p.A.mask = dy_mask;
@@ -129,6 +232,18 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
     m2d_outmap_plain(p.O, dx, Cin * ks, 1);
     return m2d_gemm_launch(p, true, false, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }
+  if (!w_packed) {
+    const size_t pb = pack_bytes(Cout, Cin, ks);
+    if (!ws || ws_bytes < pb)
+      M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_bwd_data: workspace too small to pack the weights");
+    const int rc = pack_weights(w, nullptr, (float*)ws, Cout, Cin, ks, (hipStream_t)stream);
+    if (rc) return rc;
+    w_packed = (const float*)ws;
+    ws = (char*)ws + pb;
+    ws_bytes -= pb;
+  }
+  // dx[n, ci, s*q + r - pad] = sum_{t, co} wb[ci, r + s*t, co] * dy[n, co, q - t] per output phase r:
+  // K = (t, co), hi = t (taps(r) of them, resolved on the device), lo = co.
   p.bwd_data = 1;
   p.phases = stride;
   p.ph_ks = ks;
@@ -137,31 +252,23 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
   p.ph_L = L;
   p.ph_batch = B;
   p.M = Cin;
+  p.kdiv = Cout;
+  p.lo_outer = 1;
+  p.nhi = (ks + stride - 1) / stride;
   // widest phase: q in [qmin, (L-1+pad-r)/s]
-  int nq_max = 0, k_max = 0;
+  int nq_max = 0;
   for (int r = 0; r < stride; ++r) {
     const int qmin = r >= pad ? 0 : (pad - r + stride - 1) / stride;
     const int top = L - 1 + pad - r;
     const int nq = top >= 0 ? (top / stride - qmin + 1) : 0;
     if (nq > nq_max) nq_max = nq;
-    const int taps = r < ks ? (ks - r + stride - 1) / stride : 0;
-    if (Cout * taps > k_max) k_max = Cout * taps;
   }
   p.N = B * nq_max;
-  p.K = k_max;
-  // A(m = ci, k = (co,t)) = W[co*Cin*ks + ci*ks + r + s*t]  (r added per phase on device)
-  M2dOperand& a = p.A;
-  a.base = w;
-  a.nbytes = m2d_extent_bytes((long long)Cout * Cin * ks);
-  a.nrows = Cin;
-  a.rdiv = 1;
-  a.rdiv_inv = 1.f;
-  a.r_hi_stride = ks;
-  a.kdiv = 1;  // taps(r), set on device
-  a.kdiv_inv = 1.f;
-  a.k_hi_stride = Cin * ks;
-  a.k_lo_stride = stride;
-  // B(k = (co,t), col = (n,q)) = dy[n*Cout*Lout + co*Lout + q - t], valid iff 0 <= q - t < Lout
+  p.K = Cout * p.nhi;
+  // A(m = ci, k = (t,co)) = wb[ci*ks*Cout + (r + s*t)*Cout + co]  (r*Cout added per phase on device)
+  m2d_operand_plain(p.A, w_packed, Cin, ks * Cout, 1, (long long)Cout * Cin * ks);
+  p.A.k_hi_stride = stride * Cout;
+  // B(k = (t,co), col = (n,q)) = dy[n*Cout*Lout + co*Lout + q - t], valid iff 0 <= q - t < Lout
   M2dOperand& b = p.B;
   b.base = dy;
   b.nbytes = m2d_extent_bytes((long long)B * Cout * Lout);
@@ -173,11 +280,12 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
   b.r_hi_stride = Cout * Lout;
   b.r_lo_stride = 1;
   b.r_pos_mul = 1;
-  b.kdiv = 1;
-  b.kdiv_inv = 1.f;
-  b.k_hi_stride = Lout;
-  b.k_lo_stride = -1;
-  b.k_pos_mul = -1;
+  b.k_hi_stride = -1;
+  b.k_lo_stride = Lout;
+  b.k_pos_hi = -1;
+  b.k_pos_lo = 0;
+  b.k_safe_lo = 0;
+  b.k_safe_hi = 0x7fffffff;
   b.lim = Lout;
   // out(m = ci, col = (n,q)) = dx[n*Cin*L + ci*L + s*q + r - pad]
   m2d_outmap_plain(p.O, dx, L, 1);
@@ -191,11 +299,8 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
     p.bwd_data = 0;
     p.phases = 1;
     p.N = B * L;
+    p.nhi = ks;
     p.K = Cout * ks;
-    a.kdiv = ks;
-    a.kdiv_inv = 1.f / (float)ks;
-    b.kdiv = ks;
-    b.kdiv_inv = a.kdiv_inv;
     b.nrows = p.N;
     b.rdiv = L;
     b.rdiv_inv = 1.f / (float)L;
@@ -205,15 +310,15 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, float* dx, int B, int C
     p.O.cdiv_inv = b.rdiv_inv;
     p.O.c_off = 0;
     p.O.c_pos_off = 0;
-    return m2d_gemm_launch(p, /*a_kfast=*/false, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
+    return m2d_gemm_launch(p, /*a_kfast=*/true, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
                            (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }
-  return m2d_gemm_launch(p, /*a_kfast=*/false, /*b_kfast=*/false, /*allow_split=*/false, ws, ws_bytes,
+  return m2d_gemm_launch(p, /*a_kfast=*/true, /*b_kfast=*/false, /*allow_split=*/false, ws, ws_bytes,
                          (hipStream_t)stream, "m2d_conv1d_bwd_data");
 }
 
-// Replaces the weight-gradient half of convolution_backward. K = B*Lout is the long
-// dimension, so the launch is split-K with a deterministic slab reduction.
+// Replaces the weight-gradient half of convolution_backward. K = (sample, position) is the long
+// dimension (hi = n, lo = l), so the launch is split-K with a deterministic slab reduction.
 int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int L, int Cout,
                           int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
                           size_t ws_bytes, void* stream) {
@@ -231,21 +336,6 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
   p.N = Cin * ks;
   p.K = B * Lout;
   p.phases = 1;
-  // A(m = co, k = (n,l)) = dy[n*Cout*Lout + co*Lout + l]
-  M2dOperand& a = p.A;
-  a.base = dy;
-  a.nbytes = m2d_extent_bytes((long long)B * Cout * Lout);
-  a.mask = dy_mask;
-  a.mask_slope = dy_mask_slope;
-  a.nrows = Cout;
-  a.rdiv = 1;
-  a.rdiv_inv = 1.f;
-  a.r_hi_stride = Lout;
-  a.kdiv = Lout;
-  a.kdiv_inv = 1.f / (float)Lout;
-  a.k_hi_stride = Cout * Lout;
-  a.k_lo_stride = 1;
-  // B(k = (n,l), col = (ci,kk)) = x[n*Cin*L + ci*L + l*s - pad + kk]
   M2dOperand& b = p.B;
   b.base = x;
   b.nbytes = m2d_extent_bytes((long long)B * Cin * L);
@@ -257,29 +347,64 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
   b.r_off = -pad;
   b.r_pos_mul = 1;
   b.r_pos_off = -pad;
-  b.kdiv = Lout;
-  b.kdiv_inv = 1.f / (float)Lout;
-  b.k_hi_stride = Cin * L;
-  b.k_lo_stride = stride;
-  b.k_pos_mul = stride;
   b.lim = L;
+  bool a_kfast = true;
+  if (Lout >= M2D_BK) {
+    // K = (n, l): hi = sample, lo = position (contiguous in dy)
+    p.nhi = B;
+    p.kdiv = Lout;
+    // A(m = co, k = (n,l)) = dy[n*Cout*Lout + co*Lout + l]
+    m2d_operand_plain(p.A, dy, Cout, Lout, 1, (long long)B * Cout * Lout);
+    p.A.k_hi_stride = Cout * Lout;
+    // B(k = (n,l), col = (ci,kk)) = x[n*Cin*L + ci*L + l*s - pad + kk]
+    b.k_hi_stride = Cin * L;
+    b.k_lo_stride = stride;
+    b.k_pos_hi = 0;
+    b.k_pos_lo = stride;
+    // positions l whose every tap l*s - pad + kk, kk in [0, ks), lies in [0, L)
+    b.k_safe_lo = (pad + stride - 1) / stride;
+    b.k_safe_hi = (L - ks + pad) >= 0 ? (L - ks + pad) / stride + 1 : 0;
+  } else {
+    // short outputs (the encoders' deep layers, full-length kernels): K = (l, n), hi = position,
+    // lo = sample, so no chunk is mostly padding; dy is read row-fast (lanes along co, Lout apart)
+    // and the window depends on the chunk only
+    p.nhi = Lout;
+    p.kdiv = B;
+    a_kfast = false;
+    m2d_operand_plain(p.A, dy, Cout, Lout, Cout * Lout, (long long)B * Cout * Lout);
+    p.A.k_hi_stride = 1;
+    b.k_hi_stride = stride;
+    b.k_lo_stride = Cin * L;
+    b.k_pos_hi = stride;
+    b.k_pos_lo = 0;
+    b.k_safe_lo = 0;
+    b.k_safe_hi = 0x7fffffff;
+  }
+  p.A.mask = dy_mask;
+  p.A.mask_slope = dy_mask_slope;
   m2d_outmap_plain(p.O, dw, Cin * ks, 1);
-  return m2d_gemm_launch(p, /*a_kfast=*/true, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
-                         (hipStream_t)stream, "m2d_conv1d_bwd_weight");
+  return m2d_gemm_launch(p, a_kfast, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes, (hipStream_t)stream,
+                         "m2d_conv1d_bwd_weight");
 }
 
-// which: 0 forward, 1 backward-data, 2 backward-weight
+// which: 0 forward, 1 backward-data, 2 backward-weight. Includes the room forward / backward-data
+// need to pack the weights when the caller passes no `w_packed`.
 size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, int ks, int stride, int pad) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (Lout <= 0) return 0;
   if (m2d_thin_applicable(Cin, Cout, ks, stride)) return which == 2 ? m2d_thin_bwd_weight_ws(B, Cout, ks, Lout) : 0;
-  if (which == 0) return m2d_gemm_plan(Cout, B * Lout, Cin * ks, 1, true).ws_bytes;
-  if (which == 1) {
-    if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(B, Cin * ks, Cout, 1, true).ws_bytes;
-    if (stride == 1) return m2d_gemm_plan(Cin, B * L, Cout * ks, 1, true).ws_bytes;
-    return 0;
+  if (which == 0) {
+    if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(Cout, B, m2d_chunks(1, Cin * ks), 1, true).ws_bytes;
+    const bool packed = conv_uses_packed(Cin);
+    const int nch = packed ? m2d_chunks(ks, Cin) : m2d_chunks(Cin, ks);
+    return m2d_gemm_plan(Cout, B * Lout, nch, 1, true).ws_bytes + (packed ? pack_bytes(Cout, Cin, ks) : 0);
   }
-  return m2d_gemm_plan(Cout, Cin * ks, B * Lout, 1, true).ws_bytes;
+  if (which == 1) {
+    if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(B, Cin * ks, m2d_chunks(1, Cout), 1, true).ws_bytes;
+    if (stride == 1) return m2d_gemm_plan(Cin, B * L, m2d_chunks(ks, Cout), 1, true).ws_bytes + pack_bytes(Cout, Cin, ks);
+    return pack_bytes(Cout, Cin, ks);
+  }
+  return m2d_gemm_plan(Cout, Cin * ks, Lout >= M2D_BK ? m2d_chunks(B, Lout) : m2d_chunks(Lout, B), 1, true).ws_bytes;
 }
 
 // Dense row-major GEMMs behind nn.Linear (phase3/archis/default.py:153,161,176-177,256-257;
@@ -299,21 +424,26 @@ int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float*
   p.M = M;
   p.N = N;
   p.K = K;
+  p.nhi = K > 0 ? 1 : 0;
+  p.kdiv = K > 0 ? K : 1;
   p.phases = 1;
   bool akf = true, bkf = true;
+  // an empty contraction still runs the epilogue (bias / activation of zero): give the
+  // descriptors a non-empty extent, nothing is read through them
+  const long long ea = K > 0 ? (long long)M * K : 1, eb = K > 0 ? (long long)N * K : 1;
   if (mode == 0) {
-    m2d_operand_plain(p.A, a, M, K, 1, (long long)M * K);
-    m2d_operand_plain(p.B, b, N, K, 1, (long long)N * K);
+    m2d_operand_plain(p.A, a, M, K, 1, ea);
+    m2d_operand_plain(p.B, b, N, K, 1, eb);
     akf = true;
     bkf = true;
   } else if (mode == 1) {
-    m2d_operand_plain(p.A, a, M, K, 1, (long long)M * K);
-    m2d_operand_plain(p.B, b, N, 1, N, (long long)N * K);
+    m2d_operand_plain(p.A, a, M, K, 1, ea);
+    m2d_operand_plain(p.B, b, N, 1, N, eb);
     akf = true;
     bkf = false;
   } else {
-    m2d_operand_plain(p.A, a, M, 1, M, (long long)M * K);
-    m2d_operand_plain(p.B, b, N, 1, N, (long long)N * K);
+    m2d_operand_plain(p.A, a, M, 1, M, ea);
+    m2d_operand_plain(p.B, b, N, 1, N, eb);
     akf = false;
     bkf = false;
   }
@@ -331,7 +461,7 @@ int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float*
 
 size_t m2d_gemm_workspace_bytes(int mode, int M, int N, int K) {
   (void)mode;
-  return m2d_gemm_plan(M, N, K, 1, true).ws_bytes;
+  return m2d_gemm_plan(M, N, m2d_chunks(K > 0 ? 1 : 0, K > 0 ? K : 1), 1, true).ws_bytes;
 }
 
 }  // extern "C"

@@ -2,22 +2,31 @@
 //
 // One kernel computes C[M,N] = A[M,K] * B[K,N] where every operand element is fetched
 // through a *separable* address map
-//     addr(row, k) = R(row) + F(k),   valid iff row < nrows, k < K and (optionally)
+//     addr(row, k) = R(row) + F(k),   valid iff row < nrows, k valid and (optionally)
 //                                     pos_r(row) + pos_k(k) in [0, lim)
-// with row -> (hi, lo) = divmod(row, rdiv) and k -> (hi, lo) = divmod(k, kdiv).
-// That single form covers, with zero-padding handled by the window test:
-//   conv1d forward        (A = weights, B = implicit im2col of x)
-//   conv1d backward-data  (polyphase over the stride: one dense GEMM per output phase)
-//   conv1d backward-weight(split-K over batch*length)
-//   linear NT / NN / TN   (plain strided matrices)
+// with row -> (hi, lo) = divmod(row, rdiv). The contraction index is the pair
+//     k = (hi, lo),  hi in [0, nhi),  lo in [0, kdiv),  F = hi * k_hi_stride + lo * k_lo_stride
+// SHARED by both operands and walked in 16-deep chunks that never straddle a `hi` boundary
+// (each hi owns ceil(kdiv / 16) chunks, the last one zero-filled past kdiv). Inside a chunk
+// `hi` is constant and `lo` is a run of 16, so the address of every element is
+//     (per-thread constant) + (per-chunk scalar) + (loop-invariant scalar),
+// i.e. one buffer load and no vector / scalar index arithmetic per element ("uniform" chunks);
+// only chunks that hold a lo tail, or whose window test varies with lo, take the general
+// path. Conv layers order K as (tap, channel): hi = tap, lo = channel, so the zero-padding
+// window depends on the chunk only. That form covers, with padding handled by the window test:
+//   conv1d forward        (A = weights packed (Cout, k, Cin), B = implicit im2col of x)
+//   conv1d backward-data  (polyphase over the stride: one dense GEMM per output phase,
+//                          A = weights packed (Cin, k, Cout))
+//   conv1d backward-weight(K = (sample, position), split-K)
+//   linear NT / NN / TN   (plain strided matrices: nhi = 1, kdiv = K)
 // which are exactly the contractions the reference executes through nn.Conv1d /
 // nn.Linear (phase3/archis/default.py:64-70,117-128,201-204,298-303,326-333) and their
 // first and second derivatives (losses.py:40-44).
 //
 // Layout in HBM is the reference's own: activations (B, C, L) row-major, weights
-// (Cout, Cin, k). Tiles are staged global -> registers -> LDS (double buffered, one
-// barrier per 16-deep K chunk); each of the 4 waves owns a (BM/WM) x (BN/WN) sub-tile
-// made of 32x32 MFMA accumulators.
+// (Cout, Cin, k) (+ the two packed weight images above, refreshed when the weights change).
+// Tiles are staged global -> registers -> LDS (double buffered, one barrier per 16-deep
+// K chunk); each of the 4 waves owns a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA accumulators.
 #pragma once
 #include "m2d_common.h"
 
@@ -30,18 +39,19 @@ struct M2dOperand {
   const float* base;
   const float* mask;  // optional, same addressing: value *= (mask > 0 ? 1 : mask_slope)
   float mask_slope;
-  unsigned nbytes;    // extent of `base` (and `mask`) in bytes, <= 0xFFFFFFF0: the staging loads are
-                      // raw buffer loads whose hardware range check returns 0 for padding / tails
+  unsigned nbytes;    // extent of `base` (and `mask`) in bytes, < 2^31: the staging loads are raw
+                      // buffer loads whose hardware range check returns 0 for padding / tails
   int nrows;
   int rdiv;
   float rdiv_inv;
   int r_hi_stride, r_lo_stride, r_off;
   int r_pos_mul, r_pos_off;
-  int kdiv;
-  float kdiv_inv;
-  int k_hi_stride, k_lo_stride;
-  int k_pos_mul;
-  int lim;  // <= 0: no window test
+  int k_hi_stride, k_lo_stride;  // element offset of k = (hi, lo); k_lo_stride >= 0
+  int k_pos_hi, k_pos_lo;        // window position of k = hi * k_pos_hi + lo * k_pos_lo
+  int lim;                       // <= 0: no window test
+  // [k_safe_lo, k_safe_hi): lo values whose window test passes for EVERY valid row and hi
+  // (whole range when lim <= 0 or k_pos_lo == 0: the test is then chunk-uniform or absent)
+  int k_safe_lo, k_safe_hi;
 };
 
 struct M2dOutMap {
@@ -63,7 +73,9 @@ struct M2dOutMap {
 struct M2dGemmParams {
   M2dOperand A, B;
   M2dOutMap O;
-  int M, N, K;
+  int M, N, K;          // K = nhi * kdiv (reported work); the kernel walks nhi * ceil(kdiv/16) chunks
+  int nhi, kdiv;
+  int lo_outer;        // chunk order: 0 = (hi, lo block), 1 = (lo block, hi)
   // conv backward-data mode (bwd_data != 0): the kernel derives, per output phase
   // r = blockIdx.z of the stride-`phases` lattice, the tap count, the K extent and the
   // q-range [qmin, qmax] of output positions j = phases*q + r - ph_pad inside [0, ph_L).
@@ -80,15 +92,17 @@ struct M2dGemmPlan {
   size_t ws_bytes;
 };
 
-M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split);
+static inline int m2d_chunks(int nhi, int kdiv) { return nhi * ((kdiv + M2D_BK - 1) / M2D_BK); }
+M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split);
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what);
 
 static inline unsigned m2d_extent_bytes(long long elements) {
   const long long b = elements * 4;
-  return b > 0xFFFFFFF0LL ? 0u : (unsigned)b;  // 0 = too large for buffer addressing (launch refuses)
+  return b >= 0x80000000LL ? 0u : (unsigned)b;  // 0 = too large for buffer addressing (launch refuses)
 }
 
+// plain strided matrix: element (row, k) at row * row_stride + k * k_stride (use with nhi = 1, kdiv = K)
 static inline void m2d_operand_plain(M2dOperand& o, const float* base, int nrows, int row_stride,
                                      int k_stride, long long elements) {
   memset(&o, 0, sizeof(o));
@@ -98,9 +112,9 @@ static inline void m2d_operand_plain(M2dOperand& o, const float* base, int nrows
   o.rdiv = 1;
   o.rdiv_inv = 1.f;
   o.r_hi_stride = row_stride;
-  o.kdiv = 1;
-  o.kdiv_inv = 1.f;
-  o.k_hi_stride = k_stride;
+  o.k_lo_stride = k_stride;
+  o.k_safe_lo = 0;
+  o.k_safe_hi = 0x7fffffff;
 }
 
 static inline void m2d_outmap_plain(M2dOutMap& o, float* out, int m_stride, int c_stride) {

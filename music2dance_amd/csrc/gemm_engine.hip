@@ -3,137 +3,119 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// n / d and n % d for 0 <= n < 2^24 (exact in fp32; the launcher rejects larger extents). Branch-free.
 __device__ __forceinline__ void m2d_divmod(int n, int d, float inv, int& q, int& r) {
-  if (d == 1) {
-    q = n;
-    r = 0;
-    return;
-  }
   q = (int)((float)n * inv);
   r = n - q * d;
-  if (r < 0) {
-    q -= 1;
-    r += d;
-  } else if (r >= d) {
-    q += 1;
-    r -= d;
-  }
+  const int adj = (r < 0 ? -1 : 0) + (r >= d ? 1 : 0);
+  q += adj;
+  r -= adj * d;
 }
 
-// Staging loads are raw buffer loads: an element that is padding, past the K tail or past the
+// Staging loads are raw buffer loads: an element that is padding, past a lo tail or past the
 // last row gets the byte offset M2D_OOB, which the hardware range check (num_records =
-// operand extent) turns into 0.0f. No select, no divergent branch, and nothing that forces
-// a wait on the load before the LDS store that consumes it.
-#define M2D_OOB 0xFFFFFFF0u
+// operand extent < 2^31) turns into 0.0f whatever scalar offset is added. No select on the
+// data, no divergent branch, nothing that forces a wait on the load before the LDS store.
+#define M2D_OOB 0x80000000u
+#define M2D_BAD 0x40000000
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t m2d_rsrc(const float* p, unsigned nbytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)nbytes, 0x00020000);
 }
 
-__device__ __forceinline__ float m2d_bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+// voff: per-lane byte offset (range-checked), soff: wave-uniform byte offset (SGPR)
+__device__ __forceinline__ float m2d_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }
 
-// Per-thread bookkeeping for one operand tile of BR rows x M2D_BK k-values.
-//   k-fast map  : thread owns ONE k (tid % BK) and NE rows (tid / BK + i * 256 / BK)
-//                 (operands whose K index is the contiguous one: weights, dy in bwd_weight)
-//   row-fast map: thread owns ONE row (tid % BR) and NE CONSECUTIVE k's starting at
-//                 (tid / BR) * NE: one divmod per chunk, the rest by stepping.
-// Validity is folded into ONE unsigned window test per element: pos_row + pos_k < lim_eff.
-// Rows past the extent get pos_row = M2D_BAD, k's past the tail get pos_k = M2D_BAD, operands
-// without a window use lim_eff = M2D_BAD - 1 with all positions 0. (Booleans combined with
-// && / ?: made hipcc materialise 0/1 integers: ~7 VALU per element instead of 4.)
-#define M2D_BAD 0x40000000
-
+// Per-thread bookkeeping for one operand tile of BR rows x M2D_BK k-slots of a chunk
+// (hi, lo0 .. lo0 + 15).
+//   k-fast map  : thread owns ONE k-slot (tid % BK) and NE rows (tid / BK + i * 256 / BK):
+//                 operands whose lo index is the contiguous one (packed weights, dy in
+//                 bwd_weight, plain row-major matrices). No window test (launcher enforces).
+//                 address = eoff[i] (row + slot, per thread) + S (chunk scalar, in soffset)
+//   row-fast map: thread owns ONE row (tid % BR) and NE consecutive k-slots from
+//                 kb = (tid / BR) * NE: address = eoff (row + kb) + S (chunk scalar, added on
+//                 the vector side so that S may be negative) + i * k_lo_stride (loop-invariant
+//                 scalar, in soffset for uniform chunks). The hardware range check covers the
+//                 vector offset only, so that part is always a real element's offset.
+// UNIFORM chunks (no lo tail, window independent of lo or known to pass): validity is one test
+// per thread per chunk. General chunks test every element.
 template <bool KF, int BR, bool MASKED>
 struct TileMap {
   static constexpr int NE = BR * M2D_BK / 256;
   static constexpr int NR = KF ? NE : 1;
   static constexpr int NM = MASKED ? NE : 1;
-  int off[NR];
-  int pos[NR];
+  unsigned eoff[NR];
+  int posr;  // row-fast: window position of the row incl. kb * k_pos_lo; M2D_BAD for rows past the extent
+  int kb;    // k-fast: the thread's slot; row-fast: its first slot
+  unsigned lim_eff;
   float v[NE];   // staged values
   float mv[NM];  // staged mask values (MASKED only)
-  int kbase, khi, klo;  // row-fast maps: k decomposition of the chunk's first element
-  int bk_div, bk_mod;   // M2D_BK = bk_div * kdiv + bk_mod
-  unsigned lim_eff;
 
   __device__ __forceinline__ void prep(const M2dOperand& op, int row0, int tid) {
     lim_eff = op.lim > 0 ? (unsigned)op.lim : (unsigned)(M2D_BAD - 1);
+    if constexpr (KF) {
+      kb = tid % M2D_BK;
+      posr = 0;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int rl = KF ? (tid / M2D_BK + i * (256 / M2D_BK)) : (tid % BR);
-      const int g = row0 + rl;
+      for (int i = 0; i < NE; ++i) {
+        const int g = row0 + tid / M2D_BK + i * (256 / M2D_BK);
+        const bool rv = g < op.nrows;
+        int hi, lo;
+        m2d_divmod(rv ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
+        const int off = hi * op.r_hi_stride + lo * op.r_lo_stride + op.r_off + kb * op.k_lo_stride;
+        eoff[i] = rv ? ((unsigned)off << 2) : M2D_OOB;
+      }
+    } else {
+      const int kb_t = (tid / BR) * NE;
+      kb = BR >= 64 ? __builtin_amdgcn_readfirstlane(kb_t) : kb_t;  // wave-uniform when a wave spans <= 1 k-group
+      const int g = row0 + tid % BR;
       const bool rv = g < op.nrows;
       int hi, lo;
       m2d_divmod(rv ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
-      off[i] = hi * op.r_hi_stride + lo * op.r_lo_stride + op.r_off;
-      pos[i] = rv ? (op.lim > 0 ? lo * op.r_pos_mul + op.r_pos_off : 0) : M2D_BAD;
+      const int off = hi * op.r_hi_stride + lo * op.r_lo_stride + op.r_off + kb * op.k_lo_stride;
+      eoff[0] = (unsigned)off << 2;
+      posr = rv ? (op.lim > 0 ? lo * op.r_pos_mul + op.r_pos_off + kb * op.k_pos_lo : 0) : M2D_BAD;
     }
   }
 
-  __device__ __forceinline__ void fetch(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs,
-                                        __amdgpu_buffer_rsrc_t rm, int i, int o, int p) {
-    const unsigned b = ((unsigned)p < lim_eff) ? ((unsigned)o << 2) : M2D_OOB;
-    v[i] = m2d_bload(rs, b);
-    if constexpr (MASKED) mv[i] = m2d_bload(rm, b);  // rm has 0 records when the operand has no mask
+  __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rm, int i, unsigned voff,
+                                        int soff) {
+    v[i] = m2d_bload(rs, voff, soff);
+    if constexpr (MASKED) mv[i] = m2d_bload(rm, voff, soff);  // rm has 0 records when the operand has no mask
   }
 
-  __device__ __forceinline__ void load(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs,
-                                       __amdgpu_buffer_rsrc_t rm, int k0, int kend, int tid) {
-    const int pmul = op.lim > 0 ? op.k_pos_mul : 0;
+  // stage chunk (hi, lo0) into registers
+  template <bool UNIFORM>
+  __device__ __forceinline__ void load(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rm,
+                                       int hi, int lo0, int kdiv) {
+    const int S = (hi * op.k_hi_stride + lo0 * op.k_lo_stride) << 2;  // wave-uniform
     if constexpr (KF) {
-      const int k = k0 + (tid % M2D_BK);
-      const bool kv = k < kend;
-      int hi, lo;
-      m2d_divmod(kv ? k : 0, op.kdiv, op.kdiv_inv, hi, lo);
-      const int koff = hi * op.k_hi_stride + lo * op.k_lo_stride;
-      const int kpos = kv ? lo * pmul : M2D_BAD;
+      if constexpr (UNIFORM) {
 #pragma unroll
-      for (int i = 0; i < NE; ++i) fetch(op, rs, rm, i, off[i] + koff, pos[i] + kpos);
-    } else {
-      // (tid / BR) is wave-uniform when BR >= 64 (a wave is 64 consecutive threads), so the
-      // whole k decomposition below lives in SGPRs / the scalar ALU and costs no VALU issue:
-      // per element the vector side only adds the offset, tests the window and selects OOB.
-      int k = k0 + kbase;
-      int lo = klo;
-      int koff = khi * op.k_hi_stride + klo * op.k_lo_stride;
-      int kpos = klo * pmul;
-      const int wrap_off = op.k_hi_stride - op.kdiv * op.k_lo_stride;
-      const int wrap_pos = op.kdiv * pmul;
+        for (int i = 0; i < NE; ++i) fetch(rs, rm, i, eoff[i], S);
+      } else {
+        const bool tv = lo0 + kb < kdiv;
 #pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        fetch(op, rs, rm, i, off[0] + koff, pos[0] + (k < kend ? kpos : M2D_BAD));
-        ++k;
-        ++lo;
-        koff += op.k_lo_stride;
-        kpos += pmul;
-        if (lo == op.kdiv) {
-          lo = 0;
-          koff += wrap_off;
-          kpos -= wrap_pos;
-        }
+        for (int i = 0; i < NE; ++i) fetch(rs, rm, i, tv ? eoff[i] : M2D_OOB, S);
       }
-      // advance the chunk-start state by BK (branch-free: BK = bk_div * kdiv + bk_mod)
-      klo += bk_mod;
-      khi += bk_div;
-      const bool carry = klo >= op.kdiv;
-      klo -= carry ? op.kdiv : 0;
-      khi += carry ? 1 : 0;
-    }
-  }
-
-  // row-fast maps: position the wave-uniform k state on the first chunk of this block
-  __device__ __forceinline__ void begin(const M2dOperand& op, int k0, int tid) {
-    if constexpr (!KF) {
-      const int kb = (tid / BR) * NE;
-      kbase = BR >= 64 ? __builtin_amdgcn_readfirstlane(kb) : kb;
-      m2d_divmod(k0 + kbase, op.kdiv, op.kdiv_inv, khi, klo);
-      bk_div = M2D_BK / op.kdiv;
-      bk_mod = M2D_BK - bk_div * op.kdiv;
-      if (BR >= 64) {
-        khi = __builtin_amdgcn_readfirstlane(khi);
-        klo = __builtin_amdgcn_readfirstlane(klo);
+    } else {
+      const int P = hi * op.k_pos_hi + lo0 * op.k_pos_lo;  // wave-uniform
+      const unsigned full = eoff[0] + (unsigned)S;
+      const int ls4 = op.k_lo_stride << 2;
+      if constexpr (UNIFORM) {
+        const unsigned voff = ((unsigned)(posr + P) < lim_eff) ? full : M2D_OOB;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) fetch(rs, rm, i, voff, i * ls4);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+          // the range check sees the vector offset only: it must be the element's own offset
+          // (the thread's first slot may be padding while slot i is not)
+          const int pp = (lo0 + kb + i < kdiv) ? P + i * op.k_pos_lo : M2D_BAD;
+          fetch(rs, rm, i, ((unsigned)(posr + pp) < lim_eff) ? full + (unsigned)(i * ls4) : M2D_OOB, 0);
+        }
       }
     }
   }
@@ -153,6 +135,46 @@ struct TileMap {
   }
 };
 
+// wave-uniform chunk cursor: chunk (hi, lo0); a chunk is UNIFORM when it holds no lo tail and
+// both operands' windows are lo-independent there. Conv layers walk lo blocks in the outer loop
+// (16 channels, then all their taps): the activation lines a tile touches for one channel block
+// stay in L1 across the taps.
+struct ChunkCursor {
+  int hi, lo0, kdiv, nhi;
+  int lo_outer;                // chunk order: 0 = hi outer / lo inner, 1 = lo block outer / hi inner
+  int a_lo, a_hi, b_lo, b_hi;  // safe lo ranges of the two operands
+  __device__ __forceinline__ void seek(int c, int cph) {
+    if (lo_outer) {
+      const int blk = c / nhi;
+      hi = c - blk * nhi;
+      lo0 = blk * M2D_BK;
+    } else {
+      hi = c / cph;
+      lo0 = (c - hi * cph) * M2D_BK;
+    }
+  }
+  __device__ __forceinline__ bool past() const { return lo_outer ? lo0 >= kdiv : hi >= nhi; }
+  __device__ __forceinline__ bool uniform() const {
+    return (!past()) & (lo0 + M2D_BK <= kdiv) & (lo0 >= a_lo) & (lo0 + M2D_BK <= a_hi) & (lo0 >= b_lo) &
+           (lo0 + M2D_BK <= b_hi);
+  }
+  // lo extent for the general path: 0 past the end (the chunk after the last one loads zeros)
+  __device__ __forceinline__ int extent() const { return past() ? 0 : kdiv; }
+  __device__ __forceinline__ void next() {
+    if (lo_outer) {
+      hi += 1;
+      const bool wrap = hi >= nhi;
+      hi = wrap ? 0 : hi;
+      lo0 += wrap ? M2D_BK : 0;
+    } else {
+      lo0 += M2D_BK;
+      const bool wrap = lo0 >= kdiv;
+      lo0 = wrap ? 0 : lo0;
+      hi += wrap ? 1 : 0;
+    }
+  }
+};
+
 __device__ __forceinline__ float m2d_epilogue(const M2dOutMap& o, float v, int row, int col, int addr) {
   if (o.bias_mode == 1) v += o.bias[row];
   else if (o.bias_mode == 2) v += o.bias[col];
@@ -161,6 +183,49 @@ __device__ __forceinline__ float m2d_epilogue(const M2dOutMap& o, float v, int r
   if (o.residual) v += o.residual[addr];
   if (o.mask) v *= (o.mask[addr] > 0.f ? 1.f : o.mask_slope);
   return v;
+}
+
+// Multiply chunk `cur` out of LDS and write the staged registers (next chunk, loads issued by
+// the caller) into the other buffer.
+template <int BM, int BN, bool AKF, bool BKF, bool MASKED>
+__device__ __forceinline__ void m2d_chunk_mma(const TileMap<AKF, BM, MASKED>& ta, const TileMap<BKF, BN, MASKED>& tb,
+                                              const M2dOperand& A, const M2dOperand& B, float* smem, int cur,
+                                              int tid, int wm, int wn, int l31, int lh,
+                                              f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
+  constexpr int LDA = BM + M2D_LDPAD;
+  constexpr int LDB = BN + M2D_LDPAD;
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  constexpr int STAGE = M2D_BK * (LDA + LDB);
+  const float* as = smem + cur * STAGE + wm * (TM * 32) + l31;
+  const float* bs = smem + cur * STAGE + M2D_BK * LDA + wn * (TN * 32) + l31;
+  float fa[M2D_BK / 2][TM], fb[M2D_BK / 2][TN];
+#pragma unroll
+  for (int kk = 0; kk < M2D_BK / 2; ++kk) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[kk][i] = as[(2 * kk + lh) * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[kk][j] = bs[(2 * kk + lh) * LDB + j * 32];
+  }
+#pragma unroll
+  for (int kk = 0; kk < M2D_BK / 2; ++kk)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+  float* nxt = smem + (cur ^ 1) * STAGE;
+  ta.template store<LDA>(A, nxt, tid);
+  tb.template store<LDB>(B, nxt + M2D_BK * LDA, tid);
+  // software pipeline: the fragments of k-step kk+2 are read under the MFMAs of k-step kk
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+  for (int kk = 0; kk < M2D_BK / 2; ++kk) {
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+    if (kk < M2D_BK / 2 - 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  }
 }
 
 template <int BM, int BN, bool AKF, bool BKF, bool MASKED>
@@ -185,12 +250,13 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   M2dOperand A = p.A;
   M2dOperand B = p.B;
   M2dOutMap O = p.O;
-  int K = p.K;
   int N = p.N;
+  int nhi = p.nhi;
   int split = blockIdx.z;
   if (p.bwd_data) {
     // conv backward-data: output phase r of the stride-s lattice uses taps r, r+s, ...
-    //   dx[n, ci, s*q + r - pad] = sum_{co, t} W[co, ci, r + s*t] * dy[n, co, q - t]
+    //   dx[n, ci, s*q + r - pad] = sum_{t, co} Wp[ci, r + s*t, co] * dy[n, co, q - t]
+    // (K = (t, co): hi = t, lo = co; the host filled the strides for that order)
     const int r = blockIdx.z;
     const int s = p.phases;
     split = 0;
@@ -201,13 +267,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
     if (nq <= 0) return;
     N = p.ph_batch * nq;
     if ((int)(blockIdx.x * BN) >= N) return;
-    K = p.ph_cout * taps;
-    const int d = taps > 0 ? taps : 1;
-    A.r_off += r;
-    A.kdiv = d;
-    A.kdiv_inv = 1.f / (float)d;
-    B.kdiv = d;
-    B.kdiv_inv = A.kdiv_inv;
+    nhi = taps;
+    A.r_off += r * p.ph_cout;
     B.nrows = N;
     B.rdiv = nq;
     B.rdiv_inv = 1.f / (float)nq;
@@ -243,59 +304,43 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nchunks = (K + M2D_BK - 1) / M2D_BK;
+  const int cph = (p.kdiv + M2D_BK - 1) / M2D_BK;  // chunks per hi
+  const int nchunks = nhi * cph;
   const int cps = (nchunks + p.splits - 1) / p.splits;
   const int c0 = split * cps;
   const int c1 = (c0 + cps < nchunks) ? (c0 + cps) : nchunks;
 
   if (c0 < c1) {
-    ta.begin(A, c0 * M2D_BK, tid);
-    tb.begin(B, c0 * M2D_BK, tid);
-    ta.load(A, ra, rma, c0 * M2D_BK, K, tid);
-    tb.load(B, rb, rmb, c0 * M2D_BK, K, tid);
+    ChunkCursor cc;
+    cc.kdiv = p.kdiv;
+    cc.nhi = nhi;
+    cc.lo_outer = p.lo_outer;
+    cc.seek(c0, cph);
+    cc.a_lo = A.k_safe_lo; cc.a_hi = A.k_safe_hi;
+    cc.b_lo = B.k_safe_lo; cc.b_hi = B.k_safe_hi;
+    // chunk c0 through the general path (once per block)
+    ta.template load<false>(A, ra, rma, cc.hi, cc.lo0, cc.extent());
+    tb.template load<false>(B, rb, rmb, cc.hi, cc.lo0, cc.extent());
     ta.template store<LDA>(A, smem, tid);
     tb.template store<LDB>(B, smem + M2D_BK * LDA, tid);
+    cc.next();
     __syncthreads();
     for (int c = c0; c < c1; ++c) {
       const int cur = (c - c0) & 1;
-      // The loop body is ONE basic block (no `if (more)`: the loads of the chunk after the
-      // last one are all past kend, i.e. OOB -> zeros, and their LDS store is harmless), so
-      // the scheduler may interleave the next chunk's address math + buffer loads with this
-      // chunk's MFMAs; the sched_group_barrier sequence below pins that interleave.
-      ta.load(A, ra, rma, (c + 1) * M2D_BK, K, tid);
-      tb.load(B, rb, rmb, (c + 1) * M2D_BK, K, tid);
-      const float* as = smem + cur * STAGE + wm * (TM * 32) + l31;
-      const float* bs = smem + cur * STAGE + M2D_BK * LDA + wn * (TN * 32) + l31;
-      float fa[M2D_BK / 2][TM], fb[M2D_BK / 2][TN];
-#pragma unroll
-      for (int kk = 0; kk < M2D_BK / 2; ++kk) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[kk][i] = as[(2 * kk + lh) * LDA + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[kk][j] = bs[(2 * kk + lh) * LDB + j * 32];
+      // Stage chunk c + 1 (cursor cc) while chunk c is multiplied: its buffer loads are issued
+      // first (a uniform chunk costs one load per element and a handful of address
+      // instructions per chunk, so the burst is short), the MFMAs of chunk c run while they are
+      // in flight. The chunk after the last one either belongs to the next split (real data) or
+      // has hi == nhi and loads zeros through the general path; its LDS store is harmless.
+      if (cc.uniform()) {
+        ta.template load<true>(A, ra, rma, cc.hi, cc.lo0, cc.kdiv);
+        tb.template load<true>(B, rb, rmb, cc.hi, cc.lo0, cc.kdiv);
+      } else {
+        ta.template load<false>(A, ra, rma, cc.hi, cc.lo0, cc.extent());
+        tb.template load<false>(B, rb, rmb, cc.hi, cc.lo0, cc.extent());
       }
-#pragma unroll
-      for (int kk = 0; kk < M2D_BK / 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-      float* nxt = smem + (cur ^ 1) * STAGE;
-      ta.template store<LDA>(A, nxt, tid);
-      tb.template store<LDB>(B, nxt + M2D_BK * LDA, tid);
-      // software pipeline: fragments of k-step kk+2 and 1/8 of the next chunk's staging
-      // loads are issued under the MFMAs of k-step kk
-      constexpr int NLD = (TileMap<AKF, BM, MASKED>::NE + TileMap<BKF, BN, MASKED>::NE) * (MASKED ? 2 : 1);
-      constexpr int LPK = (NLD + 3) / 4;  // all loads issued under the first 4 k-steps: the
-                                          // remaining MFMAs cover their latency
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-      for (int kk = 0; kk < M2D_BK / 2; ++kk) {
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-        if (kk < M2D_BK / 2 - 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        if (kk < 4) __builtin_amdgcn_sched_group_barrier(0x020, LPK, 0);
-      }
+      m2d_chunk_mma<BM, BN, AKF, BKF, MASKED>(ta, tb, A, B, smem, cur, tid, wm, wn, l31, lh, acc);
+      cc.next();
       __syncthreads();
     }
   }
@@ -348,7 +393,7 @@ __global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmPar
   }
 }
 
-M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split) {
+M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split) {
   M2dGemmPlan pl;
   // 1) the M tile that wastes the fewest padded rows; small tiles carry a penalty because
   //    their waves re-read the B tile more often per flop.
@@ -369,7 +414,6 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split) {
   //    >= 8 chunks per split.
   const long long nt = m2d_ceil_div(N, 128);
   const int ph = phases > 1 ? phases : 1;
-  const int nchunks = m2d_ceil_div(K, M2D_BK);
   const bool can_split = allow_split && phases <= 1;
   pl.splits = 1;
   pl.ws_bytes = 0;
@@ -391,6 +435,16 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int K, int phases, bool allow_split) {
     if (s > 128) s = 128;
     if (s > 1) pl.splits = (int)s;
   }
+#ifdef M2D_TUNING
+  if (const char* e = getenv("M2D_PLAN")) {  // "bm,splits" (tuning builds only)
+    int bm = 0, sp = 0;
+    if (sscanf(e, "%d,%d", &bm, &sp) == 2) {
+      if (bm == 32 || bm == 64 || bm == 128) pl.bm = bm;
+      if (sp >= 1 && can_split && sp <= nchunks) pl.splits = sp;
+      if (sp == 1) pl.splits = 1;
+    }
+  }
+#endif
   if (pl.splits > 1) pl.ws_bytes = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
   return pl;
 }
@@ -416,9 +470,17 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
                     size_t ws_bytes, hipStream_t stream, const char* what) {
   if (p.M <= 0 || p.N <= 0) return M2D_OK;
   if (p.A.nbytes == 0 || p.B.nbytes == 0)
-    M2D_FAIL(M2D_ERR_RANGE, "%s: operand larger than 4 GiB (buffer addressing) or empty", what);
+    M2D_FAIL(M2D_ERR_RANGE, "%s: operand larger than 2 GiB (buffer addressing) or empty", what);
+  if (p.M >= (1 << 24) || p.N >= (1 << 24))
+    M2D_FAIL(M2D_ERR_RANGE, "%s: extent >= 2^24 (row decomposition is exact below that)", what);
+  if (p.kdiv <= 0 || p.nhi < 0 || p.A.k_lo_stride < 0 || p.B.k_lo_stride < 0)
+    M2D_FAIL(M2D_ERR_ARG, "%s: bad contraction map (kdiv=%d nhi=%d)", what, p.kdiv, p.nhi);
+  if ((a_kfast && p.A.lim > 0) || (b_kfast && p.B.lim > 0))
+    M2D_FAIL(M2D_ERR_ARG, "%s: k-fast operands carry no window", what);
   if (p.phases < 1) p.phases = 1;
-  const M2dGemmPlan pl = m2d_gemm_plan(p.M, p.N, p.K, p.bwd_data ? 2 : 1, allow_split);
+  // bwd_data: the widest phase has ceil(ks / phases) taps
+  const int nhi_max = p.bwd_data ? (p.ph_ks + p.phases - 1) / p.phases : p.nhi;
+  const M2dGemmPlan pl = m2d_gemm_plan(p.M, p.N, m2d_chunks(nhi_max, p.kdiv), p.bwd_data ? 2 : 1, allow_split);
   p.splits = pl.splits;
   p.slab = nullptr;
   if (pl.splits > 1) {

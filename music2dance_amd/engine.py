@@ -12,7 +12,7 @@ throws away.
 import torch
 import torch.optim as optim
 
-from . import ops
+from . import kernels, ops
 from .dp import GradExchange
 from .losses import gradient_penalty, tv_loss
 
@@ -59,6 +59,7 @@ class WganGpEngine:
             if self.x_critic is not None:
                 self.x_critic.finish()
             self.optim_critic.step()
+            kernels.impl().invalidate_packed()
             self._critic_step_pending = False
 
     def _begin_critic_step(self):
@@ -67,11 +68,13 @@ class WganGpEngine:
             self._critic_step_pending = True
         else:
             self.optim_critic.step()
+            kernels.impl().invalidate_packed()
 
     def _gen_step(self):
         if self.x_gen is not None:
             self.x_gen.exchange()
         self.optim_gen.step()
+        kernels.impl().invalidate_packed()
 
     def flush(self):
         self._finish_critic_step()
@@ -80,9 +83,11 @@ class WganGpEngine:
         """One loop body of the reference: a critic iteration, plus a generator iteration every
         n_critic_steps-th call. Returns a dict of 0-dim device tensors (no host sync)."""
         self.total_iterations += 1
-        out = self.critic_iteration(*batch)
-        if self.total_iterations % self.n_critic_steps == 0:
-            out.update(self.generator_iteration(*batch))
+        # weights only change in the optimizer steps, which drop the packed conv-weight images
+        with kernels.impl().weight_cache():
+            out = self.critic_iteration(*batch)
+            if self.total_iterations % self.n_critic_steps == 0:
+                out.update(self.generator_iteration(*batch))
         self.last = out
         return out
 

@@ -5,7 +5,9 @@ caching allocator, so the calls are hipGraph-capture safe) and the current HIP s
 Every method enqueues hand-written gfx950 kernels and nothing else; inputs must be
 contiguous fp32 tensors on a HIP device, otherwise the call raises (no fallback).
 """
+import contextlib
 import ctypes
+import weakref
 
 import torch
 
@@ -56,6 +58,59 @@ class HipKernels:
     name = "hip"
 
     # ---------------------------------------------------------------- conv1d
+    def __init__(self):
+        # packed weight images (include/m2d.h: m2d_conv1d_pack_weights) of live weight tensors; only
+        # kept inside a weight_cache() scope, i.e. while the caller guarantees the weights are constant
+        self._packed = {}
+        self._cache_depth = 0
+        self.pack_launches = 0
+
+    @contextlib.contextmanager
+    def weight_cache(self):
+        """Scope in which conv weights are promised constant except where invalidate_packed() is
+        called (right after an optimizer step): the packed images the forward / backward-data
+        GEMMs read are built once per weight tensor instead of once per call. Outside a scope every
+        call packs afresh - a tensor's version counter is no proof of constancy (fused optimizers
+        update parameters without moving it)."""
+        self._cache_depth += 1
+        try:
+            yield self
+        finally:
+            self._cache_depth -= 1
+            if self._cache_depth == 0:
+                self._packed.clear()
+
+    def invalidate_packed(self):
+        self._packed.clear()
+
+    def packed_weights(self, w):
+        """(w_fwd (Cout, ks, Cin), w_bwd (Cin, ks, Cout)) of a conv weight (written on the current stream)."""
+        stream = _stream(w.device)
+        key = id(w)
+        if self._cache_depth > 0:
+            ent = self._packed.get(key)
+            if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == stream:
+                return ent[3], ent[4]
+        Cout, Cin, ks = w.shape
+        wf = torch.empty((Cout, ks, Cin), dtype=torch.float32, device=w.device)
+        wb = torch.empty((Cin, ks, Cout), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            rc = _lib.lib().m2d_conv1d_pack_weights(_ptr(w), _ptr(wf), _ptr(wb), Cout, Cin, ks, stream)
+        _lib.check(rc, "m2d_conv1d_pack_weights")
+        self.pack_launches += 1
+        if self._cache_depth > 0:
+            packed = self._packed
+
+            def _drop(_ref, key=key):
+                packed.pop(key, None)
+
+            packed[key] = (weakref.ref(w, _drop), w._version, stream, wf, wb)
+        return wf, wb
+
+    @staticmethod
+    def _thin(Cin, ks, stride):
+        return Cin == 1 and ks == 25 and stride == 4
+
     def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
                    out_mask_slope=0.0):
         dev = _chk(x, w, bias, residual, out_mask)
@@ -65,10 +120,12 @@ class HipKernels:
         Lout = conv_out_len(L, ks, stride, pad)
         y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=dev)
         h = _lib.lib()
+        full_length = Lout == 1 and pad == 0 and L == ks
+        wp = self.packed_weights(w)[0] if (Cin >= 16 and not full_length) else None
         ws = _ws(h.m2d_conv1d_workspace_bytes(0, B, Cin, L, Cout, ks, stride, pad), dev)
         with torch.cuda.device(dev):
-            rc = h.m2d_conv1d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, Cin, L, Cout, ks, stride, pad, act,
-                                  slope, _ptr(residual), _ptr(out_mask), out_mask_slope, _ptr(ws),
+            rc = h.m2d_conv1d_fwd(_ptr(x), _ptr(w), _ptr(wp), _ptr(bias), _ptr(y), B, Cin, L, Cout, ks, stride, pad,
+                                  act, slope, _ptr(residual), _ptr(out_mask), out_mask_slope, _ptr(ws),
                                   0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_conv1d_fwd")
         return y
@@ -80,9 +137,11 @@ class HipKernels:
         assert Cout == Cout2 and Lout == conv_out_len(L, ks, stride, pad)
         dx = torch.empty((B, Cin, L), dtype=torch.float32, device=dev)
         h = _lib.lib()
+        full_length = Lout == 1 and pad == 0 and L == ks
+        wp = None if (full_length or self._thin(Cin, ks, stride)) else self.packed_weights(w)[1]
         ws = _ws(h.m2d_conv1d_workspace_bytes(1, B, Cin, L, Cout, ks, stride, pad), dev)
         with torch.cuda.device(dev):
-            rc = h.m2d_conv1d_bwd_data(_ptr(dy), _ptr(w), _ptr(dx), B, Cin, L, Cout, ks, stride, pad,
+            rc = h.m2d_conv1d_bwd_data(_ptr(dy), _ptr(w), _ptr(wp), _ptr(dx), B, Cin, L, Cout, ks, stride, pad,
                                        _ptr(dy_mask), dy_mask_slope, _ptr(ws),
                                        0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_conv1d_bwd_data")

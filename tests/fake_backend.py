@@ -7,6 +7,8 @@ in a container without a GPU. It is installed explicitly by tests through
 Each method restates the contract of the corresponding C-ABI entry point (include/m2d.h)
 with plain torch ops.
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -25,6 +27,13 @@ def _act(y, act, slope):
 
 class FakeKernels:
     name = "fake-cpu"
+
+    @contextlib.contextmanager
+    def weight_cache(self):
+        yield self
+
+    def invalidate_packed(self):
+        pass
 
     def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
                    out_mask_slope=0.0):
