@@ -36,6 +36,7 @@ int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L
 // chunk-uniform. Narrow inputs (the encoders' first layer, Cin = 1, k = 250) keep the
 // natural order (channel, tap) over w itself.
 static inline bool conv_uses_packed(int Cin) { return Cin >= M2D_BK; }
+static inline float fwd_tile_penalty(int stride) { return stride > 1 ? 1.25f : 1.f; }
 
 static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, const float* wp, float* y, int B, int Cin,
                      int L, int Cout, int ks, int stride, int pad, int Lout) {
@@ -61,6 +62,7 @@ static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, const flo
     p.nhi = ks;
     p.kdiv = Cin;
     p.lo_outer = 1;
+    p.small_tile_penalty = fwd_tile_penalty(stride);
     // A(m = co, k = (kk,ci)) = wp[co*ks*Cin + kk*Cin + ci]
     m2d_operand_plain(p.A, wp, Cout, Cin * ks, 1, (long long)Cout * Cin * ks);
     p.A.k_hi_stride = Cin;
@@ -397,7 +399,8 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
     if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(Cout, B, m2d_chunks(1, Cin * ks), 1, true).ws_bytes;
     const bool packed = conv_uses_packed(Cin);
     const int nch = packed ? m2d_chunks(ks, Cin) : m2d_chunks(Cin, ks);
-    return m2d_gemm_plan(Cout, B * Lout, nch, 1, true).ws_bytes + (packed ? pack_bytes(Cout, Cin, ks) : 0);
+    return m2d_gemm_plan(Cout, B * Lout, nch, 1, true, packed ? fwd_tile_penalty(stride) : 1.f).ws_bytes +
+           (packed ? pack_bytes(Cout, Cin, ks) : 0);
   }
   if (which == 1) {
     if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(B, Cin * ks, m2d_chunks(1, Cout), 1, true).ws_bytes;

@@ -76,6 +76,7 @@ struct M2dGemmParams {
   int M, N, K;          // K = nhi * kdiv (reported work); the kernel walks nhi * ceil(kdiv/16) chunks
   int nhi, kdiv;
   int lo_outer;        // chunk order: 0 = (hi, lo block), 1 = (lo block, hi)
+  float small_tile_penalty;  // launch-plan hint (see m2d_gemm_plan); 0 = none
   // conv backward-data mode (bwd_data != 0): the kernel derives, per output phase
   // r = blockIdx.z of the stride-`phases` lattice, the tap count, the K extent and the
   // q-range [qmin, qmax] of output positions j = phases*q + r - ph_pad inside [0, ph_L).
@@ -93,7 +94,7 @@ struct M2dGemmPlan {
 };
 
 static inline int m2d_chunks(int nhi, int kdiv) { return nhi * ((kdiv + M2D_BK - 1) / M2D_BK); }
-M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split);
+M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty = 1.0);
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what);
 

@@ -393,48 +393,60 @@ __global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmPar
   }
 }
 
-M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split) {
+// Launch plan from a small cost model (microseconds, fitted to MI355X measurements of the
+// phase-3 layer shapes): 256 CUs, every CU works through its share of blocks; a block spends
+// tc(BM) per 16-deep chunk when the CU's matrix pipes are kept busy by other resident blocks and
+// more when it is alone (the load -> LDS -> MFMA chain of one block is then exposed). Split-K
+// costs one slab round trip through HBM plus a second launch. Block counts just above a multiple
+// of 256 leave most CUs idle for the last round, which is why the candidate split factors are
+// the ones that land ON a multiple.
+M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty) {
   M2dGemmPlan pl;
-  // 1) the M tile that wastes the fewest padded rows; small tiles carry a penalty because
-  //    their waves re-read the B tile more often per flop.
-  const int cands[3] = {32, 64, 128};
-  const double pen[3] = {1.4, 1.1, 1.0};
-  double best = 1e30;
-  pl.bm = 128;
-  for (int i = 0; i < 3; ++i) {
-    const double cost = (double)m2d_ceil_div(M, cands[i]) * cands[i] * pen[i];
-    if (cost < best - 1e-9 || (cost <= best + 1e-9 && cands[i] > pl.bm)) {
-      best = cost;
-      pl.bm = cands[i];
-    }
-  }
-  // 2) fill the chip (256 CUs x 2-4 resident blocks): split K first while every split keeps
-  //    >= 32 chunks (cheap: one slab pass), then trade tile height for block count (short-K
-  //    problems such as the TCN critic's N = B*T = 7680 columns), then split again down to
-  //    >= 8 chunks per split.
-  const long long nt = m2d_ceil_div(N, 128);
   const int ph = phases > 1 ? phases : 1;
   const bool can_split = allow_split && phases <= 1;
+  const long long nt = m2d_ceil_div(N, 128);
+  const int bms[3] = {128, 64, 32};
+  // us per block-chunk with the matrix pipes busy; `small_tile_penalty` (>= 1) prices operands whose
+  // gather is expensive per load (strided conv inputs: 16 B between lanes), which small M tiles re-load more often
+  const double pen = small_tile_penalty > 1.0 ? small_tile_penalty : 1.0;
+  const double tc[3] = {0.98, 0.56 * pen, 0.33 * pen};
+  const int resident[3] = {3, 5, 7};         // blocks per CU (VGPR / LDS budget)
+  double best = 1e30;
+  pl.bm = 128;
   pl.splits = 1;
+  for (int b = 0; b < 3; ++b) {
+    const long long tiles = (long long)m2d_ceil_div(M, bms[b]) * nt * ph;
+    long long cand[10];
+    int nc = 0;
+    cand[nc++] = 1;
+    if (can_split && nchunks >= 8) {
+      for (int k = 1; k <= 8; ++k) {
+        long long sp = (256LL * k) / tiles;
+        if (sp > 128) sp = 128;
+        if (sp > nchunks / 4) sp = nchunks / 4;
+        if (sp > 1) cand[nc++] = sp;
+      }
+    }
+    for (int c = 0; c < nc; ++c) {
+      const long long sp = cand[c];
+      // a CU holding per_cu blocks, `conc` of them resident at a time: throughput bound
+      // per_cu * tc per chunk step, latency bound (one block's load -> LDS -> MFMA chain is
+      // ~0.55 us longer than its matrix time) ceil(per_cu / conc) * (tc + 0.55)
+      const long long per_cu = m2d_ceil_div64(tiles * sp, 256);
+      const long long conc = per_cu < resident[b] ? per_cu : resident[b];
+      const double cps = (double)m2d_ceil_div64(nchunks > 0 ? nchunks : 1, sp);
+      const double thr = (double)per_cu * tc[b];
+      const double lat = (double)m2d_ceil_div64(per_cu, conc) * (tc[b] + 0.55);
+      double cost = 8.0 + cps * (thr > lat ? thr : lat);
+      if (sp > 1) cost += 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
+      if (cost < best) {
+        best = cost;
+        pl.bm = bms[b];
+        pl.splits = (int)sp;
+      }
+    }
+  }
   pl.ws_bytes = 0;
-  long long blocks = (long long)m2d_ceil_div(M, pl.bm) * nt * ph;
-  if (can_split && blocks < 384 && nchunks >= 64) {
-    long long s = m2d_ceil_div64(512, blocks);
-    if (s > nchunks / 32) s = nchunks / 32;
-    if (s > 128) s = 128;
-    if (s > 1) pl.splits = (int)s;
-  }
-  while (pl.bm > 32 && blocks * pl.splits < 384 &&
-         (long long)m2d_ceil_div(M, pl.bm / 2) * nt * ph * pl.splits <= 1024) {
-    pl.bm /= 2;
-    blocks = (long long)m2d_ceil_div(M, pl.bm) * nt * ph;
-  }
-  if (can_split && pl.splits == 1 && blocks < 384 && nchunks >= 16) {
-    long long s = m2d_ceil_div64(512, blocks);
-    if (s > nchunks / 8) s = nchunks / 8;
-    if (s > 128) s = 128;
-    if (s > 1) pl.splits = (int)s;
-  }
 #ifdef M2D_TUNING
   if (const char* e = getenv("M2D_PLAN")) {  // "bm,splits" (tuning builds only)
     int bm = 0, sp = 0;
@@ -480,7 +492,8 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
   if (p.phases < 1) p.phases = 1;
   // bwd_data: the widest phase has ceil(ks / phases) taps
   const int nhi_max = p.bwd_data ? (p.ph_ks + p.phases - 1) / p.phases : p.nhi;
-  const M2dGemmPlan pl = m2d_gemm_plan(p.M, p.N, m2d_chunks(nhi_max, p.kdiv), p.bwd_data ? 2 : 1, allow_split);
+  const M2dGemmPlan pl = m2d_gemm_plan(p.M, p.N, m2d_chunks(nhi_max, p.kdiv), p.bwd_data ? p.phases : 1, allow_split,
+                                      p.small_tile_penalty);
   p.splits = pl.splits;
   p.slab = nullptr;
   if (pl.splits > 1) {

@@ -1,4 +1,4 @@
-"""Dev tool: time one conv shape under forced (bm, splits) plans. Needs a -DM2D_TUNING build."""
+"""Dev tool: time conv shapes under forced (bm, splits) plans. Needs a -DM2D_TUNING build."""
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,7 +6,7 @@ from music2dance_amd import kernels
 K = kernels.impl()
 dev = "cuda:0"
 
-def timeit(fn, iters=20):
+def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize()
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record()
@@ -14,22 +14,31 @@ def timeit(fn, iters=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
 
+B = 64
+N = B * 120
 CASES = [("temporal.k7 B64", 64, 128, 120, 128, 7, 1, 3), ("temporal.k7 B128", 128, 128, 120, 128, 7, 1, 3),
-         ("stick.conv1 B64", 64, 69, 120, 128, 25, 1, 12), ("audio_d.l5", 64, 256, 300, 512, 25, 4, 11),
-         ("audio_d.l2", 64, 32, 19200, 64, 25, 4, 11)]
-PLANS = [None, (128, 1), (64, 1), (32, 1), (32, 2), (32, 3), (32, 4), (64, 2), (64, 3), (64, 4), (128, 2), (128, 4), (128, 7)]
+         ("stick.conv1 B64", 64, 69, 120, 128, 25, 1, 12),
+         ("audio_d.l2", B, 32, 19200, 64, 25, 4, 11), ("audio_d.l3", B, 64, 4800, 128, 25, 4, 11),
+         ("audio_d.l4", B, 128, 1200, 256, 25, 4, 11), ("audio_d.l5", B, 256, 300, 512, 25, 4, 11),
+         ("enc.c1", N, 32, 64, 64, 4, 2, 1), ("enc.c2", N, 64, 32, 128, 4, 2, 1), ("enc.c3", N, 128, 16, 256, 4, 2, 1),
+         ("enc.c5", N, 512, 4, 1024, 4, 2, 1), ("enc.c6", N, 1024, 2, 250, 2, 1, 0)]
+PLANS = [None, (128, 1), (64, 1), (32, 1), (128, 2), (64, 2), (32, 2), (128, 4), (64, 4), (32, 4), (128, 8), (64, 8), (128, 16), (64, 16), (128, 32), (64, 32), (128, 64), (64, 64)]
+only = os.environ.get("CASE")
 for name, b, cin, L, cout, ks, s, p in CASES:
+    if only and only not in name: continue
     x = torch.randn(b, cin, L, device=dev); w = torch.randn(cout, cin, ks, device=dev) / math.sqrt(cin * ks)
     bias = torch.randn(cout, device=dev); Lout = (L + 2 * p - ks) // s + 1
     dy = torch.randn(b, cout, Lout, device=dev); gf = 2.0 * b * Lout * cout * cin * ks / 1e9
     print("==", name, "GF %.2f" % gf)
-    for pl in PLANS:
-        if pl is None: os.environ.pop("M2D_PLAN", None)
-        else: os.environ["M2D_PLAN"] = "%d,%d" % pl
-        t1 = timeit(lambda: K.conv1d_fwd(x, w, bias, s, p, act=1))
-        t2 = timeit(lambda: K.conv1d_bwd_data(dy, w, L, s, p))
-        t3 = 0.0
-        if pl is None or pl[1] > 1 or name.startswith("temporal") and False:
-            t3 = timeit(lambda: K.conv1d_bwd_weight(x, dy, ks, s, p))
-        print("%-10s fwd %7.1f us %5.1f TF | bwdD %7.1f us %5.1f TF | bwdW %7.1f us %5.1f TF" % (
-            pl, 1e3 * t1, gf / t1, 1e3 * t2, gf / t2, 1e3 * t3, gf / t3 if t3 else 0), flush=True)
+    res = {0: [], 1: [], 2: []}
+    with K.weight_cache():
+        for pl in PLANS:
+            if pl is None: os.environ.pop("M2D_PLAN", None)
+            else: os.environ["M2D_PLAN"] = "%d,%d" % pl
+            t = [timeit(lambda: K.conv1d_fwd(x, w, bias, s, p, act=1)), timeit(lambda: K.conv1d_bwd_data(dy, w, L, s, p)),
+                 timeit(lambda: K.conv1d_bwd_weight(x, dy, ks, s, p))]
+            for i in range(3): res[i].append((t[i], pl))
+    for i, nm in enumerate(("fwd", "bwdD", "bwdW")):
+        auto = res[i][0][0]
+        best = sorted(res[i][1:])[:4]
+        print("  %-5s auto %7.1f us %5.1f TF | best " % (nm, 1e3 * auto, gf / auto) + "  ".join("%s %.1f us %.1f TF" % (pl, 1e3 * t, gf / t) for t, pl in best), flush=True)
