@@ -14,6 +14,7 @@ import torch.optim as optim
 
 from . import kernels, ops
 from .dp import GradExchange
+from .layers import to_device_async
 from .losses import gradient_penalty, tv_loss
 
 
@@ -196,7 +197,7 @@ class Phase2Engine(WganGpEngine):
 
     def _noise(self, B, T, device):
         if self.host_noise:
-            return torch.randn(B, T, self.input_size).to(device)
+            return to_device_async(torch.randn(B, T, self.input_size), device)
         return torch.randn(B, T, self.input_size, device=device)
 
     def critic_iteration(self, real):
@@ -250,7 +251,7 @@ class Phase1Engine(WganGpEngine):
 
     def _noise(self, B, device):
         if self.host_noise:
-            return torch.randn(B, self.latent).to(device)
+            return to_device_async(torch.randn(B, self.latent), device)
         return torch.randn(B, self.latent, device=device)
 
     def critic_iteration(self, real):

@@ -11,6 +11,32 @@ import torch.nn as nn
 from . import ops
 
 
+
+_COPY_STREAMS = {}
+
+
+def to_device_async(t, device):
+    """Move a HOST tensor (random draws from the host generator, as the reference makes them)
+    to `device` without draining the compute stream. A copy from pageable memory blocks the
+    host until everything queued before it on ITS stream has run; issued on the current stream
+    that is a full host<->device sync per draw (the host then has to refill an empty queue).
+    Here it runs on a dedicated copy stream - the host only waits for the copy itself - and the
+    current stream picks the result up through an event."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t.to(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cs = _COPY_STREAMS.get(idx)
+    if cs is None:
+        cs = _COPY_STREAMS[idx] = torch.cuda.Stream(device=device)
+    cur = torch.cuda.current_stream(device)
+    with torch.cuda.stream(cs):
+        out = t.to(device)
+    cur.wait_stream(cs)
+    out.record_stream(cur)
+    return out
+
+
 class Conv1d(nn.Conv1d):
     """nn.Conv1d (dilation 1, groups 1, zero padding) on the implicit-GEMM engine."""
 
@@ -91,7 +117,7 @@ class Dropout(nn.Dropout):
         if not self.training or self.p == 0.0:
             return x
         if self.host_rng:
-            keep = torch.empty(x.shape, dtype=x.dtype).bernoulli_(1.0 - self.p).to(x.device)
+            keep = to_device_async(torch.empty(x.shape, dtype=x.dtype).bernoulli_(1.0 - self.p), x.device)
         else:
             keep = torch.empty_like(x).bernoulli_(1.0 - self.p)
         return x * keep * (1.0 / (1.0 - self.p))

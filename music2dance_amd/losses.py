@@ -10,6 +10,7 @@ import torch
 import torch.autograd as autograd
 
 from . import ops
+from .layers import to_device_async
 
 
 def gradient_penalty(critic, bsize, real, fake, audio=None, is_seq=False, is_cond=False, lp=False, device=None):
@@ -23,7 +24,7 @@ def gradient_penalty(critic, bsize, real, fake, audio=None, is_seq=False, is_con
     the caller's tensor (losses.py:26-27)."""
     real2d = real.reshape(real.size(0), -1)
     fake2d = fake.reshape(fake.size(0), -1)
-    alpha = torch.rand(bsize, 1).to(real2d.device)
+    alpha = to_device_async(torch.rand(bsize, 1), real2d.device)
     interpol = ops.gp_interpolate(real2d, fake2d, alpha.view(-1))
     interpol = interpol.view(interpol.size(0), 69, -1) if is_seq else interpol.view(interpol.size(0), 23, 3)
     interpol.requires_grad_(True)

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...layers import GRU, BatchNorm1d, Conv1d, Linear, head_activation, lengths_tensor
+from ...layers import GRU, BatchNorm1d, Conv1d, Linear, head_activation, lengths_tensor, to_device_async
 from ...utils import initialize_weights
 
 
@@ -247,7 +247,7 @@ class SequenceGenerator(nn.Module):
         code = self.audio_enc(x.reshape(-1, 1, self.window_size)).view(-1, frames, self.input_size)
         if noise is None:
             # drawn from the HOST generator, then moved (phase3/archis/default.py:31-34)
-            noise = torch.randn(list(code.size()[:-1]) + [self.noise_size]).to(code.device)
+            noise = to_device_async(torch.randn(list(code.size()[:-1]) + [self.noise_size]), code.device)
         ls = _descending(lengths)
         # the two recurrences are independent and latency-bound (a few dozen blocks per step):
         # the 1-layer noise GRU runs on a side stream under the 3-layer audio GRU
