@@ -68,6 +68,13 @@ CONV_CASES = [
     ("odd.a", 2, 3, 17, 5, 3, 2, 1),
     ("odd.b", 1, 7, 33, 9, 5, 3, 0),
     ("odd.c", 2, 2, 40, 33, 6, 4, 5),
+    # channel counts >= 16 that are not multiples of the 16-deep chunk (lo tails of the packed path)
+    ("odd.d", 2, 20, 50, 24, 5, 3, 2),
+    ("odd.e", 3, 17, 21, 40, 2, 2, 0),
+    ("odd.f", 2, 33, 64, 70, 7, 1, 3),
+    # batch large enough for split-K plans and several column tiles per sample boundary
+    ("split.a", 40, 32, 100, 48, 5, 2, 2),
+    ("split.b", 70, 16, 33, 130, 3, 1, 1),
 ]
 
 
@@ -94,6 +101,63 @@ def test_conv1d_fwd_bwd(case):
     assert rel_err(dx, gx) < 2e-5, "bwd_data"
     dw = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p)
     assert rel_err(dw, gw) < 3e-5, "bwd_weight"
+
+
+def test_conv1d_cabi_without_packed_weights():
+    """Straight through the C-ABI with w_packed = NULL: the call packs into its workspace."""
+    import ctypes
+    from music2dance_amd import _lib
+    h = _lib.lib()
+    B, Cin, L, Cout, ks, s, p = 3, 32, 40, 24, 5, 2, 2
+    x, w = gen(B, Cin, L, seed=1).to(DEV), gen(Cout, Cin, ks, seed=2, scale=0.1).to(DEV)
+    Lout = (L + 2 * p - ks) // s + 1
+    y = torch.empty(B, Cout, Lout, device=DEV)
+    nws = h.m2d_conv1d_workspace_bytes(0, B, Cin, L, Cout, ks, s, p)
+    assert nws >= Cout * Cin * ks * 4
+    ws = torch.empty(nws // 4 + 1, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = h.m2d_conv1d_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, Cin, L, Cout, ks, s, p, 0, 0.0,
+                          None, None, 0.0, ws.data_ptr(), nws, st)
+    assert rc == 0, h.m2d_last_error()
+    ref = F.conv1d(x.cpu().double(), w.cpu().double(), None, stride=s, padding=p)
+    assert rel_err(y, ref) < 2e-5
+    dy = gen(B, Cout, Lout, seed=3).to(DEV)
+    dx = torch.empty(B, Cin, L, device=DEV)
+    nws = h.m2d_conv1d_workspace_bytes(1, B, Cin, L, Cout, ks, s, p)
+    ws = torch.empty(nws // 4 + 1, device=DEV)
+    rc = h.m2d_conv1d_bwd_data(dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, Cin, L, Cout, ks, s, p, None, 0.0,
+                               ws.data_ptr(), nws, st)
+    assert rc == 0, h.m2d_last_error()
+    x64 = x.cpu().double().requires_grad_(True)
+    (gx,) = torch.autograd.grad(F.conv1d(x64, w.cpu().double(), None, stride=s, padding=p), x64, dy.cpu().double())
+    assert rel_err(dx, gx) < 2e-5
+    # too small a workspace is refused, not overrun
+    rc = h.m2d_conv1d_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, Cin, L, Cout, ks, s, p, 0, 0.0,
+                          None, None, 0.0, ws.data_ptr(), 16, st)
+    assert rc != 0
+
+
+def test_packed_weight_cache_scope():
+    """Outside weight_cache() every call packs afresh; inside, the images are reused until
+    invalidate_packed() - in-place updates that do not move the version counter (fused optimizers)
+    are only seen after it."""
+    k = K()
+    x, w = gen(2, 32, 30, seed=1).to(DEV), gen(16, 32, 3, seed=2, scale=0.2).to(DEV)
+    ref = lambda: F.conv1d(x.cpu().double(), w.cpu().double(), None, padding=1)
+    assert rel_err(k.conv1d_fwd(x, w, None, 1, 1), ref()) < 2e-5
+    w.mul_(2.0)
+    assert rel_err(k.conv1d_fwd(x, w, None, 1, 1), ref()) < 2e-5          # no scope: fresh
+    with k.weight_cache():
+        n0 = k.pack_launches
+        assert rel_err(k.conv1d_fwd(x, w, None, 1, 1), ref()) < 2e-5
+        assert rel_err(k.conv1d_fwd(x, w, None, 1, 1), ref()) < 2e-5
+        assert k.pack_launches == n0 + 1                                   # packed once
+        torch._foreach_mul_([w], 0.5)                                      # version-less style update ...
+        k.invalidate_packed()                                              # ... announced by the caller
+        assert rel_err(k.conv1d_fwd(x, w, None, 1, 1), ref()) < 2e-5
+        w.add_(1.0)                                                        # ordinary in-place op: version moves
+        assert rel_err(k.conv1d_fwd(x, w, None, 1, 1), ref()) < 2e-5
+    assert not k._packed
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[6], CONV_CASES[12], CONV_CASES[29]],
