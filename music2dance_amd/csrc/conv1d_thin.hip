@@ -309,6 +309,98 @@ size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout) {
   return nblk * Cout * ks * sizeof(float);
 }
 
+// Forward for Cout == 32 on the matrix pipe: per wave 32 channels x 32*NT consecutive positions as
+// NT 32x32 tiles of v_mfma_f32_32x32x2_f32, K = the k taps (13 steps for k = 25; the weights stay
+// in 13 registers per lane for the whole launch). 13 MFMAs per 4 KB of output instead of 25 vector
+// FMAs per output.
+//   A[row = lane & 31][k = 2*ks + (lane >> 5)] = W[row, k]
+//   B[k][col = lane & 31]                      = x[n, (l0 + col)*S - pad + k]
+//   C: col = lane & 31 (position), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (channel)
+// The accumulators go through a wave-private LDS image [channel][32*NT positions] so that the
+// epilogue reads the mask and writes the result as dwordx4 runs of 128*NT bytes per channel row
+// (measured at B = 64: 79 us plain / 107 us masked, against 71 / 161 us for dword accesses
+// straight from the accumulator layout, and ~117 us for the vector-ALU kernel).
+template <int KS, int S, int NT>
+__global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
+  constexpr int NS = (KS + 1) / 2;
+  constexpr int NP = 32 * NT;    // positions per wave
+  constexpr int LDP = NP + 4;
+  constexpr int LPR = NP / 4;    // lanes per channel row in the epilogue
+  constexpr int RPI = 64 / LPR;  // channel rows per store instruction
+  __shared__ float img[4][32 * LDP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c31 = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const float* xr = a.x + (size_t)n * a.L;
+  float* im = img[wave];
+  float wa[NS];
+#pragma unroll
+  for (int ks = 0; ks < NS; ++ks) {
+    const int k = 2 * ks + h;
+    wa[ks] = k < KS ? a.w[c31 * KS + k] : 0.f;
+  }
+  const int p0 = (blockIdx.x * 4 + wave) * NP;  // first position of this wave
+  if (p0 >= a.Lout) return;
+  float xb[2][NS];
+  auto fetch = [&](int t, float (&dst)[NS]) {
+    const int l = p0 + t * 32 + c31;
+    const int base = l * S - a.pad + h;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const int pos = base + 2 * ks;
+      dst[ks] = (2 * ks + h < KS && l < a.Lout && pos >= 0 && pos < a.L) ? xr[pos] : 0.f;
+    }
+  };
+  fetch(0, xb[0]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t + 1 < NT) fetch(t + 1, xb[(t + 1) & 1]);
+    thin_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ks], xb[t & 1][ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) im[((r & 3) + 8 * (r >> 2) + 4 * h) * LDP + t * 32 + c31] = acc[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool full = (a.Lout % 4 == 0) && (p0 + NP <= a.Lout);
+  const int cq = lane % LPR;
+#pragma unroll 4
+  for (int i = 0; i < 32 / RPI; ++i) {
+    const int co = lane / LPR + RPI * i;
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    const float4 q = *reinterpret_cast<const float4*>(im + co * LDP + 4 * cq);
+    float v[4] = {q.x + bv, q.y + bv, q.z + bv, q.w + bv};
+    const size_t o = ((size_t)n * 32 + co) * a.Lout + p0 + 4 * cq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (a.act == 1) v[j] = v[j] > 0.f ? v[j] : 0.f;
+      else if (a.act == 2) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
+    }
+    if (full) {
+      if (a.mask) {
+        const float4 m = *reinterpret_cast<const float4*>(a.mask + o);
+        v[0] *= m.x > 0.f ? 1.f : a.mask_slope;
+        v[1] *= m.y > 0.f ? 1.f : a.mask_slope;
+        v[2] *= m.z > 0.f ? 1.f : a.mask_slope;
+        v[3] *= m.w > 0.f ? 1.f : a.mask_slope;
+      }
+      *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p0 + 4 * cq + j < a.Lout) {
+          float y = v[j];
+          if (a.mask) y *= a.mask[o + j] > 0.f ? 1.f : a.mask_slope;
+          a.out[o + j] = y;
+        }
+    }
+  }
+}
+
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
                  int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
                  hipStream_t stream) {
@@ -319,7 +411,10 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
-  hipLaunchKernelGGL((thin_fwd_kernel<25, 4, 4>), dim3(m2d_ceil_div(Lout, 1024), B), dim3(256), 0, stream, a);
+  if (Cout == 32)
+    hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2>), dim3(m2d_ceil_div(Lout, 256), B), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((thin_fwd_kernel<25, 4, 4>), dim3(m2d_ceil_div(Lout, 1024), B), dim3(256), 0, stream, a);
   M2D_CHECK_LAUNCH("thin_fwd_kernel");
   return M2D_OK;
 }
