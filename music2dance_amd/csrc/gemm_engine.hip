@@ -374,14 +374,25 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   }
 }
 
-// Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue.
+// Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue. Eight
+// independent partial chains (slab z goes to chain z % 8, chains combined pairwise) keep eight
+// loads per thread in flight: one dependent chain over up to 128 slabs is latency-bound.
 __global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmParams p) {
   const size_t total = (size_t)p.M * p.N;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int row = (int)(idx / p.N);
     const int col = (int)(idx - (size_t)row * p.N);
-    float s = 0.f;
-    for (int z = 0; z < p.splits; ++z) s += p.slab[(size_t)z * total + idx];
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* sp = p.slab + idx;
+    int z = 0;
+    for (; z + 8 <= p.splits; z += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] += sp[(size_t)(z + j) * total];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (z + j < p.splits) c[j] += sp[(size_t)(z + j) * total];
+    const float s = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
     int chi, clo;
     m2d_divmod(col, p.O.cdiv, p.O.cdiv_inv, chi, clo);
     bool ok = true;
