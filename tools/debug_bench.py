@@ -7,7 +7,7 @@ from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
 import bench
 B = int(os.environ.get("B", 64))
 dev = torch.device("cuda:0")
-gen, critic = bench.build_models(dev)
+gen, critic = bench.build_models(dev, 120, os.environ.get("ENC", "default"))
 eng = Phase3Engine(gen, critic, bench.P3_DEFAULT)
 real, audio, slices = synthetic_phase3_batch(B, 120, dev, seed=1)
 print("built", flush=True)
