@@ -7,6 +7,7 @@ contiguous fp32 tensors on a HIP device, otherwise the call raises (no fallback)
 """
 import contextlib
 import ctypes
+import os
 import weakref
 
 import torch
@@ -39,7 +40,40 @@ def _chk(*tensors):
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    # raw hipStream_t of the current stream without building a torch.cuda.Stream object
+    return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(dev):
+    """Device guard for a launch: a no-op when `dev` is already current (the common case)."""
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(dev)
+
+
+_WS_BYTES = {}
+
+
+def _ws_bytes(name, *args):
+    """Workspace size queries are pure functions of the shape: ask the library once per shape."""
+    if "M2D_PLAN" in os.environ:  # tuning builds: the plan (and its workspace) follows the environment
+        return getattr(_lib.lib(), name)(*args)
+    key = (name,) + args
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = _WS_BYTES[key] = getattr(_lib.lib(), name)(*args)
+    return n
 
 
 def _ws(nbytes, dev):
@@ -94,7 +128,7 @@ class HipKernels:
         Cout, Cin, ks = w.shape
         wf = torch.empty((Cout, ks, Cin), dtype=torch.float32, device=w.device)
         wb = torch.empty((Cin, ks, Cout), dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
+        with _on(w.device):
             rc = _lib.lib().m2d_conv1d_pack_weights(_ptr(w), _ptr(wf), _ptr(wb), Cout, Cin, ks, stream)
         _lib.check(rc, "m2d_conv1d_pack_weights")
         self.pack_launches += 1
@@ -122,8 +156,8 @@ class HipKernels:
         h = _lib.lib()
         full_length = Lout == 1 and pad == 0 and L == ks
         wp = self.packed_weights(w)[0] if (Cin >= 16 and not full_length) else None
-        ws = _ws(h.m2d_conv1d_workspace_bytes(0, B, Cin, L, Cout, ks, stride, pad), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 0, B, Cin, L, Cout, ks, stride, pad), dev)
+        with _on(dev):
             rc = h.m2d_conv1d_fwd(_ptr(x), _ptr(w), _ptr(wp), _ptr(bias), _ptr(y), B, Cin, L, Cout, ks, stride, pad,
                                   act, slope, _ptr(residual), _ptr(out_mask), out_mask_slope, _ptr(ws),
                                   0 if ws is None else ws.numel() * 4, _stream(dev))
@@ -139,8 +173,8 @@ class HipKernels:
         h = _lib.lib()
         full_length = Lout == 1 and pad == 0 and L == ks
         wp = None if (full_length or self._thin(Cin, ks, stride)) else self.packed_weights(w)[1]
-        ws = _ws(h.m2d_conv1d_workspace_bytes(1, B, Cin, L, Cout, ks, stride, pad), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 1, B, Cin, L, Cout, ks, stride, pad), dev)
+        with _on(dev):
             rc = h.m2d_conv1d_bwd_data(_ptr(dy), _ptr(w), _ptr(wp), _ptr(dx), B, Cin, L, Cout, ks, stride, pad,
                                        _ptr(dy_mask), dy_mask_slope, _ptr(ws),
                                        0 if ws is None else ws.numel() * 4, _stream(dev))
@@ -154,8 +188,8 @@ class HipKernels:
         assert B == B2 and Lout == conv_out_len(L, ks, stride, pad)
         dw = torch.empty((Cout, Cin, ks), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(h.m2d_conv1d_workspace_bytes(2, B, Cin, L, Cout, ks, stride, pad), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 2, B, Cin, L, Cout, ks, stride, pad), dev)
+        with _on(dev):
             rc = h.m2d_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, L, Cout, ks, stride, pad,
                                          _ptr(dy_mask), dy_mask_slope, _ptr(ws),
                                          0 if ws is None else ws.numel() * 4, _stream(dev))
@@ -179,8 +213,8 @@ class HipKernels:
         assert K == K2, "gemm: inner dimension mismatch"
         c = torch.empty((M, N), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(h.m2d_gemm_workspace_bytes(mode, M, N, K), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_gemm_workspace_bytes', mode, M, N, K), dev)
+        with _on(dev):
             rc = h.m2d_gemm(mode, _ptr(a), _ptr(b), _ptr(bias), _ptr(c), M, N, K, act, slope, _ptr(a_mask),
                             a_mask_slope, _ptr(out_mask), out_mask_slope, _ptr(ws),
                             0 if ws is None else ws.numel() * 4, _stream(dev))
@@ -195,8 +229,8 @@ class HipKernels:
         L = x.shape[2] if x.dim() == 3 else 1
         out = torch.empty((C,), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(h.m2d_bn_workspace_bytes(C), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_bn_workspace_bytes', C), dev)
+        with _on(dev):
             rc = h.m2d_channel_sums(_ptr(x), _ptr(mask), slope, _ptr(out), B, C, L, _ptr(ws), ws.numel() * 4,
                                     _stream(dev))
         _lib.check(rc, "m2d_channel_sums")
@@ -211,8 +245,8 @@ class HipKernels:
         save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
         save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(h.m2d_bn_workspace_bytes(C), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_bn_workspace_bytes', C), dev)
+        with _on(dev):
             rc = h.m2d_bn_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
                               _ptr(save_mean), _ptr(save_invstd), B, C, L, eps, momentum, 1 if training else 0,
                               act, slope, _ptr(residual), _ptr(ws), ws.numel() * 4, _stream(dev))
@@ -227,8 +261,8 @@ class HipKernels:
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(h.m2d_bn_workspace_bytes(C), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_bn_workspace_bytes', C), dev)
+        with _on(dev):
             rc = h.m2d_bn_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_invstd),
                               _ptr(dx), _ptr(dgamma), _ptr(dbeta), B, C, L, act, slope, _ptr(ws), ws.numel() * 4,
                               _stream(dev))
@@ -246,7 +280,7 @@ class HipKernels:
         if save:
             saved = torch.empty((4, B, T, H), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = h.m2d_gru_layer_fwd(_ptr(gi), _ptr(w_hh_t), _ptr(b_hh), _ptr(lengths), _ptr(out),
                                      _ptr(saved[0]) if save else 0, _ptr(saved[1]) if save else 0,
                                      _ptr(saved[2]) if save else 0, _ptr(saved[3]) if save else 0, B, T, H,
@@ -261,7 +295,7 @@ class HipKernels:
         dgh = torch.empty((B, T, 3 * H), dtype=torch.float32, device=dev)
         dh_buf = torch.empty((2, B, H), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = h.m2d_gru_layer_bwd(_ptr(dout), _ptr(out), _ptr(saved[0]), _ptr(saved[1]), _ptr(saved[2]),
                                      _ptr(saved[3]), _ptr(w_hh), _ptr(lengths), _ptr(dgi), _ptr(dgh),
                                      _ptr(dh_buf), B, T, H, _stream(dev))
@@ -284,7 +318,7 @@ class HipKernels:
         saved = [torch.empty((4, B, T, H), dtype=torch.float32, device=dev) for _ in range(L)] if save else None
         keep = [self._ptr_array(v) for v in (w_ih_t, b_ih, w_hh_t, b_hh, outs)]
         sv = self._ptr_array(saved) if save else (None, None)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_gru_stack_fwd(_ptr(gi0), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
                                               sv[1], _ptr(lengths), B, T, H, L, _stream(dev))
         _lib.check(rc, "m2d_gru_stack_fwd")
@@ -299,7 +333,7 @@ class HipKernels:
         dgh = [torch.empty((B, T, 3 * H), dtype=torch.float32, device=dev) for _ in range(L)]
         dhb = [torch.empty((2, B, H), dtype=torch.float32, device=dev) for _ in range(L)]
         keep = [self._ptr_array(v) for v in (outs, saved, w_hh, w_ih, dgi, dgh, dhb)]
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_gru_stack_bwd(_ptr(dout), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
                                               keep[5][1], keep[6][1], _ptr(lengths), B, T, H, L, _stream(dev))
         _lib.check(rc, "m2d_gru_stack_bwd")
@@ -311,7 +345,7 @@ class HipKernels:
         dev = _chk(real, fake, alpha)
         B, n = real.shape
         out = torch.empty_like(real)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_gp_interpolate(_ptr(real), _ptr(fake), _ptr(alpha), _ptr(out), B, n, _stream(dev))
         _lib.check(rc, "m2d_gp_interpolate")
         return out
@@ -322,8 +356,8 @@ class HipKernels:
         norms = torch.empty((B,), dtype=torch.float32, device=dev)
         pen = torch.empty((), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(h.m2d_gp_penalty_workspace_bytes(B), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_gp_penalty_workspace_bytes', B), dev)
+        with _on(dev):
             rc = h.m2d_gp_penalty_fwd(_ptr(g), _ptr(norms), _ptr(pen), B, n, 1 if lp else 0, _ptr(ws),
                                       ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_gp_penalty_fwd")
@@ -333,7 +367,7 @@ class HipKernels:
         dev = _chk(g, norms, gout)
         B, n = g.shape
         dg = torch.empty_like(g)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_gp_penalty_bwd(_ptr(g), _ptr(norms), _ptr(gout), _ptr(dg), B, n, 1 if lp else 0,
                                                _stream(dev))
         _lib.check(rc, "m2d_gp_penalty_bwd")
@@ -344,8 +378,8 @@ class HipKernels:
         dev = _chk(a, b)
         out = torch.empty((), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(h.m2d_reduce_workspace_bytes(), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_reduce_workspace_bytes', ), dev)
+        with _on(dev):
             rc = h.m2d_l1_mean_fwd(_ptr(a), _ptr(b), _ptr(out), a.numel(), _ptr(ws), ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_l1_mean_fwd")
         return out
@@ -353,7 +387,7 @@ class HipKernels:
     def l1_mean_bwd(self, a, b, gout):
         dev = _chk(a, b, gout)
         da = torch.empty_like(a)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_l1_mean_bwd(_ptr(a), _ptr(b), _ptr(gout), _ptr(da), a.numel(), _stream(dev))
         _lib.check(rc, "m2d_l1_mean_bwd")
         return da
@@ -363,8 +397,8 @@ class HipKernels:
         dev = _chk(x)
         out = torch.empty((), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(h.m2d_reduce_workspace_bytes(), dev)
-        with torch.cuda.device(dev):
+        ws = _ws(_ws_bytes('m2d_reduce_workspace_bytes', ), dev)
+        with _on(dev):
             rc = h.m2d_tv_mean_fwd(_ptr(x), _ptr(out), B, C, T, sb, sc, st, _ptr(ws), ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_tv_mean_fwd")
         return out
@@ -372,7 +406,7 @@ class HipKernels:
     def tv_mean_bwd(self, x, gout, B, C, T, sb, sc, st):
         dev = _chk(x, gout)
         dx = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_tv_mean_bwd(_ptr(x), _ptr(gout), _ptr(dx), B, C, T, sb, sc, st, _stream(dev))
         _lib.check(rc, "m2d_tv_mean_bwd")
         return dx
@@ -382,7 +416,7 @@ class HipKernels:
         dev = _chk(x)
         B, C, L = x.shape
         y = torch.empty((B, C, L // 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_maxpool2_fwd(_ptr(x), _ptr(y), B * C, L, _stream(dev))
         _lib.check(rc, "m2d_maxpool2_fwd")
         return y
@@ -391,7 +425,7 @@ class HipKernels:
         dev = _chk(x, dy)
         B, C, L = x.shape
         dx = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_maxpool2_bwd(_ptr(x), _ptr(dy), _ptr(dx), B * C, L, _stream(dev))
         _lib.check(rc, "m2d_maxpool2_bwd")
         return dx
@@ -400,7 +434,7 @@ class HipKernels:
         dev = _chk(x)
         B, C, L = x.shape
         y = torch.empty((B, C, 2 * L), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_upsample2_fwd(_ptr(x), _ptr(y), B * C, L, _stream(dev))
         _lib.check(rc, "m2d_upsample2_fwd")
         return y
@@ -409,7 +443,7 @@ class HipKernels:
         dev = _chk(dy)
         B, C, Lo = dy.shape
         dx = torch.empty((B, C, Lo // 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = _lib.lib().m2d_upsample2_bwd(_ptr(dy), _ptr(dx), B * C, Lo // 2, _stream(dev))
         _lib.check(rc, "m2d_upsample2_bwd")
         return dx
