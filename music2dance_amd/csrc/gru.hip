@@ -256,17 +256,17 @@ struct GruStackFwdArgs {
   int B, T, H, L, d;
 };
 
-template <int NB>
+template <int NB, int NW>
 __device__ __forceinline__ void gru_mac(const float* arow, bool rok, const float* wt, int H, int ncol, int bcol,
                                         bool cok, int wave, int lane, f32x4 (&acc)[NB], const int (&col_of)[NB]) {
-  // acc[j] += A[16 rows, K = H] * W^T[:, col_of[j] * H + bcol]; this wave takes k-steps wave, wave+4, ...
+  // acc[j] += A[16 rows, K = H] * W^T[:, col_of[j] * H + bcol]; this wave takes k-steps wave, wave+NW, ...
   const int nsteps = (H + 3) / 4;
-  for (int s0 = wave; s0 < nsteps; s0 += 4 * GRU_UNROLL) {
+  for (int s0 = wave; s0 < nsteps; s0 += NW * GRU_UNROLL) {
     float av[GRU_UNROLL], bv[GRU_UNROLL][NB];
 #pragma unroll
     for (int i = 0; i < GRU_UNROLL; ++i) {
-      const int k = 4 * (s0 + 4 * i) + (lane >> 4);
-      const bool kok = (s0 + 4 * i) < nsteps && k < H;
+      const int k = 4 * (s0 + NW * i) + (lane >> 4);
+      const bool kok = (s0 + NW * i) < nsteps && k < H;
       av[i] = (rok && kok) ? arow[k] : 0.f;
       const float* wrow = wt + (size_t)(kok ? k : 0) * ncol + (cok ? bcol : 0);
       const bool ok = kok && cok;
@@ -280,8 +280,13 @@ __device__ __forceinline__ void gru_mac(const float* arow, bool rok, const float
   }
 }
 
-__global__ void __launch_bounds__(256) m2d_gru_stack_fwd_kernel(const GruStackFwdArgs a) {
-  __shared__ float red[4][4][256];
+// 8 waves split K: at H = 240 a wave multiplies 8 k-steps per contraction instead of 15 (the
+// dependent MFMA chain and the operand burst per wave halve; the step is latency-bound)
+#define GRU_FWD_NW 8
+__global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_stack_fwd_kernel(const GruStackFwdArgs a) {
+  constexpr int NW = GRU_FWD_NW;
+  constexpr int UN = GRU_UNROLL * 4 / NW;  // k-steps per wave in the single-batch path (covers H <= 256)
+  __shared__ float red[NW][4][256];
   const int l = blockIdx.z;
   const int t = a.d - l;
   if (t < 0 || t >= a.T) return;
@@ -296,19 +301,19 @@ __global__ void __launch_bounds__(256) m2d_gru_stack_fwd_kernel(const GruStackFw
   const int bcol = u0 + (lane & 15);
   const bool rok = arow < a.B, cok = bcol < H;
   // Both contractions (hidden: h_l[t-1] W_hh^T, input: h_{l-1}[t] W_ih^T) have K = H. When a
-  // wave's share fits one batch (H <= 4 * 4 * GRU_UNROLL = 256) ALL operand loads of both are
+  // wave's share fits one batch (H <= 4 * NW * UN = 256) ALL operand loads of both are
   // issued before the first MFMA: one memory round trip per step instead of two.
   const int nsteps = (H + 3) / 4;
   const bool use_h = t > 0, use_i = l > 0;
-  if (nsteps <= 4 * GRU_UNROLL) {
-    float ah[GRU_UNROLL], bh[GRU_UNROLL][3], ai[GRU_UNROLL], bi[GRU_UNROLL][3];
+  if (nsteps <= NW * UN) {
+    float ah[UN], bh[UN][3], ai[UN], bi[UN][3];
     const float* hrow = a.out[l] + ((size_t)arow * T + (use_h ? t - 1 : 0)) * H;
     const float* irow = a.out[use_i ? l - 1 : 0] + ((size_t)arow * T + t) * H;
     const float* wh = a.w_hh_t[l];
     const float* wi = a.w_ih_t[use_i ? l : 0];
 #pragma unroll
-    for (int i = 0; i < GRU_UNROLL; ++i) {
-      const int st = wave + 4 * i;
+    for (int i = 0; i < UN; ++i) {
+      const int st = wave + NW * i;
       const int k = 4 * st + (lane >> 4);
       const bool kok = st < nsteps && k < H;
       const size_t wo = (size_t)(kok ? k : 0) * 3 * H + (cok ? bcol : 0);
@@ -323,7 +328,7 @@ __global__ void __launch_bounds__(256) m2d_gru_stack_fwd_kernel(const GruStackFw
     }
     if (use_h) {
 #pragma unroll
-      for (int i = 0; i < GRU_UNROLL; ++i) {
+      for (int i = 0; i < UN; ++i) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][0], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][1], acc[1], 0, 0, 0);
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][2], acc[2], 0, 0, 0);
@@ -331,7 +336,7 @@ __global__ void __launch_bounds__(256) m2d_gru_stack_fwd_kernel(const GruStackFw
     }
     if (use_i) {
 #pragma unroll
-      for (int i = 0; i < GRU_UNROLL; ++i) {
+      for (int i = 0; i < UN; ++i) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][0], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][1], acc[1], 0, 0, 0);
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][2], acc[3], 0, 0, 0);
@@ -341,13 +346,13 @@ __global__ void __launch_bounds__(256) m2d_gru_stack_fwd_kernel(const GruStackFw
     if (use_h) {
       f32x4 h3[3] = {acc[0], acc[1], acc[2]};
       const int cols[3] = {0, 1, 2};
-      gru_mac<3>(a.out[l] + ((size_t)arow * T + (t - 1)) * H, rok, a.w_hh_t[l], H, 3 * H, bcol, cok, wave, lane, h3, cols);
+      gru_mac<3, NW>(a.out[l] + ((size_t)arow * T + (t - 1)) * H, rok, a.w_hh_t[l], H, 3 * H, bcol, cok, wave, lane, h3, cols);
       acc[0] = h3[0]; acc[1] = h3[1]; acc[2] = h3[2];
     }
     if (use_i) {
       f32x4 i3[3] = {acc[0], acc[1], acc[3]};
       const int cols[3] = {0, 1, 2};
-      gru_mac<3>(a.out[l - 1] + ((size_t)arow * T + t) * H, rok, a.w_ih_t[l], H, 3 * H, bcol, cok, wave, lane, i3, cols);
+      gru_mac<3, NW>(a.out[l - 1] + ((size_t)arow * T + t) * H, rok, a.w_ih_t[l], H, 3 * H, bcol, cok, wave, lane, i3, cols);
       acc[0] = i3[0]; acc[1] = i3[1]; acc[3] = i3[2];
     }
   }
@@ -356,12 +361,18 @@ __global__ void __launch_bounds__(256) m2d_gru_stack_fwd_kernel(const GruStackFw
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][g][((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[g][r];
   __syncthreads();
+  if (tid >= 256) return;
   const int row = tid >> 4, col = tid & 15;
   const int b = b0 + row, u = u0 + col;
   if (b >= a.B || u >= H) return;
   float s[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) s[g] = red[0][g][tid] + red[1][g][tid] + red[2][g][tid] + red[3][g][tid];
+  for (int g = 0; g < 4; ++g) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][g][tid];
+    s[g] = v;
+  }
   const size_t bt = (size_t)b * T + t;
   float gir, giz, gin;
   if (l == 0) {
@@ -402,16 +413,17 @@ struct GruStackBwdArgs {
   int B, T, H, L, e;
 };
 
+template <int NW>
 __device__ __forceinline__ void gru_mac1(const float* arow, bool rok, const float* w, int K, int H, int bcol, bool cok,
                                          int wave, int lane, f32x4& acc) {
   // acc += A[16 rows, K] * W[K, H][:, bcol]
   const int nsteps = (K + 3) / 4;
-  for (int s0 = wave; s0 < nsteps; s0 += 4 * GRU_UNROLL) {
+  for (int s0 = wave; s0 < nsteps; s0 += NW * GRU_UNROLL) {
     float av[GRU_UNROLL], bv[GRU_UNROLL];
 #pragma unroll
     for (int i = 0; i < GRU_UNROLL; ++i) {
-      const int k = 4 * (s0 + 4 * i) + (lane >> 4);
-      const bool kok = (s0 + 4 * i) < nsteps && k < K;
+      const int k = 4 * (s0 + NW * i) + (lane >> 4);
+      const bool kok = (s0 + NW * i) < nsteps && k < K;
       av[i] = (rok && kok) ? arow[k] : 0.f;
       bv[i] = (kok && cok) ? w[(size_t)k * H + bcol] : 0.f;
     }
@@ -420,8 +432,10 @@ __device__ __forceinline__ void gru_mac1(const float* arow, bool rok, const floa
   }
 }
 
-__global__ void __launch_bounds__(256) m2d_gru_stack_bwd_kernel(const GruStackBwdArgs a) {
-  __shared__ float red[4][256];
+#define GRU_BWD_NW 8
+__global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_stack_bwd_kernel(const GruStackBwdArgs a) {
+  constexpr int NW = GRU_BWD_NW;
+  __shared__ float red[NW][256];
   const int l = a.L - 1 - (int)blockIdx.z;
   const int t = a.T - 1 - (a.e - (int)blockIdx.z);
   if (t < 0 || t >= a.T) return;
@@ -434,18 +448,21 @@ __global__ void __launch_bounds__(256) m2d_gru_stack_bwd_kernel(const GruStackBw
   const bool rok = arow < a.B, cok = bcol < H;
   const bool has_next = (t + 1) < T;
   const bool has_up = (l + 1) < a.L;
-  if (has_next) gru_mac1(a.dgh[l] + ((size_t)arow * T + (t + 1)) * 3 * H, rok, a.w_hh[l], 3 * H, H, bcol, cok, wave, lane, acc);
-  if (has_up) gru_mac1(a.dgi[l + 1] + ((size_t)arow * T + t) * 3 * H, rok, a.w_ih[l + 1], 3 * H, H, bcol, cok, wave, lane, acc);
+  if (has_next) gru_mac1<NW>(a.dgh[l] + ((size_t)arow * T + (t + 1)) * 3 * H, rok, a.w_hh[l], 3 * H, H, bcol, cok, wave, lane, acc);
+  if (has_up) gru_mac1<NW>(a.dgi[l + 1] + ((size_t)arow * T + t) * 3 * H, rok, a.w_ih[l + 1], 3 * H, H, bcol, cok, wave, lane, acc);
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
   __syncthreads();
+  if (tid >= 256) return;
   const int row = tid >> 4, col = tid & 15;
   const int b = b0 + row, u = u0 + col;
   if (b >= a.B || u >= H) return;
   const size_t bt = (size_t)b * T + t;
   const size_t plane = (size_t)a.B * T * H;
   const float* sv = a.saved[l];
-  float dh = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  float dh = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) dh += red[w][tid];
   if (!has_up) dh += a.dout[bt * H + u];
   if (has_next) dh += a.dh_buf[l][((size_t)((t + 1) & 1) * a.B + b) * H + u] * sv[plane + (bt + 1) * H + u];
   if (a.lengths && t >= a.lengths[b]) dh = 0.f;
@@ -483,7 +500,7 @@ int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float*
   M2dProfScope prof(M2D_FAM_GRU, stream, 2.0 * B * 3.0 * H * H * (double)T * (2 * L - 1), 0.0, "gru_stack_fwd", B, T, H);
   for (int d = 0; d < T + L - 1; ++d) {
     a.d = d;
-    hipLaunchKernelGGL(m2d_gru_stack_fwd_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(m2d_gru_stack_fwd_kernel, grid, dim3(64 * GRU_FWD_NW), 0, stream, a);
   }
   M2D_CHECK_LAUNCH("m2d_gru_stack_fwd_kernel");
   return M2D_OK;
@@ -507,7 +524,7 @@ int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* c
   M2dProfScope prof(M2D_FAM_GRU, stream, 2.0 * B * 3.0 * H * H * (double)T * (2 * L - 1), 0.0, "gru_stack_bwd", B, T, H);
   for (int e = 0; e < T + L - 1; ++e) {
     a.e = e;
-    hipLaunchKernelGGL(m2d_gru_stack_bwd_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(m2d_gru_stack_bwd_kernel, grid, dim3(64 * GRU_BWD_NW), 0, stream, a);
   }
   M2D_CHECK_LAUNCH("m2d_gru_stack_bwd_kernel");
   return M2D_OK;
