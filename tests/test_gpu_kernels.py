@@ -473,3 +473,46 @@ def test_gru_stack_lengths():
     with torch.no_grad():
         out = ops.gru_stack(x.to(DEV), params, lens)
     assert rel_err(out, ref) < 1e-5
+
+
+def test_conv1d_random_shapes():
+    """Seeded sweep over conv geometries (tails of every kind, padding wider than the kernel
+    reach, strides that do not divide, batches that split tiles across samples), plain and
+    masked, against fp64 torch."""
+    import random
+    rng = random.Random(1234)
+    k = K()
+    n_done = 0
+    while n_done < 48:
+        B = rng.choice([1, 2, 3, 5, 9, 33])
+        Cin = rng.choice([1, 2, 5, 15, 16, 17, 31, 32, 40, 64, 100])
+        Cout = rng.choice([1, 3, 16, 31, 32, 33, 64, 70, 129])
+        ks = rng.choice([1, 2, 3, 4, 5, 7, 9, 16, 25])
+        s = rng.choice([1, 1, 2, 3, 4, 5])
+        p = rng.choice([0, 0, 1, 2, ks // 2, ks - 1])
+        L = rng.choice([ks, ks + 1, 8, 17, 40, 63, 130, 257])
+        if L + 2 * p < ks:
+            continue
+        Lout = (L + 2 * p - ks) // s + 1
+        seed = 100 + n_done
+        x = gen(B, Cin, L, seed=seed)
+        w = gen(Cout, Cin, ks, seed=seed + 1, scale=1.0 / math.sqrt(Cin * ks))
+        b = gen(Cout, seed=seed + 2, scale=0.1)
+        dy = gen(B, Cout, Lout, seed=seed + 3)
+        mask = gen(B, Cout, Lout, seed=seed + 4)
+        use_mask = n_done % 3 == 0
+        tag = "B%d Cin%d L%d Cout%d k%d s%d p%d mask%d" % (B, Cin, L, Cout, ks, s, p, use_mask)
+        xd, wd, bd, dyd, md = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV), mask.to(DEV)
+        x64 = x.double().requires_grad_(True)
+        w64 = w.double().requires_grad_(True)
+        ref = F.conv1d(x64, w64, b.double(), stride=s, padding=p)
+        m0 = (mask.double() > 0).double() if use_mask else torch.ones_like(ref)
+        gx, gw = torch.autograd.grad(ref, (x64, w64), dy.double() * m0)
+        with k.weight_cache():
+            y = k.conv1d_fwd(xd, wd, bd, s, p, out_mask=md if use_mask else None, out_mask_slope=0.0)
+            dx = k.conv1d_bwd_data(dyd, wd, L, s, p, dy_mask=md if use_mask else None, dy_mask_slope=0.0)
+            dw = k.conv1d_bwd_weight(xd, dyd, ks, s, p, dy_mask=md if use_mask else None, dy_mask_slope=0.0)
+        assert rel_err(y, ref.detach() * m0) < 2e-5, "fwd " + tag
+        assert rel_err(dx, gx) < 2e-5, "bwd_data " + tag
+        assert rel_err(dw, gw) < 3e-5, "bwd_weight " + tag
+        n_done += 1
