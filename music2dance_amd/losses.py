@@ -13,7 +13,8 @@ from . import ops
 from .layers import to_device_async
 
 
-def gradient_penalty(critic, bsize, real, fake, audio=None, is_seq=False, is_cond=False, lp=False, device=None):
+def gradient_penalty(critic, bsize, real, fake, audio=None, is_seq=False, is_cond=False, lp=False, device=None,
+                     alpha=None):
     """Gradient penalty for the stick (phase 1) and sequence (phase 2/3) WGAN frameworks.
 
     lp=False: WGAN-GP  mean_b (sqrt(sum g_b^2 + 1e-12) - 1)^2
@@ -21,10 +22,13 @@ def gradient_penalty(critic, bsize, real, fake, audio=None, is_seq=False, is_con
     With `audio` the critic takes (poses, audio) and the penalty is the SUM of the pose term
     and the audio term. As in the reference, alpha ~ U(0,1) per sample comes from the
     default HOST generator (losses.py:15) and `audio.requires_grad_(True)` is applied to
-    the caller's tensor (losses.py:26-27)."""
+    the caller's tensor (losses.py:26-27). `alpha` (extension, (bsize, 1) on the device): use
+    these interpolation weights instead of drawing them (captured-graph replays feed the draw
+    through a static buffer)."""
     real2d = real.reshape(real.size(0), -1)
     fake2d = fake.reshape(fake.size(0), -1)
-    alpha = to_device_async(torch.rand(bsize, 1), real2d.device)
+    if alpha is None:
+        alpha = to_device_async(torch.rand(bsize, 1), real2d.device)
     interpol = ops.gp_interpolate(real2d, fake2d, alpha.view(-1))
     interpol = interpol.view(interpol.size(0), 69, -1) if is_seq else interpol.view(interpol.size(0), 23, 3)
     interpol.requires_grad_(True)

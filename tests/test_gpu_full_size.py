@@ -203,3 +203,35 @@ def test_long_sequence_sampling_and_validation(models, batch):
     real = torch.rand(2, 120, 69, generator=torch.Generator().manual_seed(6)).to(DEV)
     val = eng.validation_l1([(real, sl[:, :120].contiguous())])
     assert gen.training and torch.isfinite(val)
+
+
+def test_graph_mode_matches_eager():
+    """Phase3Engine.enable_graphs(): nine loop bodies (eight critic iterations + one generator
+    iteration) replayed from captured graphs give the eager path's losses and parameters (same
+    kernels in the same order, host draws made in the reference's order before each replay)."""
+    import bench
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+    dev = torch.device(DEV)
+    b, t = 8, 120
+    batches = [synthetic_phase3_batch(b, t, dev, seed=20 + i) for i in range(2)]
+    traces, params = [], []
+    for use_graphs in (False, True):
+        gen, critic = bench.build_models(dev, t)
+        eng = Phase3Engine(gen, critic, bench.P3_DEFAULT)
+        if use_graphs:
+            eng.enable_graphs()
+        torch.manual_seed(77)
+        tr = []
+        for i in range(9):
+            out = eng.train_step(*batches[i % 2])
+            tr.append({k: float(v) for k, v in out.items()})
+        eng.flush()
+        traces.append(tr)
+        params.append([p.detach().clone() for p in list(critic.parameters()) + list(gen.parameters())]
+                      + [bf.detach().clone().float() for bf in gen.buffers()])
+    for e, g in zip(*traces):
+        assert set(e) == set(g)
+        for k in e:
+            assert abs(e[k] - g[k]) <= 1e-5 * max(1.0, abs(e[k])), (k, e[k], g[k])
+    for pe, pg in zip(*params):
+        assert rel(pg, pe) < 1e-5
