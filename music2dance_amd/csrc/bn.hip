@@ -43,6 +43,26 @@ struct BnReduceArgs {
   float slope;
 };
 
+// one element's contribution to the two running sums
+__device__ __forceinline__ void bn_accum(const BnReduceArgs& a, float xv, float dyv, float mv, float g, float bt,
+                                         float mu, float is, float& s0, float& s1) {
+  if (a.mode == 0) {
+    s0 += xv;
+    s1 += xv * xv;
+  } else if (a.mode == 1) {
+    const float xh = (xv - mu) * is;
+    float dz = dyv;
+    if (a.act) {
+      const float z = g * xh + bt;
+      if (!(z > 0.f)) dz = a.act == 1 ? 0.f : dz * a.slope;
+    }
+    s0 += dz;
+    s1 += dz * xh;
+  } else {
+    s0 += a.mask ? xv * (mv > 0.f ? 1.f : a.slope) : xv;
+  }
+}
+
 __global__ void __launch_bounds__(256) m2d_bn_reduce_kernel(const BnReduceArgs a) {
   __shared__ double sh0[256];
   __shared__ double sh1[256];
@@ -55,36 +75,61 @@ __global__ void __launch_bounds__(256) m2d_bn_reduce_kernel(const BnReduceArgs a
   if (n_end > a.B) n_end = a.B;
   const size_t row_stride = (size_t)a.C * a.L;
   float s0 = 0.f, s1 = 0.f;
-  for (int p = t; p < P; p += 256) {
-    const int c = c0 + (a.cpb > 1 ? p / a.L : 0);
+  if (a.cpb == 1 && (a.L & 3) == 0) {
+    // long rows (the audio critic's activations: L up to 19 200): one channel per block, 16-byte
+    // loads, four positions per thread and step
     float g = 0.f, bt = 0.f, mu = 0.f, is = 0.f;
     if (a.mode == 1) {
-      g = a.gamma[c];
-      bt = a.beta[c];
-      mu = a.mean[c];
-      is = a.invstd[c];
+      g = a.gamma[c0];
+      bt = a.beta[c0];
+      mu = a.mean[c0];
+      is = a.invstd[c0];
     }
-    const size_t base = (size_t)c0 * a.L + p;
+    float q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
     for (int n = n_begin; n < n_end; ++n) {
-      const size_t idx = (size_t)n * row_stride + base;
-      const float xv = a.x[idx];
-      if (a.mode == 0) {
-        s0 += xv;
-        s1 += xv * xv;
-      } else if (a.mode == 1) {
-        const float xh = (xv - mu) * is;
-        float dz = a.dy[idx];
-        if (a.act) {
-          const float z = g * xh + bt;
-          if (!(z > 0.f)) dz = a.act == 1 ? 0.f : dz * a.slope;
-        }
-        s0 += dz;
-        s1 += dz * xh;
-      } else {
-        float v = xv;
-        if (a.mask) v *= (a.mask[idx] > 0.f ? 1.f : a.slope);
-        s0 += v;
+      const size_t rb = (size_t)n * row_stride + (size_t)c0 * a.L;
+      for (int p = 4 * t; p < P; p += 1024) {
+        const float4 xv = *reinterpret_cast<const float4*>(a.x + rb + p);
+        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), mv = dv;
+        if (a.mode == 1) dv = *reinterpret_cast<const float4*>(a.dy + rb + p);
+        if (a.mode == 2 && a.mask) mv = *reinterpret_cast<const float4*>(a.mask + rb + p);
+        bn_accum(a, xv.x, dv.x, mv.x, g, bt, mu, is, q0[0], q1[0]);
+        bn_accum(a, xv.y, dv.y, mv.y, g, bt, mu, is, q0[1], q1[1]);
+        bn_accum(a, xv.z, dv.z, mv.z, g, bt, mu, is, q0[2], q1[2]);
+        bn_accum(a, xv.w, dv.w, mv.w, g, bt, mu, is, q0[3], q1[3]);
       }
+    }
+    s0 = (q0[0] + q0[1]) + (q0[2] + q0[3]);
+    s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+  } else {
+    for (int p = t; p < P; p += 256) {
+      const int c = c0 + (a.cpb > 1 ? p / a.L : 0);
+      float g = 0.f, bt = 0.f, mu = 0.f, is = 0.f;
+      if (a.mode == 1) {
+        g = a.gamma[c];
+        bt = a.beta[c];
+        mu = a.mean[c];
+        is = a.invstd[c];
+      }
+      const size_t base = (size_t)c0 * a.L + p;
+      // four independent row chains keep four loads per tensor in flight
+      float q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
+      int n = n_begin;
+      for (; n + 4 <= n_end; n += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const size_t idx = (size_t)(n + j) * row_stride + base;
+          bn_accum(a, a.x[idx], a.mode == 1 ? a.dy[idx] : 0.f, (a.mode == 2 && a.mask) ? a.mask[idx] : 0.f, g, bt, mu,
+                   is, q0[j], q1[j]);
+        }
+      }
+      for (; n < n_end; ++n) {
+        const size_t idx = (size_t)n * row_stride + base;
+        bn_accum(a, a.x[idx], a.mode == 1 ? a.dy[idx] : 0.f, (a.mode == 2 && a.mask) ? a.mask[idx] : 0.f, g, bt, mu, is,
+                 q0[0], q1[0]);
+      }
+      s0 += (q0[0] + q0[1]) + (q0[2] + q0[3]);
+      s1 += (q1[0] + q1[1]) + (q1[2] + q1[3]);
     }
   }
   sh0[t] = (double)s0;
