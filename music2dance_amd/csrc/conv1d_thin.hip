@@ -288,12 +288,24 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
   }
 }
 
-__global__ void __launch_bounds__(256) thin_sum_partials_kernel(const float* partial, float* dw, int nblk, int n_out) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= n_out) return;
+// dw[o] = sum over the nblk partial slabs, fixed order: 16 groups of slabs per output (group g takes
+// slabs g, g + 16, ...) summed in fp64, then combined in group order. One chain over all slabs per
+// thread was latency-bound (77 us for 320 slabs of 800 outputs).
+__global__ void __launch_bounds__(1024) thin_sum_partials_kernel(const float* partial, float* dw, int nblk, int n_out) {
+  __shared__ double part[16][64];
+  const int ox = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + ox;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * n_out + o];
-  dw[o] = (float)s;
+  if (o < n_out)
+    for (int b = g; b < nblk; b += 16) s += (double)partial[(size_t)b * n_out + o];
+  part[g][ox] = s;
+  __syncthreads();
+  if (g == 0 && o < n_out) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += part[j][ox];
+    dw[o] = (float)t;
+  }
 }
 
 static bool thin_ok(int Cin, int Cout, int ks, int stride) {
@@ -302,7 +314,7 @@ static bool thin_ok(int Cin, int Cout, int ks, int stride) {
 
 bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride) { return thin_ok(Cin, Cout, ks, stride); }
 
-static const int THIN_BW_CHUNK = 4096;
+static const int THIN_BW_CHUNK = 1024;
 
 size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout) {
   const size_t nblk = (size_t)B * m2d_ceil_div(Lout, THIN_BW_CHUNK);
@@ -452,7 +464,7 @@ int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L
     hipLaunchKernelGGL((thin_bwd_weight_mfma_kernel<25, 4>), dim3(nchunk, B), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL((thin_bwd_weight_kernel<25, 4, 8>), dim3(nchunk, B, Cout / 4), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(thin_sum_partials_kernel, dim3(m2d_ceil_div(Cout * ks, 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(thin_sum_partials_kernel, dim3(m2d_ceil_div(Cout * ks, 64)), dim3(1024), 0, stream,
                      (const float*)ws, dw, nchunk * B, Cout * ks);
   M2D_CHECK_LAUNCH("thin_bwd_weight_kernel");
   return M2D_OK;
