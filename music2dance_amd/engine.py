@@ -53,6 +53,7 @@ class WganGpEngine:
         self.x_gen = GradExchange(gen.parameters()) if data_parallel else None
         self._critic_step_pending = False
         self.last = {}
+        self.last_full = {}  # most recent value of every scalar (generator scalars persist between G steps)
 
     # -- critic optimiser step, possibly deferred so its all-reduce overlaps the next G forward
     def _finish_critic_step(self):
@@ -90,6 +91,7 @@ class WganGpEngine:
             if self.total_iterations % self.n_critic_steps == 0:
                 out.update(self.generator_iteration(*batch))
         self.last = out
+        self.last_full.update(out)
         return out
 
 
@@ -118,11 +120,12 @@ class Phase3Engine(WganGpEngine):
         """Forward / backward of the critic iteration up to the gradients (no optimizer step).
         noise / alpha: None = drawn from the host generator where the reference draws them."""
         B, T = self._shapes(real)
-        self.optim_critic.zero_grad(set_to_none=True)
         with torch.no_grad():  # the reference builds and drops this graph (phase3/train.py:195)
             fake_rows = self.gen(audio_slices, [T] * B, noise)
         if finish_inside:
             self._finish_critic_step()
+        # only after the deferred step has consumed the previous iteration's gradients
+        self.optim_critic.zero_grad(set_to_none=True)
         fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         audio_c = audio.unsqueeze(1)
@@ -206,17 +209,26 @@ class Phase3Engine(WganGpEngine):
         # host draws in the reference's order: generator noise, then the penalty's alpha
         g["noise_c"].copy_(to_device_async(torch.randn(B, T, nz), real.device))
         g["alpha"].copy_(to_device_async(torch.rand(B, 1), real.device))
+        # every captured graph writes its gradients into the tensors it was captured with
+        self._bind_grads(self.critic, g["critic_grads"])
         g["critic"].replay()
         self._begin_critic_step()
         out = dict(g["critic_out"])
         if self.total_iterations % self.n_critic_steps == 0:
             self._finish_critic_step()
             g["noise_g"].copy_(to_device_async(torch.randn(B, T, nz), real.device))
+            self._bind_grads(self.gen, g["gen_grads"])
             g["gen"].replay()
             self._gen_step()
             out.update(g["gen_out"])
         self.last = out
+        self.last_full.update(out)
         return out
+
+    @staticmethod
+    def _bind_grads(module, grads):
+        for p, gr in zip(module.parameters(), grads):
+            p.grad = gr
 
     def _graph_for(self, real, audio, audio_slices):
         key = (tuple(real.shape), tuple(audio.shape), tuple(audio_slices.shape))
@@ -257,9 +269,13 @@ class Phase3Engine(WganGpEngine):
         g["critic"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["critic"]):
             g["critic_out"] = critic_body()
+        # the gradient tensors live in this graph's private pool: a graph captured later for another
+        # shape allocates its own, so each replay re-binds p.grad to the set it writes
+        g["critic_grads"] = [p.grad for p in self.critic.parameters()]
         g["gen"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["gen"], pool=g["critic"].pool()):
             g["gen_out"] = gen_body()
+        g["gen_grads"] = [p.grad for p in self.gen.parameters()]
         with torch.no_grad():
             for m, bufs in zip(mods, saved):
                 for b, v in zip(m.buffers(), bufs):
@@ -307,11 +323,11 @@ class Phase2Engine(WganGpEngine):
     def critic_iteration(self, real):
         B = real.size(0)
         T = real.numel() // (B * self.output_size)
-        self.optim_critic.zero_grad(set_to_none=True)
         noise = self._noise(B, T, real.device)
         with torch.no_grad():
             fake_rows = self.gen(noise, [T] * B)
         self._finish_critic_step()
+        self.optim_critic.zero_grad(set_to_none=True)  # after the deferred step used the old gradients
         fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=True, device=real.device)
@@ -360,11 +376,11 @@ class Phase1Engine(WganGpEngine):
 
     def critic_iteration(self, real):
         B = real.size(0)
-        self.optim_critic.zero_grad(set_to_none=True)
         noise = self._noise(B, real.device)
         with torch.no_grad():
             fake = self.gen(noise)
         self._finish_critic_step()
+        self.optim_critic.zero_grad(set_to_none=True)  # after the deferred step used the old gradients
         gp = gradient_penalty(self.critic, B, real, fake, device=real.device)
         err_real = self.critic(real).mean()
         err_fake = self.critic(fake).mean()

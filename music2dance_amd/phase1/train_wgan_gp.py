@@ -38,6 +38,11 @@ def main(argv=None):
     gen = Generator(cfg["latent_vector_size"], cfg["size"], cfg["output_size"], cfg["nblocks_gen"]).to(device)
     critic = Discriminator(cfg["output_size"], cfg["size"], cfg["nblocks_critic"]).to(device)
     engine = Phase1Engine(gen, critic, cfg)
+    if world > 1:  # identical weights must come from a common seed; the reference (single process) sets none
+        for m in (gen, critic):
+            for t in list(m.parameters()) + list(m.buffers()):
+                torch.distributed.broadcast(t.data, 0)
+        torch.manual_seed(torch.initial_seed() + rank)
     engine.host_noise = False  # phase1/train_wgan-gp.py:83 draws the noise on the device
     log = runner.ScalarLog(logdir, opts.log_every)
     B = cfg["batch_size"]
@@ -59,6 +64,7 @@ def main(argv=None):
         if done:
             break
         if logdir is not None and (epoch + 1) % 5 == 0:
+            engine.flush()
             runner.save_state(gen, logdir + "/models/gen_{}.pt".format(epoch + 1))
             runner.save_state(critic, logdir + "/models/critic_{}.pt".format(epoch + 1))
     engine.flush()

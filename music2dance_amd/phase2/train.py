@@ -45,6 +45,7 @@ def main(argv=None):
     critic = SequenceDiscriminator(cfg["output_size"], cfg["channels"], stick_length, cfg["init_kernel"],
                                    cfg["nblocks_critic"], device)
     engine = Phase2Engine(gen, critic, cfg)
+    torch.manual_seed(rank)  # identical weights (seed 0 above), rank-distinct noise / alpha draws
     engine.host_noise = False  # phase2/train.py:139-140 draws the noise on the device
     log = runner.ScalarLog(logdir, opts.log_every)
     runner.dump_architectures(logdir, gen, critic)
@@ -67,6 +68,7 @@ def main(argv=None):
         if done:
             break
         if logdir is not None and (epoch + 1) % 5000 == 0:
+            engine.flush()
             runner.save_state(gen, logdir + "/models/gpgen_{}.pt".format(epoch + 1))
             runner.save_state(critic, logdir + "/models/gpcritic_{}.pt".format(epoch + 1))
     engine.flush()

@@ -15,6 +15,9 @@ from ..engine import Phase3Engine, synthetic_phase3_batch
 from .archis.default import AblatedSequenceDiscriminator, SequenceDiscriminator, SequenceGenerator
 
 
+LAST_LOG = None  # the ScalarLog of the most recent main() (tests and notebooks read .last)
+
+
 def build(cfg, device, stick_length):
     rate = cfg["dataset"]["audio_rate"]
     window = int(cfg["window_size"] * rate)
@@ -37,6 +40,7 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=None, help="override batch_size (per GPU)")
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--no-run-dir", action="store_true")
+    ap.add_argument("--val-batches", type=int, default=1, help="held-out synthetic batches for l1_loss_val")
     opts = ap.parse_args(argv)
 
     rank, world, local = dp.init_from_env()
@@ -52,13 +56,29 @@ def main(argv=None):
     logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
     gen, critic = build(cfg, device, stick_length)
     engine = Phase3Engine(gen, critic, cfg, ablated=cfg["ablated"])
-    log = runner.ScalarLog(logdir, opts.log_every)
+    # seed 0 built identical weights on every rank; the in-loop host draws (generator noise,
+    # penalty alpha) must differ between ranks, as they do between samples of one global batch
+    torch.manual_seed(rank)
+    global LAST_LOG
+    log = LAST_LOG = runner.ScalarLog(logdir, opts.log_every)
     runner.dump_architectures(logdir, gen, critic)
 
     batches_per_epoch = max(cfg["num_train"] // cfg["batch_size"], 1)
     np.random.seed(14)
+    n_valid_steps = 1  # phase3/train.py:168
+
+    def val_batches():
+        # the reference's validation loader serves the held-out 20 % split as one batch
+        # (phase3/train.py:161); here: fixed held-out synthetic batches, disjoint seeds from training
+        for v in range(opts.val_batches):
+            real, _, slices = synthetic_phase3_batch(batch_size, stick_length, device, seed=-(1 + v * world + rank),
+                                                     audio_rate=ds["audio_rate"], video_rate=ds["video_rate"],
+                                                     window_s=cfg["window_size"])
+            yield real, slices
+
     print("Start training..")
     done = False
+    e_val_loss = float("nan")
     for epoch in range(cfg["num_epochs"]):
         gen.train()
         for b in range(batches_per_epoch):
@@ -74,15 +94,24 @@ def main(argv=None):
             if opts.iterations is not None and it >= opts.iterations:
                 done = True
                 break
+        if epoch % n_valid_steps == 0:
+            # eval-mode L1 on held-out batches (phase3/train.py:245-261); validation_l1 restores train mode
+            e_val = engine.validation_l1(val_batches())
+            log.scalars({"l1_loss_val": e_val}, engine.total_iterations, force=True)
+            last_val = e_val
         if done:
             break
         if (epoch + 1) % 500 == 0 and rank == 0:
-            o = engine.last
-            print("Iteration: {} LossD : {}".format(engine.total_iterations, float(o["loss_critic"])))
+            o = engine.last_full
+            e_val_loss = float(last_val)
+            print("Iteration: {} LossG : {} LossD : {} L1 train : {} L1 val : {}".format(
+                engine.total_iterations, float(o.get("loss_gen", float("nan"))), float(o["loss_critic"]),
+                float(o.get("l1_loss_train", float("nan"))), e_val_loss))
         if logdir is not None:
             if (epoch + 1) <= 1000 and (epoch + 1) % 100 == 0:
                 runner.save_state(gen, logdir + "/models/gpgen_{}.pt".format(epoch + 1))
             if (epoch + 1) % 5000 == 0:
+                engine.flush()  # a deferred (data-parallel) critic step must be in the checkpoint
                 runner.save_state(gen, logdir + "/models/gpgen_{}.pt".format(epoch + 1))
                 runner.save_state(critic, logdir + "/models/gpcritic_{}.pt".format(epoch + 1))
     engine.flush()

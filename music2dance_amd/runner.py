@@ -42,6 +42,7 @@ class ScalarLog:
     def __init__(self, logdir, every=1):
         self.every = max(int(every), 1)
         self.writer = None
+        self.last = {}  # most recent value per tag (device tensors; tests and prints read it)
         if logdir is not None:
             try:
                 from torch.utils.tensorboard import SummaryWriter
@@ -49,8 +50,9 @@ class ScalarLog:
             except Exception:
                 self.writer = None
 
-    def scalars(self, values, step):
-        if self.writer is None or step % self.every:
+    def scalars(self, values, step, force=False):
+        self.last.update(values)
+        if self.writer is None or (step % self.every and not force):
             return
         for tag, v in values.items():
             self.writer.add_scalar(tag, float(v), step)

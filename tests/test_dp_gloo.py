@@ -139,3 +139,84 @@ def test_sharded_critic_gradient_equals_global_batch():
     # both ranks hold identical parameters after the step
     for a, b in zip(res[0][2], res[1][2]):
         assert (a == b).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# Several critic-only train_steps in a row (n_critic_steps = 100: no generator iteration follows):
+# the deferred optimiser step of iteration i must be taken, with iteration i's averaged gradients,
+# before iteration i + 1 clears them. (Round 1 cleared them first: Adam then stepped over nothing.)
+def _multi_step_full(B, T, alphas, noises, real, steps):
+    import music2dance_amd.losses as L
+    from music2dance_amd.engine import Phase2Engine
+    gen, critic = _make_p2()
+    eng = Phase2Engine(gen, critic, CFG, data_parallel=False)
+    it = {"i": 0}
+    eng._noise = lambda b, t, d: noises[it["i"]]
+    orig = L.torch.rand
+    L.torch.rand = lambda *a, **k: alphas[it["i"]].clone()
+    try:
+        gen.eval()
+        for i in range(steps):
+            it["i"] = i
+            eng.train_step(real)
+        eng.flush()
+    finally:
+        L.torch.rand = orig
+    return [p.detach().clone() for p in critic.parameters()]
+
+
+def _multi_step_worker(rank, world, port, q, B, T, alphas, noises, real, steps):
+    _setup(rank, world, port)
+    import music2dance_amd.losses as L
+    from music2dance_amd.engine import Phase2Engine
+    gen, critic = _make_p2()
+    eng = Phase2Engine(gen, critic, CFG, data_parallel=True)
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    it = {"i": 0}
+    eng._noise = lambda b, t, d: noises[it["i"]][lo:hi]
+    L.torch.rand = lambda *a, **k: alphas[it["i"]][lo:hi].clone()
+    gen.eval()
+    for i in range(steps):
+        it["i"] = i
+        eng.train_step(real[lo:hi])
+    eng.flush()
+    st = eng.optim_critic.state
+    adam_steps = sorted({int(v["step"]) for v in st.values()})
+    q.put((rank, adam_steps, [p.detach().numpy().copy() for p in critic.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deferred_critic_step_is_taken_every_iteration():
+    from music2dance_amd import kernels
+    from tests.fake_backend import FakeKernels
+    B, T, steps = 4, 24, 3
+    g = torch.Generator().manual_seed(5)
+    alphas = [torch.rand(B, 1, generator=g) for _ in range(steps)]
+    noises = [torch.randn(B, T, 8, generator=g) for _ in range(steps)]
+    real = torch.rand(B, T, 69, generator=g)
+    prev = kernels.set_impl(FakeKernels())
+    try:
+        init = [p.detach().clone() for p in _make_p2()[1].parameters()]
+        full = _multi_step_full(B, T, alphas, noises, real, steps)
+    finally:
+        kernels.set_impl(prev)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_multi_step_worker, args=(r, world, port, q, B, T, alphas, noises, real, steps))
+             for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(world)]
+    [p.join(60) for p in procs]
+    moved = max(float((a - b).abs().max()) for a, b in zip(full, init))
+    assert moved > 1e-3  # three Adam steps at lr 1e-3
+    for rank, adam_steps, params in res:
+        assert adam_steps == [steps], (rank, adam_steps)
+        for a, b in zip(params, full):
+            a = torch.from_numpy(a)
+            # Adam normalises the step: rounding differences of the all-reduce order move a
+            # parameter by at most a small fraction of lr per step
+            assert torch.allclose(a, b, rtol=0, atol=2e-4), (rank, float((a - b).abs().max()))
+    for a, b in zip(res[0][2], res[1][2]):
+        assert (a == b).all()
