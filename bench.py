@@ -96,8 +96,51 @@ def cpu_baseline(sample_b=16, T=120, threads=None):
                       % (sample_b, t3 - t0, t_critic, t_gen)}
 
 
+PRESETS = {  # BASELINE.json configs[2..4] at their per-GPU shapes
+    "c3": dict(enc_type="default", batch=64, frames=120, ablated=False),
+    "c4": dict(enc_type="wavegan", batch=32, frames=120, ablated=False),  # global 256 on 8 GPUs
+    "c5": dict(enc_type="unet", batch=16, frames=300, ablated=True),     # global 128 on 8 GPUs
+}
+
+
+def baseline_tag(args):
+    key = dict(enc_type=args.enc_type, batch=args.batch, frames=args.frames, ablated=args.ablated)
+    for name, idx in (("c3", 2), ("c4", 3), ("c5", 4)):
+        if PRESETS[name] == key:
+            return " (BASELINE.json configs[%d]%s)" % (idx, "" if idx == 2 else " per-GPU shape")
+    return ""
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes
+    (this parent has made no GPU call), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.exit("bench.py: ranks failed (rank, exit code): %s" % bad)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=None, choices=sorted(PRESETS),
+                    help="BASELINE.json config preset at its per-GPU shape: c3 (default), c4 wavegan B=32, "
+                         "c5 unet T=300 ablated B=16; explicit flags below override nothing when given")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=8)
@@ -113,6 +156,11 @@ def main():
     ap.add_argument("--graphs", default="off", choices=["on", "off"],
                     help="replay each loop body's forward/backward from a captured HIP graph (Phase3Engine.enable_graphs)")
     args = ap.parse_args()
+    if args.config:
+        for k, v in PRESETS[args.config].items():
+            setattr(args, k, v)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # before anything touches the GPU
 
     from music2dance_amd import dp, kernels
     from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
@@ -121,8 +169,7 @@ def main():
     if args.same_device:
         local = 0
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the product has no CPU path")
     device = torch.device("cuda", local)
@@ -180,18 +227,16 @@ def main():
         seqs = args.steps * args.batch * world
         value = seqs / elapsed
         out = {
-            "metric": "120-frame seq/sec, phase3 WGAN-GP step, batch %d per GPU" % args.batch,
+            "metric": "%d-frame seq/sec, phase3 WGAN-GP step, batch %d per GPU" % (args.frames, args.batch),
             "value": round(value, 2), "unit": "seq/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "phase3/train.py WGAN-GP step, %s audio encoder%s, %d frames, "
                                    "batch %d per GPU%s; 1 generator iteration per 8 critic iterations"
                                    % (args.enc_type, ", ablated critic" if args.ablated else "", args.frames, args.batch,
-                                      " (BASELINE.json configs[2])" if (args.enc_type, args.frames, args.batch,
-                                                                         args.ablated) == ("default", 120, 64, False)
-                                      else ""),
+                                      baseline_tag(args)),
                        "global_batch": args.batch * world, "seq_len": args.frames,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "backend": args.backend if world > 1 else None},
             "losses_last_step": last,
         }
         if prof is not None:

@@ -79,6 +79,7 @@ def _c(t):
 class _Conv1dAct(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, act, slope):
+        ctx.set_materialize_grads(False)
         x, w, b = _c(x), _c(w), _c(b)
         y = K().conv1d_fwd(x, w, b, stride, pad, act, slope)
         ctx.save_for_backward(x, w, y if act else None)
@@ -87,6 +88,8 @@ class _Conv1dAct(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 7
         x, w, y = ctx.saved_tensors
         stride, pad, act, slope, has_bias, xkey = ctx.cfg
         mask, mslope = _mask_of(act, slope, y)
@@ -107,6 +110,7 @@ class _Conv1dBwdData(Function):
 
     @staticmethod
     def forward(ctx, gy, w, mask, L, stride, pad, mslope):
+        ctx.set_materialize_grads(False)
         gy, w = _c(gy), _c(w)
         dx = K().conv1d_bwd_data(gy, w, L, stride, pad, mask, mslope)
         ctx.save_for_backward(gy, w, mask)
@@ -116,6 +120,8 @@ class _Conv1dBwdData(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        if g is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 7
         gy, w, mask = ctx.saved_tensors
         stride, pad, mslope = ctx.cfg
         g = _c(g)
@@ -132,6 +138,7 @@ class _Conv1dBwdWeight(Function):
 
     @staticmethod
     def forward(ctx, x, gy, mask, ks, stride, pad, mslope):
+        ctx.set_materialize_grads(False)
         x, gy = _c(x), _c(gy)
         dw = K().conv1d_bwd_weight(x, gy, ks, stride, pad, mask, mslope)
         ctx.save_for_backward(x, gy, mask)
@@ -141,6 +148,8 @@ class _Conv1dBwdWeight(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        if g is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 7
         x, gy, mask = ctx.saved_tensors
         stride, pad, mslope = ctx.cfg
         g = _c(g)
@@ -157,6 +166,7 @@ class _ChannelSum(Function):
 
     @staticmethod
     def forward(ctx, gy, mask, mslope):
+        ctx.set_materialize_grads(False)
         gy = _c(gy)
         ctx.save_for_backward(mask)
         ctx.mslope = mslope
@@ -166,6 +176,8 @@ class _ChannelSum(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        if g is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 3
         (mask,) = ctx.saved_tensors
         shape = ctx.shape
         view = (1, -1, 1) if len(shape) == 3 else (1, -1)
@@ -184,6 +196,7 @@ def conv1d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0):
 class _LinearAct(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, slope):
+        ctx.set_materialize_grads(False)
         x, w, b = _c(x), _c(w), _c(b)
         y = K().gemm(0, x, w, b, act, slope)
         ctx.save_for_backward(x, w, y if act else None)
@@ -192,6 +205,8 @@ class _LinearAct(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 5
         x, w, y = ctx.saved_tensors
         act, slope, has_bias, xkey = ctx.cfg
         mask, mslope = _mask_of(act, slope, y)
@@ -212,6 +227,7 @@ class _LinearBwdData(Function):
 
     @staticmethod
     def forward(ctx, gy, w, mask, mslope):
+        ctx.set_materialize_grads(False)
         gy, w = _c(gy), _c(w)
         ctx.save_for_backward(gy, w, mask)
         ctx.mslope = mslope
@@ -220,6 +236,8 @@ class _LinearBwdData(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        if g is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 4
         gy, w, mask = ctx.saved_tensors
         g = _c(g)
         g_gy = g_w = None
@@ -235,6 +253,7 @@ class _LinearBwdWeight(Function):
 
     @staticmethod
     def forward(ctx, gy, x, mask, mslope):
+        ctx.set_materialize_grads(False)
         gy, x = _c(gy), _c(x)
         ctx.save_for_backward(gy, x, mask)
         ctx.mslope = mslope
@@ -243,6 +262,8 @@ class _LinearBwdWeight(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        if g is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 4
         gy, x, mask = ctx.saved_tensors
         g = _c(g)
         g_gy = g_x = None
@@ -265,6 +286,7 @@ def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
 class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, eps, momentum, act, slope):
+        ctx.set_materialize_grads(False)
         x, residual = _c(x), _c(residual)
         y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, training, eps, momentum, act,
                                      slope, residual)
@@ -275,6 +297,8 @@ class _BatchNormAct(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
+        if gy is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 11
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         training, act, slope, has_res = ctx.cfg
         if not training:
@@ -295,6 +319,7 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
 class _GRULayer(Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, lengths, save):
+        ctx.set_materialize_grads(False)
         x, w_ih, w_hh = _c(x), _c(w_ih), _c(w_hh)
         B, T, I = x.shape
         H = w_hh.shape[1]
@@ -308,6 +333,8 @@ class _GRULayer(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
+        if dout is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 7
         x, w_ih, w_hh, out, saved, lengths = ctx.saved_tensors
         B, T, I = x.shape
         H = w_hh.shape[1]
@@ -328,6 +355,7 @@ class _GRUStack(Function):
 
     @staticmethod
     def forward(ctx, x, lengths, save, *params):
+        ctx.set_materialize_grads(False)
         L = len(params) // 4
         w_ih = [_c(params[4 * l]) for l in range(L)]
         w_hh = [_c(params[4 * l + 1]) for l in range(L)]
@@ -348,6 +376,8 @@ class _GRUStack(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
+        if dout is None:
+            return (None,) * (3 + 4 * ctx.L)
         L = ctx.L
         t = ctx.saved_tensors
         x, lengths = t[0], t[1]
@@ -389,6 +419,7 @@ def gp_interpolate(real2d, fake2d, alpha):
 class _GPPenalty(Function):
     @staticmethod
     def forward(ctx, g, lp):
+        ctx.set_materialize_grads(False)
         g = _c(g)
         pen, norms = K().gp_penalty_fwd(g, lp)
         ctx.save_for_backward(g, norms)
@@ -398,6 +429,8 @@ class _GPPenalty(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
+        if gout is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 2
         g, norms = ctx.saved_tensors
         return K().gp_penalty_bwd(g, norms, _c(gout), ctx.lp), None
 
@@ -411,6 +444,7 @@ def gp_penalty(grad2d, lp=False):
 class _L1Mean(Function):
     @staticmethod
     def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)
         a, b = _c(a), _c(b)
         ctx.save_for_backward(a, b)
         return K().l1_mean_fwd(a, b)
@@ -418,6 +452,8 @@ class _L1Mean(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
+        if gout is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 2
         a, b = ctx.saved_tensors
         gout = _c(gout)
         ga = K().l1_mean_bwd(a, b, gout) if ctx.needs_input_grad[0] else None
@@ -433,6 +469,7 @@ def l1_mean(a, b):
 class _TVMean(Function):
     @staticmethod
     def forward(ctx, store, B, C, T, sb, sc, st):
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(store)
         ctx.cfg = (B, C, T, sb, sc, st)
         return K().tv_mean_fwd(store, B, C, T, sb, sc, st)
@@ -440,6 +477,8 @@ class _TVMean(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
+        if gout is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 7
         (store,) = ctx.saved_tensors
         return (K().tv_mean_bwd(store, _c(gout), *ctx.cfg),) + (None,) * 6
 
@@ -459,6 +498,7 @@ def tv_mean(seq):
 class _MaxPool2(Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)
         x = _c(x)
         ctx.save_for_backward(x)
         return K().maxpool2_fwd(x)
@@ -466,6 +506,8 @@ class _MaxPool2(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
+        if gy is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 1
         (x,) = ctx.saved_tensors
         return K().maxpool2_bwd(x, _c(gy))
 
@@ -473,11 +515,14 @@ class _MaxPool2(Function):
 class _Upsample2(Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)
         return K().upsample2_fwd(_c(x))
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
+        if gy is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
+            return (None,) * 1
         return K().upsample2_bwd(_c(gy))
 
 

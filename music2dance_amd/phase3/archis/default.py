@@ -11,6 +11,7 @@ iteration (losses.py:29, phase3/train.py:204-211), so inside that context its co
 computed once and shared (identical scores).
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -339,8 +340,39 @@ class SequenceDiscriminator(nn.Module):
             self._share[key] = hit
         return hit[1]
 
+    # The pose branch and the audio branch meet only at fc1: the pose branch (small launches that
+    # leave most CUs idle between dependent kernels) runs on a side stream under the audio branch's
+    # large convolutions. Autograd replays each node's backward on the stream of its forward, so
+    # the first, second and final backward passes overlap the same way.
+    overlap_branches = os.environ.get("M2D_BRANCH_OVERLAP", "1") != "0"
+
+    def _stick_code(self, x):
+        dev = x.device
+        if dev.type != "cuda" or not self.overlap_branches or torch.cuda.is_current_stream_capturing():
+            return self.stick_d(x)
+        if getattr(self, "_stick_stream", None) is None:
+            self._stick_stream = torch.cuda.Stream(device=dev)
+        side, cur = self._stick_stream, torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            code = self.stick_d(x)
+        x.record_stream(side)
+        self._join = (side, cur, code)
+        return code
+
+    def _joined(self, code):
+        j = getattr(self, "_join", None)
+        if j is not None and j[2] is code:
+            side, cur, _ = j
+            cur.wait_stream(side)
+            code.record_stream(cur)
+            self._join = None
+        return code
+
     def forward(self, x, c):
-        code = torch.cat((self.stick_d(x), self._audio_code(c)), -1)
+        stick = self._stick_code(x)  # enqueued first, on the side stream
+        acode = self._audio_code(c)
+        code = torch.cat((self._joined(stick), acode), -1)
         return self.fc2(self.fc1(code, act=ops.ACT_RELU))
 
     def score_pair(self, x_a, x_b, c):
@@ -348,8 +380,9 @@ class SequenceDiscriminator(nn.Module):
         has no cross-sample coupling, so the scores are the per-call ones; twice the columns
         per launch fill the chip better) and one evaluation of the audio branch."""
         n = x_a.size(0)
-        stick = self.stick_d(torch.cat((x_a, x_b), 0))
+        stick = self._stick_code(torch.cat((x_a, x_b), 0))
         acode = self._audio_code(c)
+        stick = self._joined(stick)
         code = torch.cat((stick, torch.cat((acode, acode), 0)), -1)
         s = self.fc2(self.fc1(code, act=ops.ACT_RELU))
         return s[:n], s[n:]
