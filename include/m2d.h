@@ -51,9 +51,12 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const 
                    int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
                    const float* residual, const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes,
                    void* stream);
+/* `out_mask` (optional, shape of dx): the result is multiplied by (mask>0 ? 1 : out_mask_slope) in the
+ * epilogue - the activation derivative of the layer that produced x, so that a chain of fused
+ * conv + ReLU layers hands each other gradients that are already masked (no masked operand loads). */
 int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
-                        int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
-                        size_t ws_bytes, void* stream);
+                        int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                        const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream);
 int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int L, int Cout,
                           int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
                           size_t ws_bytes, void* stream);

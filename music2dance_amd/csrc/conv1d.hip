@@ -206,15 +206,15 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const 
 // `w_packed` (optional): the (Cin, ks, Cout) image of w from m2d_conv1d_pack_weights.
 // `dy_mask` (optional, shape of dy): dy is read as dy * (mask>0 ? 1 : dy_mask_slope).
 int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
-                        int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
-                        size_t ws_bytes, void* stream) {
+                        int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                        const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_data: bad shape");
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout) ||
       !fits_i32((long long)Cout * Cin * ks))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_bwd_data: tensor exceeds 2^31 elements");
-  if (m2d_thin_applicable(Cin, Cout, ks, stride))
+  if (m2d_thin_applicable(Cin, Cout, ks, stride) && !out_mask)
     return m2d_thin_bwd_data(dy, w, dx, B, L, Cout, ks, stride, pad, Lout, dy_mask, dy_mask_slope,
                              (hipStream_t)stream);
   M2dGemmParams p;
@@ -232,6 +232,8 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
     p.A.mask_slope = dy_mask_slope;
     m2d_operand_plain(p.B, w, p.N, 1, Cin * ks, (long long)Cout * Cin * ks);
     m2d_outmap_plain(p.O, dx, Cin * ks, 1);
+    p.O.mask = out_mask;
+    p.O.mask_slope = out_mask_slope;
     return m2d_gemm_launch(p, true, false, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }
   if (!w_packed) {
@@ -295,6 +297,8 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
   p.O.c_lo_stride = stride;
   p.O.c_pos_mul = stride;
   p.O.c_lim = L;
+  p.O.mask = out_mask;
+  p.O.mask_slope = out_mask_slope;
   if (stride == 1) {
     // single phase: resolve the phase parameters here (r = 0, taps = ks, q in [pad, L-1+pad]) so the
     // launch is an ordinary GEMM and may be split along K (the TCN critic's small grids need it)

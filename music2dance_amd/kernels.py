@@ -164,19 +164,22 @@ class HipKernels:
         _lib.check(rc, "m2d_conv1d_fwd")
         return y
 
-    def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0):
-        dev = _chk(dy, w, dy_mask)
+    def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0, out_mask=None,
+                        out_mask_slope=0.0):
+        dev = _chk(dy, w, dy_mask, out_mask)
         B, Cout, Lout = dy.shape
         Cout2, Cin, ks = w.shape
         assert Cout == Cout2 and Lout == conv_out_len(L, ks, stride, pad)
         dx = torch.empty((B, Cin, L), dtype=torch.float32, device=dev)
         h = _lib.lib()
         full_length = Lout == 1 and pad == 0 and L == ks
+        if out_mask is not None and self._thin(Cin, ks, stride):
+            raise _lib.M2dError("conv1d_bwd_data: out_mask is not supported on the thin (Cin = 1, k25 s4) path")
         wp = None if (full_length or self._thin(Cin, ks, stride)) else self.packed_weights(w)[1]
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 1, B, Cin, L, Cout, ks, stride, pad), dev)
         with _on(dev):
             rc = h.m2d_conv1d_bwd_data(_ptr(dy), _ptr(w), _ptr(wp), _ptr(dx), B, Cin, L, Cout, ks, stride, pad,
-                                       _ptr(dy_mask), dy_mask_slope, _ptr(ws),
+                                       _ptr(dy_mask), dy_mask_slope, _ptr(out_mask), out_mask_slope, _ptr(ws),
                                        0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_conv1d_bwd_data")
         return dx

@@ -40,10 +40,13 @@ def to_device_async(t, device):
 class Conv1d(nn.Conv1d):
     """nn.Conv1d (dilation 1, groups 1, zero padding) on the implicit-GEMM engine."""
 
-    def forward(self, x, act=ops.ACT_NONE, slope=0.0):
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0, in_act=None, out_pm=False):
+        """in_act / out_pm: the pre-masked gradient contract of ops.conv1d - only for a conv whose
+        input comes straight from a fused conv + activation that has no other consumer (in_act, with
+        out_pm on that producer)."""
         if self.dilation[0] != 1 or self.groups != 1 or self.padding_mode != "zeros":
             raise NotImplementedError("m2d Conv1d: dilation / groups / non-zero padding are not on the hot path")
-        return ops.conv1d(x, self.weight, self.bias, self.stride[0], self.padding[0], act, slope)
+        return ops.conv1d(x, self.weight, self.bias, self.stride[0], self.padding[0], act, slope, in_act, out_pm)
 
 
 class Linear(nn.Linear):

@@ -17,6 +17,7 @@ derivative needs an extra elementwise pass over HBM.
 Generator-only ops (BatchNorm, GRU, pooling, losses) are first-order.
 """
 import contextlib
+import os
 
 import torch
 from torch.autograd import Function
@@ -76,120 +77,154 @@ def _c(t):
 
 
 # --------------------------------------------------------------------------------------- conv1d
+# Pre-masked gradients. y = act(conv(x)) needs h = gy * act'(y) in its backward. Read through a
+# masked operand that costs the GEMM engine two loads per element in every tile that re-reads it
+# (measured 10-30 % on the audio critic's layers). In a chain of fused conv + activation layers the
+# consumer of y is the next conv, whose backward-data kernel can multiply its result by act'(its
+# input) in the epilogue, once per element. Two flags, set by the MODULE that owns the chain
+# (the op cannot see who consumes its output):
+#   out_pm: every gradient that reaches this op's output is already multiplied by act'(y)
+#           (all consumers of y are convs called with in_act);
+#   in_act: (act, slope) of the op that produced x: every gradient this op returns for x - at any
+#           order of differentiation - is multiplied by act'(x) in the producing kernel's epilogue.
+# Activations are piecewise linear, so masks carry no gradient, and for every node below the rule
+# is the same at first and second order: gradients w.r.t. `x` get the in_act epilogue, gradients
+# w.r.t. `gy` / `h` get the act'(y) epilogue (that one is plain calculus: h = gy * act'(y)), and an
+# operand is read through a mask only when nobody pre-multiplied it.
+_PREMASK = os.environ.get("M2D_PREMASK", "1") != "0"  # dev switch for A/B timing: 0 = masked operand loads
+
+
+def _slope_of(act, slope):
+    return slope if act == ACT_LEAKY else 0.0
+
+
 class _Conv1dAct(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, slope):
+    def forward(ctx, x, w, b, stride, pad, act, slope, in_act, out_pm):
         ctx.set_materialize_grads(False)
         x, w, b = _c(x), _c(w), _c(b)
         y = K().conv1d_fwd(x, w, b, stride, pad, act, slope)
         ctx.save_for_backward(x, w, y if act else None)
-        ctx.cfg = (stride, pad, act, slope, b is not None, x.data_ptr())
+        ctx.cfg = (stride, pad, act, slope, b is not None, x.data_ptr(), in_act, bool(out_pm) and act != ACT_NONE)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         if gy is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
-            return (None,) * 7
+            return (None,) * 9
         x, w, y = ctx.saved_tensors
-        stride, pad, act, slope, has_bias, xkey = ctx.cfg
-        mask, mslope = _mask_of(act, slope, y)
+        stride, pad, act, slope, has_bias, xkey, in_act, out_pm = ctx.cfg
+        ymask, yslope = _mask_of(act, slope, y)
+        hmask = None if out_pm else ymask  # operand mask only when the gradient is not pre-multiplied
+        xmask, xslope = (x, _slope_of(*in_act)) if in_act else (None, 0.0)
         gy = _c(gy)
         gx = gw = gb = None
         if ctx.needs_input_grad[0] and xkey not in _state["dead_inputs"]:
-            gx = _Conv1dBwdData.apply(gy, w, mask, x.shape[2], stride, pad, mslope)
+            gx = _Conv1dBwdData.apply(gy, w, hmask, ymask, xmask, x.shape[2], stride, pad, yslope, xslope)
         if not _state["inputs_only"]:
             if ctx.needs_input_grad[1]:
-                gw = _Conv1dBwdWeight.apply(x, gy, mask, w.shape[2], stride, pad, mslope)
+                gw = _Conv1dBwdWeight.apply(x, gy, hmask, ymask, xmask, w.shape[2], stride, pad, yslope, xslope)
             if has_bias and ctx.needs_input_grad[2]:
-                gb = _ChannelSum.apply(gy, mask, mslope)
-        return gx, gw, gb, None, None, None, None
+                gb = _ChannelSum.apply(gy, hmask, ymask, yslope)
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 class _Conv1dBwdData(Function):
-    """dx = conv_transpose(gy * act'(y), W). Differentiable w.r.t. gy and W."""
+    """dx = act_in'(x) * conv_transpose(h, W), h = gy * act'(y) (read through `hmask`, or already
+    multiplied when hmask is None). Differentiable w.r.t. gy and W."""
 
     @staticmethod
-    def forward(ctx, gy, w, mask, L, stride, pad, mslope):
+    def forward(ctx, gy, w, hmask, ymask, xmask, L, stride, pad, yslope, xslope):
         ctx.set_materialize_grads(False)
         gy, w = _c(gy), _c(w)
-        dx = K().conv1d_bwd_data(gy, w, L, stride, pad, mask, mslope)
-        ctx.save_for_backward(gy, w, mask)
-        ctx.cfg = (stride, pad, mslope)
+        dx = K().conv1d_bwd_data(gy, w, L, stride, pad, hmask, yslope, xmask, xslope)
+        ctx.save_for_backward(gy, w, hmask, ymask)
+        ctx.cfg = (stride, pad, yslope)
         return dx
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        if g is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
-            return (None,) * 7
-        gy, w, mask = ctx.saved_tensors
-        stride, pad, mslope = ctx.cfg
+        # g arrives multiplied by act_in'(x) whenever xmask was applied: its producers are the
+        # second-order nodes of the layer that made x, which all end in that layer's act' epilogue
+        if g is None:
+            return (None,) * 10
+        gy, w, hmask, ymask = ctx.saved_tensors
+        stride, pad, yslope = ctx.cfg
         g = _c(g)
         g_gy = g_w = None
         if ctx.needs_input_grad[0]:
-            g_gy = K().conv1d_fwd(g, w, None, stride, pad, 0, 0.0, None, mask, mslope)
+            g_gy = K().conv1d_fwd(g, w, None, stride, pad, 0, 0.0, None, ymask, yslope)
         if ctx.needs_input_grad[1]:
-            g_w = K().conv1d_bwd_weight(g, gy, w.shape[2], stride, pad, mask, mslope)
-        return g_gy, g_w, None, None, None, None, None
+            g_w = K().conv1d_bwd_weight(g, gy, w.shape[2], stride, pad, hmask, yslope)
+        return (g_gy, g_w) + (None,) * 8
 
 
 class _Conv1dBwdWeight(Function):
-    """dW = correlate(x, gy * act'(y)). Differentiable w.r.t. x and gy."""
+    """dW = correlate(x, h), h = gy * act'(y). Differentiable w.r.t. x and gy."""
 
     @staticmethod
-    def forward(ctx, x, gy, mask, ks, stride, pad, mslope):
+    def forward(ctx, x, gy, hmask, ymask, xmask, ks, stride, pad, yslope, xslope):
         ctx.set_materialize_grads(False)
         x, gy = _c(x), _c(gy)
-        dw = K().conv1d_bwd_weight(x, gy, ks, stride, pad, mask, mslope)
-        ctx.save_for_backward(x, gy, mask)
-        ctx.cfg = (stride, pad, mslope)
+        dw = K().conv1d_bwd_weight(x, gy, ks, stride, pad, hmask, yslope)
+        ctx.save_for_backward(x, gy, hmask, ymask, xmask)
+        ctx.cfg = (stride, pad, yslope, xslope)
         return dw
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        if g is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
-            return (None,) * 7
-        x, gy, mask = ctx.saved_tensors
-        stride, pad, mslope = ctx.cfg
+        if g is None:
+            return (None,) * 10
+        x, gy, hmask, ymask, xmask = ctx.saved_tensors
+        stride, pad, yslope, xslope = ctx.cfg
         g = _c(g)
         g_x = g_gy = None
         if ctx.needs_input_grad[0]:
-            g_x = K().conv1d_bwd_data(gy, g, x.shape[2], stride, pad, mask, mslope)
+            g_x = K().conv1d_bwd_data(gy, g, x.shape[2], stride, pad, hmask, yslope, xmask, xslope)
         if ctx.needs_input_grad[1]:
-            g_gy = K().conv1d_fwd(x, g, None, stride, pad, 0, 0.0, None, mask, mslope)
-        return g_x, g_gy, None, None, None, None, None
+            g_gy = K().conv1d_fwd(x, g, None, stride, pad, 0, 0.0, None, ymask, yslope)
+        return (g_x, g_gy) + (None,) * 8
 
 
 class _ChannelSum(Function):
-    """sum over (batch, length) of gy * act'(y): bias gradients."""
+    """sum over (batch, length) of h = gy * act'(y): bias gradients (`hmask` None: gy is already h)."""
 
     @staticmethod
-    def forward(ctx, gy, mask, mslope):
+    def forward(ctx, gy, hmask, ymask, mslope):
         ctx.set_materialize_grads(False)
         gy = _c(gy)
-        ctx.save_for_backward(mask)
+        ctx.save_for_backward(ymask)
         ctx.mslope = mslope
         ctx.shape = gy.shape
-        return K().channel_sums(gy, mask, mslope)
+        return K().channel_sums(gy, hmask, mslope)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        if g is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
-            return (None,) * 3
-        (mask,) = ctx.saved_tensors
+        if g is None:
+            return (None,) * 4
+        (ymask,) = ctx.saved_tensors
         shape = ctx.shape
         view = (1, -1, 1) if len(shape) == 3 else (1, -1)
         out = g.view(view).expand(shape)
-        if mask is not None:
-            out = out * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, ctx.mslope))
-        return out.contiguous(), None, None
+        if ymask is not None:
+            out = out * torch.where(ymask > 0, torch.ones_like(ymask), torch.full_like(ymask, ctx.mslope))
+        return out.contiguous(), None, None, None
 
 
-def conv1d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0):
-    """nn.Conv1d forward with optional fused ReLU / LeakyReLU, twice differentiable."""
-    return _Conv1dAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope))
+def conv1d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, in_act=None, out_pm=False):
+    """nn.Conv1d forward with optional fused ReLU / LeakyReLU, twice differentiable.
+    in_act / out_pm: the pre-masked gradient contract described above (module-level promise)."""
+    if not _PREMASK:
+        in_act, out_pm = None, False
+    if in_act is not None:
+        in_act = (int(in_act[0]), float(in_act[1]))
+        if in_act[0] == ACT_NONE:
+            in_act = None
+    return _Conv1dAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope), in_act,
+                            bool(out_pm))
 
 
 # --------------------------------------------------------------------------------------- linear
@@ -218,7 +253,7 @@ class _LinearAct(Function):
             if ctx.needs_input_grad[1]:
                 gw = _LinearBwdWeight.apply(gy, x, mask, mslope)
             if has_bias and ctx.needs_input_grad[2]:
-                gb = _ChannelSum.apply(gy, mask, mslope)
+                gb = _ChannelSum.apply(gy, mask, mask, mslope)
         return gx, gw, gb, None, None
 
 

@@ -83,7 +83,9 @@ class TemporalBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        h = self.conv2(self.conv1(x, act=ops.ACT_RELU), act=ops.ACT_RELU)
+        # conv1 -> conv2 is a sole-consumer edge: pre-masked gradients (ops.conv1d, in_act / out_pm)
+        h = self.conv2(self.conv1(x, act=ops.ACT_RELU, out_pm=True), act=ops.ACT_RELU,
+                       in_act=(ops.ACT_RELU, 0.0))
         return x + h
 
 

@@ -28,9 +28,12 @@ def _descending(lengths):
     return ls
 
 
-def _head(module, conv, x):
+RELU_IN = (ops.ACT_RELU, 0.0)  # "my input is the sole-consumer output of a fused conv + ReLU" (ops.conv1d)
+
+
+def _head(module, conv, x, in_act=None):
     """last conv of an encoder / critic branch followed by the 'id'|'relu'|'tanh' switch"""
-    y = conv(x, act=module._head_act)
+    y = conv(x, act=module._head_act, in_act=in_act)
     return torch.tanh(y) if module._head_tanh else y
 
 
@@ -92,7 +95,9 @@ class TemporalBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        h = self.conv2(self.conv1(x, act=ops.ACT_RELU), act=ops.ACT_RELU)
+        # conv1's output feeds conv2 only: conv2's backward hands conv1 a gradient already multiplied
+        # by relu'(conv1 output); conv2's own output also feeds the residual add, so it keeps its mask
+        h = self.conv2(self.conv1(x, act=ops.ACT_RELU, out_pm=True), act=ops.ACT_RELU, in_act=RELU_IN)
         return x + h
 
 
@@ -301,9 +306,12 @@ class AudioDiscriminator(nn.Module):
         self.activ, self._head_act, self._head_tanh = head_activation(activ)
 
     def forward(self, x):
-        for conv in (self.l1, self.l2, self.l3, self.l4, self.l5):
-            x = conv(x, act=ops.ACT_RELU)
-        return _head(self, self.l6, x).squeeze(-1)
+        # a pure chain: every layer's output has exactly one consumer, the next conv, so gradients
+        # travel pre-multiplied by relu' (epilogue of the consumer's backward-data kernel)
+        x = self.l1(x, act=ops.ACT_RELU, out_pm=True)
+        for conv in (self.l2, self.l3, self.l4, self.l5):
+            x = conv(x, act=ops.ACT_RELU, in_act=RELU_IN, out_pm=True)
+        return _head(self, self.l6, x, in_act=RELU_IN).squeeze(-1)
 
 
 class SequenceDiscriminator(nn.Module):

@@ -44,10 +44,14 @@ class FakeKernels:
             y = y * _mf(out_mask, out_mask_slope)
         return y
 
-    def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0):
+    def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0, out_mask=None,
+                        out_mask_slope=0.0):
         if dy_mask is not None:
             dy = dy * _mf(dy_mask, dy_mask_slope)
-        return torch.nn.grad.conv1d_input((dy.shape[0], w.shape[1], L), w, dy, stride=stride, padding=pad)
+        dx = torch.nn.grad.conv1d_input((dy.shape[0], w.shape[1], L), w, dy, stride=stride, padding=pad)
+        if out_mask is not None:
+            dx = dx * _mf(out_mask, out_mask_slope)
+        return dx
 
     def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0):
         if dy_mask is not None:

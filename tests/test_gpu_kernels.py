@@ -126,7 +126,7 @@ def test_conv1d_cabi_without_packed_weights():
     nws = h.m2d_conv1d_workspace_bytes(1, B, Cin, L, Cout, ks, s, p)
     ws = torch.empty(nws // 4 + 1, device=DEV)
     rc = h.m2d_conv1d_bwd_data(dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, Cin, L, Cout, ks, s, p, None, 0.0,
-                               ws.data_ptr(), nws, st)
+                               None, 0.0, ws.data_ptr(), nws, st)
     assert rc == 0, h.m2d_last_error()
     x64 = x.cpu().double().requires_grad_(True)
     (gx,) = torch.autograd.grad(F.conv1d(x64, w.cpu().double(), None, stride=s, padding=p), x64, dy.cpu().double())
@@ -189,6 +189,16 @@ def test_conv1d_masks_and_epilogue(case):
     assert rel_err(dx, gx) < 2e-5
     dw = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p, dy_mask=mask.to(DEV), dy_mask_slope=0.0)
     assert rel_err(dw, gw) < 3e-5
+    # epilogue mask on backward-data (shape of dx), with and without the operand mask, slope 0.2
+    if not (Cin == 1 and ks == 25 and s == 4):
+        om = gen(B, Cin, L, seed=6)
+        omf = torch.where(om.double() > 0, torch.ones((), dtype=torch.float64), torch.full((), 0.2, dtype=torch.float64))
+        dx = K().conv1d_bwd_data(dy.to(DEV), wd, L, s, p, dy_mask=mask.to(DEV), dy_mask_slope=0.0,
+                                 out_mask=om.to(DEV), out_mask_slope=0.2)
+        assert rel_err(dx, gx * omf) < 2e-5
+        (gx_plain,) = torch.autograd.grad(F.conv1d(x64, w64, None, stride=s, padding=p), x64, dy.double())
+        dx = K().conv1d_bwd_data(dy.to(DEV), wd, L, s, p, out_mask=om.to(DEV), out_mask_slope=0.2)
+        assert rel_err(dx, gx_plain * omf) < 2e-5
 
 
 GEMM_CASES = [(64, 128, 200), (7680, 256, 250), (3840, 720, 250), (33, 69, 256), (1, 1, 128), (100, 1, 128),
