@@ -6,7 +6,7 @@ golden fixtures, through the same code path on two kernel layers:
                  wiring incl. double backward, module structure, loops) without a GPU.
 
 Tolerances as in test_oracle_golden.py: 1e-4 abs on poses / scores / penalties (the
-north_star's per-joint bound), 2e-3 rel on gradient norms, 2e-2 rel on 8-step loss traces.
+north_star's per-joint bound), 2e-3 rel on gradient norms, 2e-3 rel on 8-step loss traces.
 """
 import os
 
@@ -22,6 +22,16 @@ from music2dance_amd.phase1.archis import residual as p1
 from music2dance_amd.phase2.archis import default as p2
 from music2dance_amd.phase3.archis import default as p3
 from tests.golden import patterns as P
+
+# 8-step loss traces, relative (+1e-3 absolute). Measured against the fixtures: <= 1e-4 on the CPU
+# stand-in, <= ~1e-3 on HIP (other summation orders; Adam turns a 1e-7 gradient difference into an
+# O(lr) parameter difference only where |g| ~ eps, which the synthetic weights do not have). The
+# oracle run in fp64 tracks its own fp32 run to 1e-6 over these 8 steps, so nothing here is
+# "amplification": round 1's 2e-2 was simply loose.
+TRACE_RTOL = 2e-3
+# Phase 2 (WGAN-LP): product and oracle agree with each other but BOTH sit 1.1e-2 from the reference at
+# one of the 8 iterations - the LP term max(0, |g| - 1)^2 has a kink that a 1e-7 difference can cross.
+TRACE_RTOL_P2 = 2e-2
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -156,8 +166,8 @@ def test_p1_trace(dev):
         if "loss_gen" in out:
             lg.append(out["loss_gen"].item())
     eng.flush()
-    close(np.array(lc), fx["trace_loss_critic"], 1e-3, 2e-2)
-    close(np.array(lg), fx["trace_loss_gen"], 1e-3, 2e-2)
+    close(np.array(lc), fx["trace_loss_critic"], 1e-3, TRACE_RTOL)
+    close(np.array(lg), fx["trace_loss_gen"], 1e-3, TRACE_RTOL)
     close(np.array(lc[:1]), fx["trace_loss_critic"][:1], 1e-4)
     sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=1e-4, adam_steps=1)
     sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=1e-4, adam_steps=6)
@@ -215,7 +225,7 @@ def test_p2_trace(dev):
                 tr[k].append(out[k].item())
     eng.flush()
     for k in tr:
-        close(np.array(tr[k]), fx["trace_" + k], 1e-3, 2e-2)
+        close(np.array(tr[k]), fx["trace_" + k], 1e-3, TRACE_RTOL_P2)
     close(np.array(tr["loss_critic"][:1]), fx["trace_loss_critic"][:1], 1e-4)
     assert len(tr["loss_gen"]) == 1
     sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=5e-4, adam_steps=1)
@@ -302,7 +312,7 @@ def test_p3_trace(dev, case):
     eng.flush()
     for k, fk in (("loss_critic", "loss_critic"), ("gp", "gp"), ("w_dist", "w_dist"), ("loss_gen", "loss_gen"),
                   ("l1_loss_train", "err_l1")):
-        close(np.array(tr[k]), fx["trace_" + fk], 1e-3, 2e-2)
+        close(np.array(tr[k]), fx["trace_" + fk], 1e-3, TRACE_RTOL)
     close(np.array(tr["loss_critic"][:1]), fx["trace_loss_critic"][:1], 2e-4)
     assert len(tr["loss_gen"]) == 1
     sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=2e-4, adam_steps=1)
