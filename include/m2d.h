@@ -57,9 +57,11 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const 
 int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
                         int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
                         const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream);
-int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int L, int Cout,
-                          int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
-                          size_t ws_bytes, void* stream);
+/* `dbias` (optional, Cout floats): sum over (batch, length) of dy (masked like dy) - the bias gradient -
+ * from the same launch (an all-ones column appended to the x operand), instead of a second pass over dy. */
+int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
+                          int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                          void* ws, size_t ws_bytes, void* stream);
 /* The GEMMs behind forward / backward-data contract over (tap, channel) and read the weights
  * through packed images: w_fwd (Cout, ks, Cin) and w_bwd (Cin, ks, Cout) of w (Cout, Cin, ks).
  * `w_packed` above is the matching image, or NULL: the call then packs into its workspace.

@@ -27,9 +27,9 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
                  hipStream_t stream);
 int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, int Cout, int ks, int stride,
                       int pad, int Lout, const float* dy_mask, float dy_mask_slope, hipStream_t stream);
-int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L, int Cout, int ks, int stride,
-                        int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes,
-                        hipStream_t stream);
+int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int L, int Cout, int ks,
+                        int stride, int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws,
+                        size_t ws_bytes, hipStream_t stream);
 
 // Forward conv as a GEMM. Cin >= 16: K ordered (tap, channel) - hi = tap, lo = ci - over the
 // packed weights wp (Cout, ks, Cin): every 16-chunk sits on one tap, so the padding window is
@@ -325,17 +325,19 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
 
 // Replaces the weight-gradient half of convolution_backward. K = (sample, position) is the long
 // dimension (hi = n, lo = l), so the launch is split-K with a deterministic slab reduction.
-int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int L, int Cout,
-                          int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope, void* ws,
-                          size_t ws_bytes, void* stream) {
+// `dbias` (optional, Cout floats): the bias gradient sum_{n,l} dy[n,co,l] (masked like dy) from the
+// same launch - one all-ones column appended to the x operand - instead of a second pass over dy.
+int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
+                          int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                          void* ws, size_t ws_bytes, void* stream) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight: bad shape");
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_bwd_weight: tensor exceeds 2^31 elements");
   if (m2d_thin_applicable(Cin, Cout, ks, stride))
-    return m2d_thin_bwd_weight(x, dy, dw, B, L, Cout, ks, stride, pad, Lout, dy_mask, dy_mask_slope, ws, ws_bytes,
-                               (hipStream_t)stream);
+    return m2d_thin_bwd_weight(x, dy, dw, dbias, B, L, Cout, ks, stride, pad, Lout, dy_mask, dy_mask_slope, ws,
+                               ws_bytes, (hipStream_t)stream);
   M2dGemmParams p;
   memset(&p, 0, sizeof(p));
   p.M = Cout;
@@ -389,6 +391,13 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
   p.A.mask = dy_mask;
   p.A.mask_slope = dy_mask_slope;
   m2d_outmap_plain(p.O, dw, Cin * ks, 1);
+  if (dbias) {
+    // column Cin*ks of the x operand reads as ones: dbias[co] = sum_k dy[co, k]
+    p.N = Cin * ks + 1;
+    b.ones_row_p1 = Cin * ks + 1;
+    p.O.col_out = dbias;
+    p.O.redirect_col_p1 = Cin * ks + 1;
+  }
   return m2d_gemm_launch(p, a_kfast, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes, (hipStream_t)stream,
                          "m2d_conv1d_bwd_weight");
 }
@@ -411,7 +420,11 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
     if (stride == 1) return m2d_gemm_plan(Cin, B * L, m2d_chunks(ks, Cout), 1, true).ws_bytes + pack_bytes(Cout, Cin, ks);
     return pack_bytes(Cout, Cin, ks);
   }
-  return m2d_gemm_plan(Cout, Cin * ks, Lout >= M2D_BK ? m2d_chunks(B, Lout) : m2d_chunks(Lout, B), 1, true).ws_bytes;
+  // sized for the launch with the bias column (one more column), which is never smaller
+  const int nch = Lout >= M2D_BK ? m2d_chunks(B, Lout) : m2d_chunks(Lout, B);
+  const size_t a = m2d_gemm_plan(Cout, Cin * ks, nch, 1, true).ws_bytes;
+  const size_t c = m2d_gemm_plan(Cout, Cin * ks + 1, nch, 1, true).ws_bytes;
+  return a > c ? a : c;
 }
 
 // Dense row-major GEMMs behind nn.Linear (phase3/archis/default.py:153,161,176-177,256-257;

@@ -13,7 +13,6 @@
 #include "m2d_common.h"
 
 #define THIN_MAX_K 32
-#define THIN_MAX_W 2048  // Cout * k floats of LDS
 
 struct ThinArgs {
   const float* x;      // (B, 1, L)
@@ -22,69 +21,17 @@ struct ThinArgs {
   const float* dy;     // (B, Cout, Lout)   bwd
   const float* mask;   // optional
   float* out;          // fwd: y; bwd_data: dx; bwd_weight: partial slabs
+  float* out2;         // bwd_weight: bias-gradient partial slabs (optional)
   int B, L, Cout, ks, stride, pad, Lout;
   int act;
   float slope, mask_slope;
   int chunk;           // bwd_weight: positions per block
 };
 
-// Register blocking: every thread owns P CONSECUTIVE output positions, so that one weight
-// read (an LDS broadcast) feeds P FMAs and the input windows of neighbouring positions,
-// which overlap by k - stride samples, are loaded once.
-template <int KS, int S, int P>
-__global__ void __launch_bounds__(256) thin_fwd_kernel(const ThinArgs a) {
-  // weights are read with wave-uniform indices straight from global memory: hipcc turns
-  // them into scalar (s_load) loads served by the scalar cache, so the FMAs take the weight
-  // as an SGPR operand and no LDS or vector-memory issue slot is spent on them
-  const float* __restrict__ wl = a.w;
-  constexpr int XW = KS + S * (P - 1);
-  const int n = blockIdx.y;
-  const int l0 = (blockIdx.x * 256 + threadIdx.x) * P;
-  if (l0 >= a.Lout) return;
-  const float* xr = a.x + (size_t)n * a.L;
-  float xw[XW];
-  const int base = l0 * S - a.pad;
-#pragma unroll
-  for (int k = 0; k < XW; ++k) {
-    const int pos = base + k;
-    xw[k] = (pos >= 0 && pos < a.L) ? xr[pos] : 0.f;
-  }
-  const size_t orow = (size_t)n * a.Cout * a.Lout + l0;
-  const bool vec = (P == 4) && (a.Lout % 4 == 0);
-  for (int co = 0; co < a.Cout; ++co) {
-    float acc[P];
-#pragma unroll
-    for (int j = 0; j < P; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      const float wv = wl[co * KS + k];
-#pragma unroll
-      for (int j = 0; j < P; ++j) acc[j] += wv * xw[k + S * j];
-    }
-    const float bv = a.bias ? a.bias[co] : 0.f;
-    const size_t o = orow + (size_t)co * a.Lout;
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-      float v = acc[j] + bv;
-      if (a.act == 1) v = v > 0.f ? v : 0.f;
-      else if (a.act == 2) v = v > 0.f ? v : v * a.slope;
-      if (a.mask && l0 + j < a.Lout) v *= (a.mask[o + j] > 0.f ? 1.f : a.mask_slope);
-      acc[j] = v;
-    }
-    if (vec) {
-      *reinterpret_cast<float4*>(a.out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < P; ++j)
-        if (l0 + j < a.Lout) a.out[o + j] = acc[j];
-    }
-  }
-}
-
 // dx[n, s*q + r - pad] = sum_co sum_t W[co, r + s*t] * dy[n, co, q - t]; thread = P consecutive q
 template <int KS, int S, int P>
 __global__ void __launch_bounds__(256) thin_bwd_data_kernel(const ThinArgs a) {
-  const float* __restrict__ wl = a.w;  // wave-uniform indices -> scalar loads (see thin_fwd_kernel)
+  const float* __restrict__ wl = a.w;  // wave-uniform indices -> scalar loads (a broadcast through the scalar cache)
   constexpr int T = (KS + S - 1) / S;
   constexpr int DW = T + P - 1;  // dy window: l in [q0 - (T-1), q0 + P - 1]
   const int n = blockIdx.y;
@@ -128,71 +75,6 @@ __global__ void __launch_bounds__(256) thin_bwd_data_kernel(const ThinArgs a) {
       const int jj = S * (q0 + j) + r - a.pad;
       if (jj >= 0 && jj < a.L) dxn[jj] = acc[j][r];
     }
-}
-
-// partial[block][co_local][k] = sum over the block's positions of dy[n,co,l] * x[n, l*s - pad + k];
-// thread = P consecutive positions per step (dy read as contiguous runs, x window slid in registers)
-template <int KS, int S, int P>
-__global__ void __launch_bounds__(256) thin_bwd_weight_kernel(const ThinArgs a) {
-  __shared__ float red[4][4 * KS];
-  constexpr int XW = KS + S * (P - 1);
-  const int n = blockIdx.y;
-  const int cg = blockIdx.z;  // group of 4 output channels
-  const int l0 = blockIdx.x * a.chunk;
-  int l1 = l0 + a.chunk;
-  if (l1 > a.Lout) l1 = a.Lout;
-  float acc[4][KS];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int k = 0; k < KS; ++k) acc[c][k] = 0.f;
-  const float* xr = a.x + (size_t)n * a.L;
-  const float* dyn = a.dy + ((size_t)n * a.Cout + cg * 4) * a.Lout;
-  const float* mkn = a.mask ? a.mask + ((size_t)n * a.Cout + cg * 4) * a.Lout : nullptr;
-  for (int l = l0 + threadIdx.x * P; l < l1; l += 256 * P) {
-    float xw[XW];
-    const int base = l * S - a.pad;
-#pragma unroll
-    for (int k = 0; k < XW; ++k) {
-      const int pos = base + k;
-      xw[k] = (pos >= 0 && pos < a.L) ? xr[pos] : 0.f;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float d[P];
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        float v = 0.f;
-        if (l + j < l1) {
-          v = dyn[(size_t)c * a.Lout + l + j];
-          if (mkn) v *= (mkn[(size_t)c * a.Lout + l + j] > 0.f ? 1.f : a.mask_slope);
-        }
-        d[j] = v;
-      }
-#pragma unroll
-      for (int k = 0; k < KS; ++k)
-#pragma unroll
-        for (int j = 0; j < P; ++j) acc[c][k] += d[j] * xw[k + S * j];
-    }
-  }
-  // wave reduction (64 lanes), then the 4 waves through LDS
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      float v = acc[c][k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) red[wave][c * KS + k] = v;
-    }
-  __syncthreads();
-  if (threadIdx.x < 4 * KS) {
-    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;  // (n, chunk)
-    const int c = threadIdx.x / KS, k = threadIdx.x % KS;
-    a.out[(blk * a.Cout + cg * 4 + c) * KS + k] = s;
-  }
 }
 
 // Backward-weight on the matrix pipe for Cout == 32: dW^T[kk, co] = sum_l x[n, s*l - pad + kk] * dy[n, co, l]
@@ -268,6 +150,7 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
       const int l = lt + 2 * j + h;
       const int pos = l * S - a.pad + i31;
       av[j] = (i31 < KS && l < l1 && pos >= 0 && pos < a.L) ? xr[pos] : 0.f;  // A[kk = i31][k = h]
+      if (KS < 32 && i31 == 31) av[j] = l < l1 ? 1.f : 0.f;  // spare row 31 = ones: C[31][co] = sum_l dy (bias gradient)
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -286,15 +169,25 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
     const int idx = kk * 32 + co;
     a.out[blk * 32 * KS + o] = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
   }
+  if (a.out2 && threadIdx.x < 32) {
+    const int idx = 31 * 32 + threadIdx.x;
+    a.out2[blk * 32 + threadIdx.x] = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+  }
 }
 
 // dw[o] = sum over the nblk partial slabs, fixed order: 16 groups of slabs per output (group g takes
 // slabs g, g + 16, ...) summed in fp64, then combined in group order. One chain over all slabs per
 // thread was latency-bound (77 us for 320 slabs of 800 outputs).
-__global__ void __launch_bounds__(1024) thin_sum_partials_kernel(const float* partial, float* dw, int nblk, int n_out) {
+__global__ void __launch_bounds__(1024) thin_sum_partials_kernel(const float* partial, float* dw, int nblk, int n_out,
+                                                                   const float* partial2, float* out2, int n_out2) {
   __shared__ double part[16][64];
   const int ox = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int o = blockIdx.x * 64 + ox;
+  if (partial2 && blockIdx.x == gridDim.x - 1) {  // the extra block sums the bias partials the same way
+    partial = partial2;
+    dw = out2;
+    n_out = n_out2;
+  }
+  const int o = (partial == partial2 && partial2 ? 0 : blockIdx.x * 64) + ox;
   double s = 0.0;
   if (o < n_out)
     for (int b = g; b < nblk; b += 16) s += (double)partial[(size_t)b * n_out + o];
@@ -309,7 +202,8 @@ __global__ void __launch_bounds__(1024) thin_sum_partials_kernel(const float* pa
 }
 
 static bool thin_ok(int Cin, int Cout, int ks, int stride) {
-  return Cin == 1 && (ks == 25) && (stride == 4) && Cout % 4 == 0 && Cout * ks <= THIN_MAX_W;
+  // the layers that exist: AudioDiscriminator.l1 / WaveGANAudioEncoder.l1, Conv1d(1, 32, 25, stride=4)
+  return Cin == 1 && ks == 25 && stride == 4 && Cout == 32;
 }
 
 bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride) { return thin_ok(Cin, Cout, ks, stride); }
@@ -318,7 +212,7 @@ static const int THIN_BW_CHUNK = 1024;
 
 size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout) {
   const size_t nblk = (size_t)B * m2d_ceil_div(Lout, THIN_BW_CHUNK);
-  return nblk * Cout * ks * sizeof(float);
+  return nblk * (Cout * ks + Cout) * sizeof(float);  // weight partials + bias partials
 }
 
 // Forward for Cout == 32 on the matrix pipe: per wave 32 channels x 32*NT consecutive positions as
@@ -423,11 +317,8 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
-  if (Cout == 32)
-    hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2>), dim3(m2d_ceil_div(Lout, 256), B), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL((thin_fwd_kernel<25, 4, 4>), dim3(m2d_ceil_div(Lout, 1024), B), dim3(256), 0, stream, a);
-  M2D_CHECK_LAUNCH("thin_fwd_kernel");
+  hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2>), dim3(m2d_ceil_div(Lout, 256), B), dim3(256), 0, stream, a);
+  M2D_CHECK_LAUNCH("thin_fwd_mfma_kernel");
   return M2D_OK;
 }
 
@@ -446,9 +337,9 @@ int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, 
   return M2D_OK;
 }
 
-int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L, int Cout, int ks, int stride,
-                        int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes,
-                        hipStream_t stream) {
+int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int L, int Cout, int ks,
+                        int stride, int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws,
+                        size_t ws_bytes, hipStream_t stream) {
   if (!ws || ws_bytes < m2d_thin_bwd_weight_ws(B, Cout, ks, Lout))
     M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_bwd_weight (thin): workspace too small");
   ThinArgs a;
@@ -460,12 +351,12 @@ int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, int B, int L
   const int nchunk = m2d_ceil_div(Lout, THIN_BW_CHUNK);
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (dy_mask ? 2 : 1)), "thin_conv_bwd_weight", Cout, ks, B * Lout);
-  if (Cout == 32)
-    hipLaunchKernelGGL((thin_bwd_weight_mfma_kernel<25, 4>), dim3(nchunk, B), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL((thin_bwd_weight_kernel<25, 4, 8>), dim3(nchunk, B, Cout / 4), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(thin_sum_partials_kernel, dim3(m2d_ceil_div(Cout * ks, 64)), dim3(1024), 0, stream,
-                     (const float*)ws, dw, nchunk * B, Cout * ks);
-  M2D_CHECK_LAUNCH("thin_bwd_weight_kernel");
+  // bias partials (row 31 of the MFMA tile = ones) sit behind the weight partials in the workspace
+  const size_t nblk = (size_t)nchunk * B;
+  a.out2 = dbias ? (float*)ws + nblk * Cout * ks : nullptr;
+  hipLaunchKernelGGL((thin_bwd_weight_mfma_kernel<25, 4>), dim3(nchunk, B), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(thin_sum_partials_kernel, dim3(m2d_ceil_div(Cout * ks, 64) + (dbias ? 1 : 0)), dim3(1024), 0,
+                     stream, (const float*)ws, dw, nchunk * B, Cout * ks, (const float*)a.out2, dbias, Cout);
+  M2D_CHECK_LAUNCH("thin_bwd_weight_mfma_kernel");
   return M2D_OK;
 }

@@ -52,6 +52,10 @@ struct M2dOperand {
   // [k_safe_lo, k_safe_hi): lo values whose window test passes for EVERY valid row and hi
   // (whole range when lim <= 0 or k_pos_lo == 0: the test is then chunk-uniform or absent)
   int k_safe_lo, k_safe_hi;
+  // row-fast operands only: row (ones_row_p1 - 1) reads as 1.0 for every k instead of being gathered
+  // (0 = none). Backward-weight appends such a column to its B operand: C[:, that column] = sum_k A[:, k],
+  // i.e. the bias gradient comes out of the same launch (A is zero wherever k is padding).
+  int ones_row_p1;
 };
 
 struct M2dOutMap {
@@ -68,6 +72,9 @@ struct M2dOutMap {
   float cdiv_inv;
   int c_hi_stride, c_lo_stride, c_off;
   int c_pos_mul, c_pos_off, c_lim;  // c_lim <= 0: no window test on the output column
+  // column (redirect_col_p1 - 1) is written raw to col_out[row] instead of through the map (0 = none)
+  float* col_out;
+  int redirect_col_p1;
 };
 
 struct M2dGemmParams {

@@ -50,11 +50,13 @@ struct TileMap {
   int posr;  // row-fast: window position of the row incl. kb * k_pos_lo; M2D_BAD for rows past the extent
   int kb;    // k-fast: the thread's slot; row-fast: its first slot
   unsigned lim_eff;
+  bool force_one;  // row-fast: this thread's row is the operand's all-ones row
   float v[NE];   // staged values
   float mv[NM];  // staged mask values (MASKED only)
 
   __device__ __forceinline__ void prep(const M2dOperand& op, int row0, int tid) {
     lim_eff = op.lim > 0 ? (unsigned)op.lim : (unsigned)(M2D_BAD - 1);
+    force_one = false;
     if constexpr (KF) {
       kb = tid % M2D_BK;
       posr = 0;
@@ -72,6 +74,7 @@ struct TileMap {
       kb = BR >= 64 ? __builtin_amdgcn_readfirstlane(kb_t) : kb_t;  // wave-uniform when a wave spans <= 1 k-group
       const int g = row0 + tid % BR;
       const bool rv = g < op.nrows;
+      force_one = (g + 1 == op.ones_row_p1);
       int hi, lo;
       m2d_divmod(rv ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
       const int off = hi * op.r_hi_stride + lo * op.r_lo_stride + op.r_off + kb * op.k_lo_stride;
@@ -130,6 +133,7 @@ struct TileMap {
       const int rl = KF ? (tid / M2D_BK + i * (256 / M2D_BK)) : (tid % BR);
       float x = v[i];
       if constexpr (MASKED) x *= (mv[i] > 0.f ? 1.f : op.mask_slope);
+      if constexpr (!KF) x = force_one ? 1.f : x;
       s[kl * LD + rl] = x;
     }
   }
@@ -364,6 +368,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
         if (row < p.M) {
           if (p.splits > 1) {
             if (cv) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + col] = acc[i][j][r];
+          } else if (col + 1 == O.redirect_col_p1) {
+            O.col_out[row] = acc[i][j][r];
           } else if (cok) {
             const int addr = row * O.m_stride + caddr;
             O.out[addr] = m2d_epilogue(O, acc[i][j][r], row, col, addr);
@@ -393,6 +399,10 @@ __global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmPar
     for (int j = 0; j < 8; ++j)
       if (z + j < p.splits) c[j] += sp[(size_t)(z + j) * total];
     const float s = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    if (col + 1 == p.O.redirect_col_p1) {
+      p.O.col_out[row] = s;
+      continue;
+    }
     int chi, clo;
     m2d_divmod(col, p.O.cdiv, p.O.cdiv_inv, chi, clo);
     bool ok = true;

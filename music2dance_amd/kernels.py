@@ -184,20 +184,22 @@ class HipKernels:
         _lib.check(rc, "m2d_conv1d_bwd_data")
         return dx
 
-    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0):
+    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0, with_bias=False):
+        """-> dw, or (dw, dbias) with `with_bias`: dbias = sum over (batch, length) of the masked dy."""
         dev = _chk(x, dy, dy_mask)
         B, Cin, L = x.shape
         B2, Cout, Lout = dy.shape
         assert B == B2 and Lout == conv_out_len(L, ks, stride, pad)
         dw = torch.empty((Cout, Cin, ks), dtype=torch.float32, device=dev)
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev) if with_bias else None
         h = _lib.lib()
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 2, B, Cin, L, Cout, ks, stride, pad), dev)
         with _on(dev):
-            rc = h.m2d_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, L, Cout, ks, stride, pad,
+            rc = h.m2d_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, L, Cout, ks, stride, pad,
                                          _ptr(dy_mask), dy_mask_slope, _ptr(ws),
                                          0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_conv1d_bwd_weight")
-        return dw
+        return (dw, db) if with_bias else dw
 
     # ---------------------------------------------------------------- gemm
     def gemm(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,

@@ -91,6 +91,7 @@ def _c(t):
 # is the same at first and second order: gradients w.r.t. `x` get the in_act epilogue, gradients
 # w.r.t. `gy` / `h` get the act'(y) epilogue (that one is plain calculus: h = gy * act'(y)), and an
 # operand is read through a mask only when nobody pre-multiplied it.
+_FUSED_BIAS = os.environ.get("M2D_FUSED_BIAS", "1") != "0"  # dev switch for A/B timing
 _PREMASK = os.environ.get("M2D_PREMASK", "1") != "0"  # dev switch for A/B timing: 0 = masked operand loads
 
 
@@ -122,9 +123,14 @@ class _Conv1dAct(Function):
         if ctx.needs_input_grad[0] and xkey not in _state["dead_inputs"]:
             gx = _Conv1dBwdData.apply(gy, w, hmask, ymask, xmask, x.shape[2], stride, pad, yslope, xslope)
         if not _state["inputs_only"]:
+            want_b = has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                gw = _Conv1dBwdWeight.apply(x, gy, hmask, ymask, xmask, w.shape[2], stride, pad, yslope, xslope)
-            if has_bias and ctx.needs_input_grad[2]:
+                # the bias gradient rides in the weight-gradient launch (an all-ones operand column)
+                gw, gb = _Conv1dBwdWeight.apply(x, gy, hmask, ymask, xmask, w.shape[2], stride, pad, yslope,
+                                                xslope, want_b and _FUSED_BIAS)
+                if want_b and not _FUSED_BIAS:
+                    gb = _ChannelSum.apply(gy, hmask, ymask, yslope)
+            elif want_b:
                 gb = _ChannelSum.apply(gy, hmask, ymask, yslope)
         return gx, gw, gb, None, None, None, None, None, None
 
@@ -161,31 +167,39 @@ class _Conv1dBwdData(Function):
 
 
 class _Conv1dBwdWeight(Function):
-    """dW = correlate(x, h), h = gy * act'(y). Differentiable w.r.t. x and gy."""
+    """dW = correlate(x, h) and, with `with_bias`, db = sum h; h = gy * act'(y). Differentiable
+    w.r.t. x and gy."""
 
     @staticmethod
-    def forward(ctx, x, gy, hmask, ymask, xmask, ks, stride, pad, yslope, xslope):
+    def forward(ctx, x, gy, hmask, ymask, xmask, ks, stride, pad, yslope, xslope, with_bias):
         ctx.set_materialize_grads(False)
         x, gy = _c(x), _c(gy)
-        dw = K().conv1d_bwd_weight(x, gy, ks, stride, pad, hmask, yslope)
         ctx.save_for_backward(x, gy, hmask, ymask, xmask)
         ctx.cfg = (stride, pad, yslope, xslope)
-        return dw
+        if with_bias:
+            return K().conv1d_bwd_weight(x, gy, ks, stride, pad, hmask, yslope, with_bias=True)
+        return K().conv1d_bwd_weight(x, gy, ks, stride, pad, hmask, yslope), None
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
-        if g is None:
-            return (None,) * 10
+    def backward(ctx, g, g_b):
+        if g is None and g_b is None:
+            return (None,) * 11
         x, gy, hmask, ymask, xmask = ctx.saved_tensors
         stride, pad, yslope, xslope = ctx.cfg
-        g = _c(g)
         g_x = g_gy = None
-        if ctx.needs_input_grad[0]:
-            g_x = K().conv1d_bwd_data(gy, g, x.shape[2], stride, pad, hmask, yslope, xmask, xslope)
-        if ctx.needs_input_grad[1]:
-            g_gy = K().conv1d_fwd(x, g, None, stride, pad, 0, 0.0, None, ymask, yslope)
-        return (g_x, g_gy) + (None,) * 8
+        if g is not None:
+            g = _c(g)
+            if ctx.needs_input_grad[0]:
+                g_x = K().conv1d_bwd_data(gy, g, x.shape[2], stride, pad, hmask, yslope, xmask, xslope)
+            if ctx.needs_input_grad[1]:
+                g_gy = K().conv1d_fwd(x, g, None, stride, pad, 0, 0.0, None, ymask, yslope)
+        if g_b is not None and ctx.needs_input_grad[1]:
+            e = g_b.view(1, -1, 1).expand(gy.shape)
+            if ymask is not None:
+                e = e * torch.where(ymask > 0, torch.ones_like(ymask), torch.full_like(ymask, yslope))
+            g_gy = e.contiguous() if g_gy is None else g_gy + e
+        return (g_x, g_gy) + (None,) * 9
 
 
 class _ChannelSum(Function):

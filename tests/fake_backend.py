@@ -53,10 +53,11 @@ class FakeKernels:
             dx = dx * _mf(out_mask, out_mask_slope)
         return dx
 
-    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0):
+    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0, with_bias=False):
         if dy_mask is not None:
             dy = dy * _mf(dy_mask, dy_mask_slope)
-        return torch.nn.grad.conv1d_weight(x, (dy.shape[1], x.shape[1], ks), dy, stride=stride, padding=pad)
+        dw = torch.nn.grad.conv1d_weight(x, (dy.shape[1], x.shape[1], ks), dy, stride=stride, padding=pad)
+        return (dw, dy.sum((0, 2))) if with_bias else dw
 
     def gemm(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,
              out_mask_slope=0.0):

@@ -101,6 +101,10 @@ def test_conv1d_fwd_bwd(case):
     assert rel_err(dx, gx) < 2e-5, "bwd_data"
     dw = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p)
     assert rel_err(dw, gw) < 3e-5, "bwd_weight"
+    # bias gradient from the same launch (all-ones operand column / spare MFMA row)
+    dw2, db = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p, with_bias=True)
+    assert rel_err(dw2, gw) < 3e-5, "bwd_weight (with bias)"
+    assert rel_err(db, dy.double().sum((0, 2))) < 3e-5, "bias gradient"
 
 
 def test_conv1d_cabi_without_packed_weights():
@@ -187,8 +191,9 @@ def test_conv1d_masks_and_epilogue(case):
     gx, gw = torch.autograd.grad(out, (x64, w64), dy.double() * m0)
     dx = K().conv1d_bwd_data(dy.to(DEV), wd, L, s, p, dy_mask=mask.to(DEV), dy_mask_slope=0.0)
     assert rel_err(dx, gx) < 2e-5
-    dw = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p, dy_mask=mask.to(DEV), dy_mask_slope=0.0)
+    dw, db = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p, dy_mask=mask.to(DEV), dy_mask_slope=0.0, with_bias=True)
     assert rel_err(dw, gw) < 3e-5
+    assert rel_err(db, (dy.double() * m0).sum((0, 2))) < 3e-5
     # epilogue mask on backward-data (shape of dx), with and without the operand mask, slope 0.2
     if not (Cin == 1 and ks == 25 and s == 4):
         om = gen(B, Cin, L, seed=6)

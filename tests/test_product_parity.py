@@ -9,6 +9,7 @@ Tolerances as in test_oracle_golden.py: 1e-4 abs on poses / scores / penalties (
 north_star's per-joint bound), 2e-3 rel on gradient norms, 2e-3 rel on 8-step loss traces.
 """
 import os
+import re
 
 import numpy as np
 import pytest
@@ -80,10 +81,20 @@ def norms_close(got, want, rtol=2e-3):
     np.testing.assert_allclose(got[m], want[m], rtol=rtol, atol=1e-6 * np.nanmax(want))
 
 
-def sums_close(sd, want, rtol=2e-4, adam_lr=0.0, adam_steps=0):
+# Biases that feed a BatchNorm directly have an exactly-zero gradient; what the kernels produce for
+# them is rounding noise, and Adam turns noise of any size into +-lr steps whose signs need not
+# cancel. Their post-step checksums get lr * steps * numel instead of the random-walk bound.
+_NOISE_BIAS = re.compile(r"(^|\.)(fc1\.bias|blocks\.\d+\.fc2\.bias|conv_layers\.\d+\.bias|convblock\d\.conv\.bias|"
+                         r"audio_enc\.model\.l[1-4]\.bias)$")
+
+
+def sums_close(sd, want, rtol=2e-4, adam_lr=0.0, adam_steps=0, bn_biases=False):
+    """bn_biases: the module is a generator - its fc1 / fc2 / encoder-conv biases sit in front of BatchNorm."""
     got = P.sd_checksums({k: v.detach().cpu() for k, v in sd.items()})
     numel = np.array([v.numel() for v in sd.values()], dtype=np.float64)
-    atol = 1e-5 + 4.0 * adam_lr * adam_steps * np.sqrt(numel)
+    noisy = np.array([bn_biases and bool(_NOISE_BIAS.search(k)) for k in sd])
+    walk = np.where(noisy, numel, 4.0 * np.sqrt(numel))
+    atol = 1e-5 + adam_lr * adam_steps * walk
     err = np.abs(got - want)
     bound = atol[:, None] + rtol * np.abs(want)
     assert (err <= bound).all(), "checksum mismatch at %s" % [
@@ -169,7 +180,7 @@ def test_p1_trace(dev):
     close(np.array(lc), fx["trace_loss_critic"], 1e-3, TRACE_RTOL)
     close(np.array(lg), fx["trace_loss_gen"], 1e-3, TRACE_RTOL)
     close(np.array(lc[:1]), fx["trace_loss_critic"][:1], 1e-4)
-    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=1e-4, adam_steps=1)
+    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=1e-4, adam_steps=1, bn_biases=True)
     sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=1e-4, adam_steps=6)
 
 
@@ -228,7 +239,7 @@ def test_p2_trace(dev):
         close(np.array(tr[k]), fx["trace_" + k], 1e-3, TRACE_RTOL_P2)
     close(np.array(tr["loss_critic"][:1]), fx["trace_loss_critic"][:1], 1e-4)
     assert len(tr["loss_gen"]) == 1
-    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=5e-4, adam_steps=1)
+    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=5e-4, adam_steps=1, bn_biases=True)
     sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=5e-4, adam_steps=8)
 
 
@@ -315,5 +326,5 @@ def test_p3_trace(dev, case):
         close(np.array(tr[k]), fx["trace_" + fk], 1e-3, TRACE_RTOL)
     close(np.array(tr["loss_critic"][:1]), fx["trace_loss_critic"][:1], 2e-4)
     assert len(tr["loss_gen"]) == 1
-    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=2e-4, adam_steps=1)
+    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=2e-4, adam_steps=1, bn_biases=True)
     sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=2e-4, adam_steps=8)
