@@ -42,6 +42,10 @@ int m2d_prof_begin(void);
 int m2d_prof_end(double* out, int n_out /* >= 20 */);
 /* per-launch CSV "family,tag,d0,d1,d2,ms,flops" of the current session; call before m2d_prof_end */
 int m2d_prof_dump(char* buf, int cap);
+/* GEMM-engine launch plans (tile height, split-K factor) come from a cost model; with M2D_AUTOTUNE=1
+ * the best few are timed once per operand shape, on the caller's operands, and the fastest is cached.
+ * Number of shapes timed so far: */
+int m2d_plan_cache_size(void);
 
 /* ---- conv1d: nn.Conv1d forward and both halves of its backward -------------------------
  * reference: phase3/archis/default.py:64-70 (DefaultAudioEncoder), :90-97,216 (U-Net),

@@ -414,15 +414,27 @@ __global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmPar
   }
 }
 
-// Launch plan from a small cost model (microseconds, fitted to MI355X measurements of the
-// phase-3 layer shapes): 256 CUs, every CU works through its share of blocks; a block spends
-// tc(BM) per 16-deep chunk when the CU's matrix pipes are kept busy by other resident blocks and
-// more when it is alone (the load -> LDS -> MFMA chain of one block is then exposed). Split-K
-// costs one slab round trip through HBM plus a second launch. Block counts just above a multiple
-// of 256 leave most CUs idle for the last round, which is why the candidate split factors are
-// the ones that land ON a multiple.
-M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty) {
-  M2dGemmPlan pl;
+// Launch plans. A plan is (tile height BM, split-K factor). Candidates are ranked by a small cost
+// model (microseconds, fitted to MI355X measurements of the phase-3 layer shapes): 256 CUs, every
+// CU works through its share of blocks; a block spends tc(BM) per 16-deep chunk when the CU's
+// matrix pipes are kept busy by other resident blocks and more when it is alone (the load -> LDS ->
+// MFMA chain of one block is then exposed). Split-K costs one slab round trip through HBM plus a
+// second launch. Block counts just above a multiple of 256 leave most CUs idle for the last round,
+// which is why the candidate split factors are the ones that land ON a multiple.
+// With M2D_AUTOTUNE=1 the launcher TIMES the model's few best candidates the first time it meets a
+// shape - on the caller's own operands; every plan writes the same output up to summation order -
+// and keeps the fastest. Measured on the phase-3 step (A/B on one box, 3 runs each): 16.21 vs 16.28 ms,
+// i.e. the model's first choice is already within 0.5 % of the timed best, so timing is OFF by
+// default (plans, and with them summation orders, then do not depend on timing noise).
+#define M2D_MAX_CAND 6
+
+struct PlanCand {
+  int bm, splits;
+  double cost;
+};
+
+static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty,
+                           PlanCand* out) {
   const int ph = phases > 1 ? phases : 1;
   const bool can_split = allow_split && phases <= 1;
   const long long nt = m2d_ceil_div(N, 128);
@@ -432,9 +444,8 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_spli
   const double pen = small_tile_penalty > 1.0 ? small_tile_penalty : 1.0;
   const double tc[3] = {0.98, 0.56 * pen, 0.33 * pen};
   const int resident[3] = {3, 5, 7};         // blocks per CU (VGPR / LDS budget)
-  double best = 1e30;
-  pl.bm = 128;
-  pl.splits = 1;
+  PlanCand all[40];
+  int na = 0;
   for (int b = 0; b < 3; ++b) {
     const long long tiles = (long long)m2d_ceil_div(M, bms[b]) * nt * ph;
     long long cand[10];
@@ -450,6 +461,9 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_spli
     }
     for (int c = 0; c < nc; ++c) {
       const long long sp = cand[c];
+      bool dup = false;
+      for (int q = 0; q < na; ++q) dup |= all[q].bm == bms[b] && all[q].splits == (int)sp;
+      if (dup || na >= 40) continue;
       // a CU holding per_cu blocks, `conc` of them resident at a time: throughput bound
       // per_cu * tc per chunk step, latency bound (one block's load -> LDS -> MFMA chain is
       // ~0.55 us longer than its matrix time) ceil(per_cu / conc) * (tc + 0.55)
@@ -460,25 +474,49 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_spli
       const double lat = (double)m2d_ceil_div64(per_cu, conc) * (tc[b] + 0.55);
       double cost = 8.0 + cps * (thr > lat ? thr : lat);
       if (sp > 1) cost += 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
-      if (cost < best) {
-        best = cost;
-        pl.bm = bms[b];
-        pl.splits = (int)sp;
-      }
+      all[na].bm = bms[b];
+      all[na].splits = (int)sp;
+      all[na].cost = cost;
+      ++na;
     }
   }
+  for (int i = 0; i < na; ++i)
+    for (int j = i + 1; j < na; ++j)
+      if (all[j].cost < all[i].cost) {
+        PlanCand t = all[i];
+        all[i] = all[j];
+        all[j] = t;
+      }
+  int n = 0;
+  for (int i = 0; i < na && n < M2D_MAX_CAND; ++i)
+    if (all[i].cost <= 1.5 * all[0].cost + 6.0) out[n++] = all[i];
+  return n;
+}
+
+// The model's first choice; ws_bytes covers every candidate the launcher may time.
+M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty) {
+  PlanCand c[M2D_MAX_CAND];
+  const int n = plan_candidates(M, N, nchunks, phases, allow_split, small_tile_penalty, c);
+  M2dGemmPlan pl;
+  pl.bm = n ? c[0].bm : 128;
+  pl.splits = n ? c[0].splits : 1;
   pl.ws_bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    const size_t b = c[i].splits > 1 ? (size_t)c[i].splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+    if (b > pl.ws_bytes) pl.ws_bytes = b;
+  }
 #ifdef M2D_TUNING
   if (const char* e = getenv("M2D_PLAN")) {  // "bm,splits" (tuning builds only)
     int bm = 0, sp = 0;
     if (sscanf(e, "%d,%d", &bm, &sp) == 2) {
       if (bm == 32 || bm == 64 || bm == 128) pl.bm = bm;
-      if (sp >= 1 && can_split && sp <= nchunks) pl.splits = sp;
+      if (sp >= 1 && allow_split && phases <= 1 && sp <= nchunks) pl.splits = sp;
       if (sp == 1) pl.splits = 1;
+      const size_t b = pl.splits > 1 ? (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+      if (b > pl.ws_bytes) pl.ws_bytes = b;
     }
   }
 #endif
-  if (pl.splits > 1) pl.ws_bytes = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
   return pl;
 }
 
@@ -499,6 +537,43 @@ static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hi
   return 0;
 }
 
+// one launch of the GEMM (+ the slab reduction) under plan (bm, splits)
+static int plan_run(M2dGemmParams& p, int bm, int splits, bool a_kfast, bool b_kfast, void* ws, hipStream_t stream) {
+  p.splits = splits;
+  p.slab = splits > 1 ? (float*)ws : nullptr;
+  const int mt = m2d_ceil_div(p.M, bm);
+  const long long nt = m2d_ceil_div(p.N, 128);
+  const dim3 grid((unsigned)nt, (unsigned)mt, (unsigned)(p.bwd_data ? p.phases : splits));
+  int lrc;
+  if (bm == 32) lrc = launch_maps<32>(p, a_kfast, b_kfast, grid, stream);
+  else if (bm == 64) lrc = launch_maps<64>(p, a_kfast, b_kfast, grid, stream);
+  else lrc = launch_maps<128>(p, a_kfast, b_kfast, grid, stream);
+  if (lrc) return lrc;
+  if (splits > 1) {
+    const size_t total = (size_t)p.M * p.N;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(m2d_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  }
+  return 0;
+}
+
+// ---- plan cache: shape -> fastest timed plan --------------------------------------------------
+#include <map>
+#include <mutex>
+#include <vector>
+static std::mutex g_plan_mu;
+static std::map<std::vector<int>, std::pair<int, int>> g_plan_cache;
+
+static bool autotune_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("M2D_AUTOTUNE");
+    on = (e && e[0] == '1') ? 1 : 0;
+  }
+  return on == 1;
+}
+
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what) {
   if (p.M <= 0 || p.N <= 0) return M2D_OK;
@@ -510,23 +585,87 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
     M2D_FAIL(M2D_ERR_ARG, "%s: bad contraction map (kdiv=%d nhi=%d)", what, p.kdiv, p.nhi);
   if ((a_kfast && p.A.lim > 0) || (b_kfast && p.B.lim > 0))
     M2D_FAIL(M2D_ERR_ARG, "%s: k-fast operands carry no window", what);
+  if (!((a_kfast && !b_kfast) || (!a_kfast && !b_kfast) || (a_kfast && b_kfast)))
+    M2D_FAIL(M2D_ERR_ARG, "%s: unsupported operand map combination", what);
   if (p.phases < 1) p.phases = 1;
   // bwd_data: the widest phase has ceil(ks / phases) taps
   const int nhi_max = p.bwd_data ? (p.ph_ks + p.phases - 1) / p.phases : p.nhi;
-  const M2dGemmPlan pl = m2d_gemm_plan(p.M, p.N, m2d_chunks(nhi_max, p.kdiv), p.bwd_data ? p.phases : 1, allow_split,
-                                      p.small_tile_penalty);
-  p.splits = pl.splits;
-  p.slab = nullptr;
-  if (pl.splits > 1) {
-    if (ws == nullptr || ws_bytes < pl.ws_bytes)
-      M2D_FAIL(M2D_ERR_WORKSPACE, "%s: split-K needs %zu workspace bytes, got %zu", what, pl.ws_bytes,
-               ws_bytes);
-    p.slab = (float*)ws;
+  const int nchunks = m2d_chunks(nhi_max, p.kdiv);
+  PlanCand cand[M2D_MAX_CAND];
+  int nc = plan_candidates(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, allow_split, p.small_tile_penalty, cand);
+  {
+    // a split plan needs its slabs: drop the ones the workspace cannot hold
+    int k = 0;
+    for (int i = 0; i < nc; ++i) {
+      const size_t need = cand[i].splits > 1 ? (size_t)cand[i].splits * (size_t)p.M * (size_t)p.N * sizeof(float) : 0;
+      if (need == 0 || (ws != nullptr && ws_bytes >= need)) cand[k++] = cand[i];
+    }
+    if (k == 0) {
+      if (nc > 0)
+        M2D_FAIL(M2D_ERR_WORKSPACE, "%s: split-K needs %zu workspace bytes, got %zu", what,
+                 (size_t)cand[0].splits * (size_t)p.M * (size_t)p.N * sizeof(float), ws_bytes);
+      M2D_FAIL(M2D_ERR_ARG, "%s: no launch plan", what);
+    }
+    nc = k;
   }
-  const int mt = m2d_ceil_div(p.M, pl.bm);
-  const long long nt = m2d_ceil_div(p.N, 128);
-  if (mt > 65535) M2D_FAIL(M2D_ERR_RANGE, "%s: M too large (%d)", what, p.M);
-  dim3 grid((unsigned)nt, (unsigned)mt, (unsigned)(p.bwd_data ? p.phases : pl.splits));
+  if (m2d_ceil_div(p.M, 32) > 65535) M2D_FAIL(M2D_ERR_RANGE, "%s: M too large (%d)", what, p.M);
+  int bm = cand[0].bm, splits = cand[0].splits;
+#ifdef M2D_TUNING
+  const char* forced = getenv("M2D_PLAN");
+  if (forced) {
+    const M2dGemmPlan fp = m2d_gemm_plan(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, allow_split, p.small_tile_penalty);
+    bm = fp.bm;
+    splits = fp.splits;
+    if (splits > 1 && (!ws || ws_bytes < (size_t)splits * p.M * p.N * sizeof(float)))
+      M2D_FAIL(M2D_ERR_WORKSPACE, "%s: forced plan needs more workspace", what);
+  } else
+#endif
+  if (autotune_enabled() && nc > 1) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+    std::vector<int> key;
+    key.reserve(40);
+    for (const char* c = what; *c; ++c) key.push_back((int)*c);
+    const int kf[] = {p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, (int)a_kfast, (int)b_kfast,
+                      (int)(p.A.mask || p.B.mask), (int)allow_split, p.lo_outer, p.kdiv, p.A.k_lo_stride,
+                      p.B.k_lo_stride, p.B.r_lo_stride, (int)(p.small_tile_penalty * 100.f), nc,
+                      cand[nc - 1].bm, cand[nc - 1].splits};
+    key.insert(key.end(), kf, kf + sizeof(kf) / sizeof(int));
+    std::unique_lock<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    if (it != g_plan_cache.end()) {
+      bm = it->second.first;
+      splits = it->second.second;
+    } else if (!capturing) {
+      lk.unlock();
+      // time every candidate on the real operands; two runs each, the faster one counts
+      hipEvent_t e0, e1;
+      if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        float best_ms = 1e30f;
+        for (int i = 0; i < nc; ++i) {
+          float ms = 1e30f;
+          for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(e0, stream);
+            if (plan_run(p, cand[i].bm, cand[i].splits, a_kfast, b_kfast, ws, stream)) break;
+            (void)hipEventRecord(e1, stream);
+            if (hipEventSynchronize(e1) != hipSuccess) break;
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, e0, e1) == hipSuccess && t < ms) ms = t;
+          }
+          if (ms < best_ms) {
+            best_ms = ms;
+            bm = cand[i].bm;
+            splits = cand[i].splits;
+          }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        M2D_CHECK_LAUNCH(what);
+      }
+      lk.lock();
+      g_plan_cache[key] = std::make_pair(bm, splits);
+    }
+  }
   double flops = 2.0 * p.M * (double)p.N * p.K;
   if (p.bwd_data) {
     flops = 0.0;
@@ -540,19 +679,15 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
   }
   {
     M2dProfScope prof(M2D_FAM_GEMM, stream, flops, 0.0, what, p.M, p.N, p.K);
-    int lrc;
-    if (pl.bm == 32) lrc = launch_maps<32>(p, a_kfast, b_kfast, grid, stream);
-    else if (pl.bm == 64) lrc = launch_maps<64>(p, a_kfast, b_kfast, grid, stream);
-    else lrc = launch_maps<128>(p, a_kfast, b_kfast, grid, stream);
-    if (lrc) M2D_FAIL(M2D_ERR_ARG, "%s: unsupported operand map combination", what);
+    if (plan_run(p, bm, splits, a_kfast, b_kfast, ws, stream))
+      M2D_FAIL(M2D_ERR_ARG, "%s: unsupported operand map combination", what);
     M2D_CHECK_LAUNCH(what);
-    if (pl.splits > 1) {
-      const size_t total = (size_t)p.M * p.N;
-      unsigned blocks = (unsigned)((total + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(m2d_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
-      M2D_CHECK_LAUNCH(what);
-    }
   }
   return M2D_OK;
+}
+
+// number of operand shapes with a timed launch plan (diagnostics)
+extern "C" int m2d_plan_cache_size(void) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  return (int)g_plan_cache.size();
 }
