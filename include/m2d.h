@@ -66,6 +66,17 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
 int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
                           int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
                           void* ws, size_t ws_bytes, void* stream);
+/* Audio slicing fused into the first encoder conv (reference: utils.slice_audio_batch, utils.py:329-353,
+ * then Conv1d(1, Cout, ...) on the (B*T, 1, window) slices, phase3/archis/default.py:27-28,64,90,117):
+ * the windows are read in place from the padded track (B, S) - window t of track b is
+ * track[b, t*hop : t*hop + window] - and never written. y / dy: (B*T, Cout, Lout). Workspace: as
+ * m2d_conv1d_workspace_bytes(0 / 2, B*T, 1, window, ...). */
+int m2d_conv1d_fwd_windows(const float* track, int B, int S, int T, int hop, int window, const float* w,
+                           const float* bias, float* y, int Cout, int ks, int stride, int pad, int act, float slope,
+                           void* ws, size_t ws_bytes, void* stream);
+int m2d_conv1d_bwd_weight_windows(const float* track, int B, int S, int T, int hop, int window, const float* dy,
+                                  float* dw, float* dbias, int Cout, int ks, int stride, int pad,
+                                  const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes, void* stream);
 /* The GEMMs behind forward / backward-data contract over (tap, channel) and read the weights
  * through packed images: w_fwd (Cout, ks, Cin) and w_bwd (Cin, ks, Cout) of w (Cout, Cin, ks).
  * `w_packed` above is the matching image, or NULL: the call then packs into its workspace.

@@ -20,16 +20,21 @@ static inline int conv_out_len(int L, int ks, int stride, int pad) {
 static inline bool fits_i32(long long v) { return v >= 0 && v < 2147483647LL; }
 
 // conv1d_thin.hip: vector-ALU kernels for Cin = 1, k = 25, stride 4 (HBM-bound layers)
+// Window view of a padded track (B, S): the logical input is (B*T, 1, window), window t of track b
+// starting at b*S + t*hop (utils.slice_audio_batch of the reference, never materialised). T == 0: dense.
+struct M2dWinView {
+  int T, S, hop;
+};
 bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride);
 size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout);
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
                  int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
-                 hipStream_t stream);
+                 const M2dWinView* wv, hipStream_t stream);
 int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, int Cout, int ks, int stride,
                       int pad, int Lout, const float* dy_mask, float dy_mask_slope, hipStream_t stream);
 int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int L, int Cout, int ks,
                         int stride, int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws,
-                        size_t ws_bytes, hipStream_t stream);
+                        size_t ws_bytes, const M2dWinView* wv, hipStream_t stream);
 
 // Forward conv as a GEMM. Cin >= 16: K ordered (tap, channel) - hi = tap, lo = ci - over the
 // packed weights wp (Cout, ks, Cin): every 16-chunk sits on one tap, so the padding window is
@@ -39,7 +44,7 @@ static inline bool conv_uses_packed(int Cin) { return Cin >= M2D_BK; }
 static inline float fwd_tile_penalty(int stride) { return stride > 1 ? 1.25f : 1.f; }
 
 static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, const float* wp, float* y, int B, int Cin,
-                     int L, int Cout, int ks, int stride, int pad, int Lout) {
+                     int L, int Cout, int ks, int stride, int pad, int Lout, const M2dWinView* wv = nullptr) {
   memset(&p, 0, sizeof(p));
   p.M = Cout;
   p.N = B * Lout;
@@ -58,6 +63,13 @@ static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, const flo
   b.r_pos_mul = stride;
   b.r_pos_off = -pad;
   b.lim = L;
+  if (wv && wv->T > 0) {  // Cin == 1: sample n = (track, window t) at track * S + t * hop
+    b.nbytes = m2d_extent_bytes((long long)(B / wv->T) * wv->S);
+    b.r_hi_stride = wv->hop;
+    b.rdiv2 = wv->T;
+    b.rdiv2_inv = 1.f / (float)wv->T;
+    b.r_hi2_stride = wv->S;
+  }
   if (packed) {
     p.nhi = ks;
     p.kdiv = Cin;
@@ -142,10 +154,10 @@ int m2d_conv1d_pack_weights(const float* w, float* w_fwd, float* w_bwd, int Cout
 // `w_packed` (optional): the (Cout, ks, Cin) image of w from m2d_conv1d_pack_weights.
 // `out_mask` (optional, shape of y) multiplies the result by (mask>0 ? 1 : out_mask_slope):
 // it is the d/d(dy) branch of backward-data's derivative (double backward of the GP).
-int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
-                   int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
-                   const float* residual, const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes,
-                   void* stream) {
+static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
+                           int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
+                           const float* residual, const float* out_mask, float out_mask_slope, void* ws,
+                           size_t ws_bytes, void* stream, const M2dWinView* wv) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || ks <= 0 || stride <= 0 || pad < 0 || L <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd: bad shape B=%d Cin=%d L=%d Cout=%d k=%d s=%d p=%d", B, Cin, L,
              Cout, ks, stride, pad);
@@ -155,7 +167,9 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const 
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd: tensor exceeds 2^31 elements");
   if (!residual && m2d_thin_applicable(Cin, Cout, ks, stride))
     return m2d_thin_fwd(x, w, bias, y, B, L, Cout, ks, stride, pad, Lout, act, slope, out_mask, out_mask_slope,
-                        (hipStream_t)stream);
+                        wv, (hipStream_t)stream);
+  if (wv && (Cin != 1 || (Lout == 1 && pad == 0 && L == ks)))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd_windows: window views are single-channel, non-degenerate convolutions");
   if (Lout == 1 && pad == 0 && L == ks) {
     // full-length kernel (fconv / l6 / last encoder conv): y[n,co] = b[co] + sum_k x[n,k] W[co,k], k = (ci,kk):
     // a plain NT GEMM over the natural layouts (both operands contiguous in k)
@@ -189,7 +203,7 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const 
     ws_bytes -= pb;
   }
   M2dGemmParams p;
-  fill_fwd(p, x, w, w_packed, y, B, Cin, L, Cout, ks, stride, pad, Lout);
+  fill_fwd(p, x, w, w_packed, y, B, Cin, L, Cout, ks, stride, pad, Lout, wv);
   p.O.bias = bias;
   p.O.bias_mode = bias ? 1 : 0;
   p.O.act = act;
@@ -199,6 +213,31 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const 
   p.O.mask_slope = out_mask_slope;
   return m2d_gemm_launch(p, /*a_kfast=*/true, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
                          (hipStream_t)stream, "m2d_conv1d_fwd");
+}
+
+int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
+                   int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
+                   const float* residual, const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes,
+                   void* stream) {
+  return conv1d_fwd_impl(x, w, w_packed, bias, y, B, Cin, L, Cout, ks, stride, pad, act, slope, residual, out_mask,
+                         out_mask_slope, ws, ws_bytes, stream, nullptr);
+}
+
+// The first conv of an audio encoder applied to the windows of a padded track WITHOUT writing the
+// windows: replaces utils.slice_audio_batch (utils.py:329-353) + nn.Conv1d(1, Cout, ...) on the
+// (B*T, 1, window) slices (phase3/archis/default.py:27-28,64,90,117). track: (B, S) floats, window t of
+// track b = track[b, t*hop : t*hop + window]; y: (B*T, Cout, Lout).
+int m2d_conv1d_fwd_windows(const float* track, int B, int S, int T, int hop, int window, const float* w,
+                           const float* bias, float* y, int Cout, int ks, int stride, int pad, int act, float slope,
+                           void* ws, size_t ws_bytes, void* stream) {
+  if (B <= 0 || T <= 0 || hop <= 0 || window <= 0 || (long long)(T - 1) * hop + window > S)
+    M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd_windows: windows do not fit the track (S=%d T=%d hop=%d window=%d)", S, T,
+             hop, window);
+  if (!fits_i32((long long)B * S) || !fits_i32((long long)B * T * window))
+    M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd_windows: tensor exceeds 2^31 elements");
+  const M2dWinView wv = {T, S, hop};
+  return conv1d_fwd_impl(track, w, nullptr, bias, y, B * T, 1, window, Cout, ks, stride, pad, act, slope, nullptr,
+                         nullptr, 0.f, ws, ws_bytes, stream, &wv);
 }
 
 // Replaces the input-gradient half of convolution_backward (autograd of nn.Conv1d), the
@@ -327,9 +366,9 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
 // dimension (hi = n, lo = l), so the launch is split-K with a deterministic slab reduction.
 // `dbias` (optional, Cout floats): the bias gradient sum_{n,l} dy[n,co,l] (masked like dy) from the
 // same launch - one all-ones column appended to the x operand - instead of a second pass over dy.
-int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
-                          int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
-                          void* ws, size_t ws_bytes, void* stream) {
+static int conv1d_bwd_weight_impl(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
+                                  int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                                  void* ws, size_t ws_bytes, void* stream, const M2dWinView* wv) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight: bad shape");
@@ -337,7 +376,9 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbi
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_bwd_weight: tensor exceeds 2^31 elements");
   if (m2d_thin_applicable(Cin, Cout, ks, stride))
     return m2d_thin_bwd_weight(x, dy, dw, dbias, B, L, Cout, ks, stride, pad, Lout, dy_mask, dy_mask_slope, ws,
-                               ws_bytes, (hipStream_t)stream);
+                               ws_bytes, wv, (hipStream_t)stream);
+  if (wv && (Cin != 1 || Lout < M2D_BK))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight_windows: single-channel convs with >= %d output positions only", M2D_BK);
   M2dGemmParams p;
   memset(&p, 0, sizeof(p));
   p.M = Cout;
@@ -369,6 +410,12 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbi
     b.k_lo_stride = stride;
     b.k_pos_hi = 0;
     b.k_pos_lo = stride;
+    if (wv && wv->T > 0) {  // sample n = (track, window t) at track * S + t * hop
+      b.nbytes = m2d_extent_bytes((long long)(B / wv->T) * wv->S);
+      b.k_hi_stride = wv->hop;
+      b.kdiv2 = wv->T;
+      b.k_hi2_stride = wv->S;
+    }
     // positions l whose every tap l*s - pad + kk, kk in [0, ks), lies in [0, L)
     b.k_safe_lo = (pad + stride - 1) / stride;
     b.k_safe_hi = (L - ks + pad) >= 0 ? (L - ks + pad) / stride + 1 : 0;
@@ -400,6 +447,27 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbi
   }
   return m2d_gemm_launch(p, a_kfast, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes, (hipStream_t)stream,
                          "m2d_conv1d_bwd_weight");
+}
+
+int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
+                          int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                          void* ws, size_t ws_bytes, void* stream) {
+  return conv1d_bwd_weight_impl(x, dy, dw, dbias, B, Cin, L, Cout, ks, stride, pad, dy_mask, dy_mask_slope, ws,
+                                ws_bytes, stream, nullptr);
+}
+
+// Weight (and bias) gradient of m2d_conv1d_fwd_windows; dy: (B*T, Cout, Lout). Workspace as for the
+// dense call on (B*T, 1, window).
+int m2d_conv1d_bwd_weight_windows(const float* track, int B, int S, int T, int hop, int window, const float* dy,
+                                  float* dw, float* dbias, int Cout, int ks, int stride, int pad,
+                                  const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes, void* stream) {
+  if (B <= 0 || T <= 0 || hop <= 0 || window <= 0 || (long long)(T - 1) * hop + window > S)
+    M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight_windows: windows do not fit the track");
+  if (!fits_i32((long long)B * S) || !fits_i32((long long)B * T * window))
+    M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_bwd_weight_windows: tensor exceeds 2^31 elements");
+  const M2dWinView wv = {T, S, hop};
+  return conv1d_bwd_weight_impl(track, dy, dw, dbias, B * T, 1, window, Cout, ks, stride, pad, dy_mask, dy_mask_slope,
+                                ws, ws_bytes, stream, &wv);
 }
 
 // which: 0 forward, 1 backward-data, 2 backward-weight. Includes the room forward / backward-data

@@ -22,6 +22,7 @@ struct ThinArgs {
   const float* mask;   // optional
   float* out;          // fwd: y; bwd_data: dx; bwd_weight: partial slabs
   float* out2;         // bwd_weight: bias-gradient partial slabs (optional)
+  int xT, xS, xhop;    // window view of a padded track: sample n starts at (n / xT) * xS + (n % xT) * xhop (xT = 0: dense)
   int B, L, Cout, ks, stride, pad, Lout;
   int act;
   float slope, mask_slope;
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
   const int l0 = blockIdx.x * a.chunk;
   int l1 = l0 + a.chunk;
   if (l1 > a.Lout) l1 = a.Lout;
-  const float* xr = a.x + (size_t)n * a.L;
+  const float* xr = a.xT > 0 ? a.x + (size_t)(n / a.xT) * a.xS + (size_t)(n % a.xT) * a.xhop : a.x + (size_t)n * a.L;
   const float* dyn = a.dy + (size_t)n * 32 * a.Lout;
   const float* mkn = a.mask ? a.mask + (size_t)n * 32 * a.Lout : nullptr;
   float* tl = tile[wave];
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c31 = lane & 31, h = lane >> 5;
   const int n = blockIdx.y;
-  const float* xr = a.x + (size_t)n * a.L;
+  const float* xr = a.xT > 0 ? a.x + (size_t)(n / a.xT) * a.xS + (size_t)(n % a.xT) * a.xhop : a.x + (size_t)n * a.L;
   float* im = img[wave];
   float wa[NS];
 #pragma unroll
@@ -307,11 +308,16 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
   }
 }
 
+struct M2dWinView {
+  int T, S, hop;
+};
+
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
                  int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
-                 hipStream_t stream) {
+                 const M2dWinView* wv, hipStream_t stream) {
   ThinArgs a;
   memset(&a, 0, sizeof(a));
+  if (wv) { a.xT = wv->T; a.xS = wv->S; a.xhop = wv->hop; }
   a.x = x; a.w = w; a.bias = bias; a.mask = out_mask; a.out = y;
   a.B = B; a.L = L; a.Cout = Cout; a.ks = ks; a.stride = stride; a.pad = pad; a.Lout = Lout;
   a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
@@ -339,11 +345,12 @@ int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, 
 
 int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int L, int Cout, int ks,
                         int stride, int pad, int Lout, const float* dy_mask, float dy_mask_slope, void* ws,
-                        size_t ws_bytes, hipStream_t stream) {
+                        size_t ws_bytes, const M2dWinView* wv, hipStream_t stream) {
   if (!ws || ws_bytes < m2d_thin_bwd_weight_ws(B, Cout, ks, Lout))
     M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_bwd_weight (thin): workspace too small");
   ThinArgs a;
   memset(&a, 0, sizeof(a));
+  if (wv) { a.xT = wv->T; a.xS = wv->S; a.xhop = wv->hop; }
   a.x = x; a.dy = dy; a.mask = dy_mask; a.out = (float*)ws;
   a.B = B; a.L = L; a.Cout = Cout; a.ks = ks; a.stride = stride; a.pad = pad; a.Lout = Lout;
   a.mask_slope = dy_mask_slope;

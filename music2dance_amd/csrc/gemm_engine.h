@@ -56,6 +56,15 @@ struct M2dOperand {
   // (0 = none). Backward-weight appends such a column to its B operand: C[:, that column] = sum_k A[:, k],
   // i.e. the bias gradient comes out of the same launch (A is zero wherever k is padding).
   int ones_row_p1;
+  // Window views (audio slicing fused into the first encoder conv, utils.py:329-353 of the reference):
+  // the operand is (B*T, 1, window) windows of a padded track (B, S), window t of track b starting at
+  // b*S + t*hop, never materialised. The sample index n = b*T + t is then split once more:
+  //   row side (forward):  hi = n, offset = (n / rdiv2) * r_hi2_stride + (n % rdiv2) * r_hi_stride
+  //   k side (backward-weight, K = (n, l)): hi = n, offset = (n / kdiv2) * k_hi2_stride + (n % kdiv2) * k_hi_stride
+  // (0 = plain single-level index).
+  int rdiv2, r_hi2_stride;
+  float rdiv2_inv;
+  int kdiv2, k_hi2_stride;
 };
 
 struct M2dOutMap {

@@ -28,6 +28,14 @@ __device__ __forceinline__ float m2d_bload(__amdgpu_buffer_rsrc_t r, unsigned vo
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }
 
+// element offset of row-side index hi (two-level for window views, see M2dOperand)
+__device__ __forceinline__ int m2d_hi_offset(const M2dOperand& op, int hi) {
+  if (op.rdiv2 <= 0) return hi * op.r_hi_stride;
+  int q, r;
+  m2d_divmod(hi, op.rdiv2, op.rdiv2_inv, q, r);
+  return q * op.r_hi2_stride + r * op.r_hi_stride;
+}
+
 // Per-thread bookkeeping for one operand tile of BR rows x M2D_BK k-slots of a chunk
 // (hi, lo0 .. lo0 + 15).
 //   k-fast map  : thread owns ONE k-slot (tid % BK) and NE rows (tid / BK + i * 256 / BK):
@@ -66,7 +74,7 @@ struct TileMap {
         const bool rv = g < op.nrows;
         int hi, lo;
         m2d_divmod(rv ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
-        const int off = hi * op.r_hi_stride + lo * op.r_lo_stride + op.r_off + kb * op.k_lo_stride;
+        const int off = m2d_hi_offset(op, hi) + lo * op.r_lo_stride + op.r_off + kb * op.k_lo_stride;
         eoff[i] = rv ? ((unsigned)off << 2) : M2D_OOB;
       }
     } else {
@@ -77,7 +85,7 @@ struct TileMap {
       force_one = (g + 1 == op.ones_row_p1);
       int hi, lo;
       m2d_divmod(rv ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
-      const int off = hi * op.r_hi_stride + lo * op.r_lo_stride + op.r_off + kb * op.k_lo_stride;
+      const int off = m2d_hi_offset(op, hi) + lo * op.r_lo_stride + op.r_off + kb * op.k_lo_stride;
       eoff[0] = (unsigned)off << 2;
       posr = rv ? (op.lim > 0 ? lo * op.r_pos_mul + op.r_pos_off + kb * op.k_pos_lo : 0) : M2D_BAD;
     }
@@ -93,7 +101,12 @@ struct TileMap {
   template <bool UNIFORM>
   __device__ __forceinline__ void load(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rm,
                                        int hi, int lo0, int kdiv) {
-    const int S = (hi * op.k_hi_stride + lo0 * op.k_lo_stride) << 2;  // wave-uniform
+    int hoff = hi * op.k_hi_stride;
+    if (op.kdiv2 > 0) {  // window view on the k side: hi = b * T + t (one scalar division per chunk)
+      const int q = hi / op.kdiv2;
+      hoff = q * op.k_hi2_stride + (hi - q * op.kdiv2) * op.k_hi_stride;
+    }
+    const int S = (hoff + lo0 * op.k_lo_stride) << 2;  // wave-uniform
     if constexpr (KF) {
       if constexpr (UNIFORM) {
 #pragma unroll

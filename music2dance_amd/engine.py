@@ -406,14 +406,17 @@ class Phase1Engine(WganGpEngine):
 
 
 # =========================================================================================== synthetic data
-def synthetic_phase3_batch(B, T, device, seed=0, audio_rate=16000, video_rate=25, window_s=0.2):
+def synthetic_phase3_batch(B, T, device, seed=0, audio_rate=16000, video_rate=25, window_s=0.2, lazy=None):
     """Random poses / audio of the dataset's shapes: poses U[0,1) (B, T, 69),
-    audio N(0, 0.1^2) (B, T*640), windows of 3200 samples every 640."""
+    audio N(0, 0.1^2) (B, T*640), windows of 3200 samples every 640. On a HIP device the windows are
+    the in-place view of the padded track (lazy slicing: the generator's first conv gathers them)."""
     from .utils import slice_audio_batch
     g = torch.Generator().manual_seed(seed)
     hop = audio_rate // video_rate
     window = int(window_s * audio_rate)
     real = torch.rand(B, T, 69, generator=g).to(device)
     audio = (0.1 * torch.randn(B, hop * T, generator=g)).to(device)
-    slices = slice_audio_batch(audio, window, hop, window - hop)
+    if lazy is None:
+        lazy = torch.device(device).type == "cuda"
+    slices = slice_audio_batch(audio, window, hop, window - hop, lazy=lazy)
     return real, audio, slices

@@ -39,6 +39,19 @@ def _chk(*tensors):
     return dev
 
 
+def _chk_track(track, dev, T, hop, window):
+    """(B, >= (T-1)*hop + window) fp32 rows on `dev`, unit stride inside a row; -> (B, row stride)."""
+    if not track.is_cuda or track.device != dev or track.dtype != torch.float32 or track.dim() != 2:
+        raise _lib.M2dError("window view: the track must be a 2-D fp32 tensor on %s" % dev)
+    if track.stride(1) != 1 or track.size(1) < (T - 1) * hop + window:
+        raise _lib.M2dError("window view: rows must be dense and hold (T-1)*hop + window samples")
+    B = track.size(0)
+    S = track.stride(0) if B > 1 else track.size(1)
+    if S < (T - 1) * hop + window:
+        raise _lib.M2dError("window view: overlapping tracks")
+    return B, S
+
+
 def _stream(dev):
     # raw hipStream_t of the current stream without building a torch.cuda.Stream object
     return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
@@ -199,6 +212,42 @@ class HipKernels:
                                          _ptr(dy_mask), dy_mask_slope, _ptr(ws),
                                          0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_conv1d_bwd_weight")
+        return (dw, db) if with_bias else dw
+
+    # ---------------------------------------------------------------- conv over the windows of a padded track
+    def conv1d_fwd_windows(self, track, T, hop, window, w, bias, stride, pad, act=0, slope=0.0):
+        """track (B, S); logical input (B*T, 1, window), window t of track b = track[b, t*hop : t*hop + window]
+        (never materialised). -> y (B*T, Cout, Lout)."""
+        dev = _chk(w, bias)
+        B, S = _chk_track(track, dev, T, hop, window)
+        Cout, Cin, ks = w.shape
+        assert Cin == 1, "window views are single-channel"
+        Lout = conv_out_len(window, ks, stride, pad)
+        y = torch.empty((B * T, Cout, Lout), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 0, B * T, 1, window, Cout, ks, stride, pad), dev)
+        with _on(dev):
+            rc = h.m2d_conv1d_fwd_windows(_ptr(track), B, S, T, hop, window, _ptr(w), _ptr(bias), _ptr(y), Cout, ks,
+                                          stride, pad, act, slope, _ptr(ws), 0 if ws is None else ws.numel() * 4,
+                                          _stream(dev))
+        _lib.check(rc, "m2d_conv1d_fwd_windows")
+        return y
+
+    def conv1d_bwd_weight_windows(self, track, T, hop, window, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0,
+                                  with_bias=False):
+        dev = _chk(dy, dy_mask)
+        B, S = _chk_track(track, dev, T, hop, window)
+        N, Cout, Lout = dy.shape
+        assert N == B * T and Lout == conv_out_len(window, ks, stride, pad)
+        dw = torch.empty((Cout, 1, ks), dtype=torch.float32, device=dev)
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev) if with_bias else None
+        h = _lib.lib()
+        ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 2, B * T, 1, window, Cout, ks, stride, pad), dev)
+        with _on(dev):
+            rc = h.m2d_conv1d_bwd_weight_windows(_ptr(track), B, S, T, hop, window, _ptr(dy), _ptr(dw), _ptr(db), Cout,
+                                                 ks, stride, pad, _ptr(dy_mask), dy_mask_slope, _ptr(ws),
+                                                 0 if ws is None else ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_conv1d_bwd_weight_windows")
         return (dw, db) if with_bias else dw
 
     # ---------------------------------------------------------------- gemm

@@ -49,6 +49,14 @@ class Conv1d(nn.Conv1d):
         return ops.conv1d(x, self.weight, self.bias, self.stride[0], self.padding[0], act, slope, in_act, out_pm)
 
 
+    def forward_windows(self, track, T, hop, window, act=ops.ACT_NONE, slope=0.0):
+        """This (single input channel) conv over the windows of a padded track (B, S), read in place."""
+        if self.in_channels != 1 or self.dilation[0] != 1 or self.groups != 1 or self.padding_mode != "zeros":
+            raise NotImplementedError("m2d Conv1d.forward_windows: single-channel, undilated convs only")
+        return ops.conv1d_windows(track, T, hop, window, self.weight, self.bias, self.stride[0], self.padding[0],
+                                  act, slope)
+
+
 class Linear(nn.Linear):
     def forward(self, x, act=ops.ACT_NONE, slope=0.0):
         return ops.linear(x, self.weight, self.bias, act, slope)
@@ -96,6 +104,30 @@ class GRU(nn.GRU):
         for layer in range(self.num_layers):
             out = ops.gru_layer(out, *params[4 * layer:4 * layer + 4], lengths)
         return out, None
+
+
+class WindowView:
+    """(B, T, window) audio windows as a view of the padded track (B, S): window t of track b is
+    track[b, t*hop : t*hop + window]. What utils.slice_audio_batch(..., lazy=True) stands for."""
+
+    __slots__ = ("track", "T", "hop", "window")
+
+    def __init__(self, track, T, hop, window):
+        self.track, self.T, self.hop, self.window = track, int(T), int(hop), int(window)
+
+    @staticmethod
+    def of(x):
+        """WindowView of an overlapping-window strided tensor (unfold of a padded track), else None."""
+        if not torch.is_tensor(x) or x.dim() != 3 or x.stride(2) != 1 or not 0 < x.stride(1) < x.size(2):
+            return None
+        B, T, window = x.shape
+        hop = x.stride(1)
+        need = (T - 1) * hop + window
+        S = x.stride(0) if B > 1 else need
+        if S < need:
+            return None
+        # rows of `need` samples, S apart (the kernels take the row stride, not a dense tensor)
+        return WindowView(torch.as_strided(x, (B, need), (S, 1), x.storage_offset()), T, hop, window)
 
 
 def lengths_tensor(lengths, T, device):

@@ -241,6 +241,45 @@ def conv1d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, i
                             bool(out_pm))
 
 
+class _Conv1dWindows(Function):
+    """Conv1d(1, Cout, ...) (+ fused activation) over the windows of a padded track, read in place
+    (kernels.conv1d_fwd_windows). First-order only (generator path); the track gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, track, w, b, T, hop, window, stride, pad, act, slope):
+        ctx.set_materialize_grads(False)
+        track, w, b = _c(track), _c(w), _c(b)
+        y = K().conv1d_fwd_windows(track, T, hop, window, w, b, stride, pad, act, slope)
+        ctx.save_for_backward(track, w, y if act else None)
+        ctx.cfg = (T, hop, window, stride, pad, act, slope, b is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 10
+        track, w, y = ctx.saved_tensors
+        T, hop, window, stride, pad, act, slope, has_bias = ctx.cfg
+        mask, mslope = _mask_of(act, slope, y)
+        gy = _c(gy)
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            want_b = has_bias and ctx.needs_input_grad[2]
+            out = K().conv1d_bwd_weight_windows(track, T, hop, window, gy, w.shape[2], stride, pad, mask, mslope,
+                                                with_bias=want_b)
+            gw, gb = out if want_b else (out, None)
+        return (None, gw, gb) + (None,) * 7
+
+
+def conv1d_windows(track, T, hop, window, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0):
+    """conv1d over the (B*T, 1, window) windows of `track` (B, S) without materialising them."""
+    if track.requires_grad:
+        raise NotImplementedError("conv1d_windows: no gradient w.r.t. the audio track (materialise the slices)")
+    return _Conv1dWindows.apply(track, weight, bias, int(T), int(hop), int(window), int(stride), int(padding),
+                                int(act), float(slope))
+
+
 # --------------------------------------------------------------------------------------- linear
 class _LinearAct(Function):
     @staticmethod

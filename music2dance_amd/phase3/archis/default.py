@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...layers import GRU, BatchNorm1d, Conv1d, Linear, head_activation, lengths_tensor, to_device_async
+from ...layers import (GRU, BatchNorm1d, Conv1d, Linear, WindowView, head_activation, lengths_tensor,
+                       to_device_async)
 from ...utils import initialize_weights
 
 
@@ -29,6 +30,13 @@ def _descending(lengths):
 
 
 RELU_IN = (ops.ACT_RELU, 0.0)  # "my input is the sole-consumer output of a fused conv + ReLU" (ops.conv1d)
+
+
+def _first_conv(conv, x):
+    """first encoder conv on dense (N, 1, window) windows or, in place, on a WindowView of the padded track"""
+    if isinstance(x, WindowView):
+        return conv.forward_windows(x.track, x.T, x.hop, x.window)
+    return conv(x)
 
 
 def _head(module, conv, x, in_act=None):
@@ -121,8 +129,8 @@ class DefaultAudioEncoder(nn.Module):
         self.activations.append(mod)
 
     def forward(self, x):
-        for conv, post in zip(self.conv_layers[:-1], self.activations[:-1]):
-            x = post[0](conv(x), act=ops.ACT_RELU)
+        for i, (conv, post) in enumerate(zip(self.conv_layers[:-1], self.activations[:-1])):
+            x = post[0](_first_conv(conv, x) if i == 0 else conv(x), act=ops.ACT_RELU)
         return _head(self, self.conv_layers[-1], x).squeeze()
 
 
@@ -178,8 +186,8 @@ class UNetAudioEncoder(nn.Module):
         self.activ, self._head_act, self._head_tanh = head_activation(activ)
 
     def forward(self, x):
-        for conv, post in zip(self.conv_layers, self.activations):
-            x = post[0](conv(x), act=ops.ACT_LEAKY, slope=0.2)
+        for i, (conv, post) in enumerate(zip(self.conv_layers, self.activations)):
+            x = post[0](_first_conv(conv, x) if i == 0 else conv(x), act=ops.ACT_LEAKY, slope=0.2)
         return _head(self, self.fc, self.ublock(x)).squeeze()
 
 
@@ -203,7 +211,7 @@ class WaveGANAudioEncoder(nn.Module):
 
     def forward(self, x):
         for conv, bn in ((self.l1, self.bn1), (self.l2, self.bn2), (self.l3, self.bn3), (self.l4, self.bn4)):
-            x = bn(conv(x), act=ops.ACT_RELU)
+            x = bn(_first_conv(conv, x) if conv is self.l1 else conv(x), act=ops.ACT_RELU)
         return _head(self, self.l5, x).squeeze(-1)
 
 
@@ -250,7 +258,11 @@ class SequenceGenerator(nn.Module):
     def forward(self, x, lengths, noise=None):
         # x: (batch, frames, window)
         frames = x.size(1)
-        code = self.audio_enc(x.reshape(-1, 1, self.window_size)).view(-1, frames, self.input_size)
+        # an overlapping-window view of the padded track (utils.slice_audio_batch(..., lazy=True)) is read
+        # in place by the first encoder conv; a dense (B, T, window) tensor is used as the reference does
+        wv = WindowView.of(x) if (x.is_cuda and not x.requires_grad and x.size(2) == self.window_size) else None
+        enc_in = wv if wv is not None else x.reshape(-1, 1, self.window_size)
+        code = self.audio_enc(enc_in).view(-1, frames, self.input_size)
         if noise is None:
             # drawn from the HOST generator, then moved (phase3/archis/default.py:31-34)
             noise = to_device_async(torch.randn(list(code.size()[:-1]) + [self.noise_size]), code.device)

@@ -59,6 +59,15 @@ class FakeKernels:
         dw = torch.nn.grad.conv1d_weight(x, (dy.shape[1], x.shape[1], ks), dy, stride=stride, padding=pad)
         return (dw, dy.sum((0, 2))) if with_bias else dw
 
+    def conv1d_fwd_windows(self, track, T, hop, window, w, bias, stride, pad, act=0, slope=0.0):
+        x = track.unfold(-1, window, hop)[:, :T].reshape(-1, 1, window)
+        return self.conv1d_fwd(x, w, bias, stride, pad, act, slope)
+
+    def conv1d_bwd_weight_windows(self, track, T, hop, window, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0,
+                                  with_bias=False):
+        x = track.unfold(-1, window, hop)[:, :T].reshape(-1, 1, window)
+        return self.conv1d_bwd_weight(x, dy, ks, stride, pad, dy_mask, dy_mask_slope, with_bias)
+
     def gemm(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,
              out_mask_slope=0.0):
         if a_mask is not None:

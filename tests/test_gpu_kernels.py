@@ -531,3 +531,43 @@ def test_conv1d_random_shapes():
         assert rel_err(dx, gx) < 2e-5, "bwd_data " + tag
         assert rel_err(dw, gw) < 3e-5, "bwd_weight " + tag
         n_done += 1
+
+
+# ----------------------------------------------------------------------------------- window views
+WIN_CASES = [
+    ("default.c0", 3, 7, 640, 3200, 32, 250, 50, 124),
+    ("unet.c0", 2, 5, 640, 3200, 32, 160, 4, 79),
+    ("wavegan.l1-thin", 3, 6, 640, 3200, 32, 25, 4, 0),
+    ("odd-geometry", 4, 9, 37, 101, 8, 5, 2, 1),
+    ("one-track", 1, 12, 16, 64, 16, 7, 1, 3),
+]
+
+
+@pytest.mark.parametrize("case", WIN_CASES, ids=lambda c: c[0])
+def test_conv1d_over_track_windows_equals_conv_on_materialised_slices(case):
+    """Audio slicing fused into the first encoder conv (m2d_conv1d_fwd_windows / _bwd_weight_windows):
+    same kernels, same summation order as on the materialised (B*T, 1, window) slices -> bit-equal."""
+    _, B, T, hop, window, Cout, ks, s, p = case
+    S = (T - 1) * hop + window
+    track = gen(B, S, seed=1).to(DEV)
+    w = gen(Cout, 1, ks, seed=2, scale=1.0 / math.sqrt(ks)).to(DEV)
+    b = gen(Cout, seed=3, scale=0.1).to(DEV)
+    slices = track.unfold(-1, window, hop)
+    assert slices.shape == (B, T, window)
+    dense = slices.contiguous().view(B * T, 1, window)
+    k = K()
+    y_w = k.conv1d_fwd_windows(track, T, hop, window, w, b, s, p, act=1)
+    y_d = k.conv1d_fwd(dense, w, b, s, p, act=1)
+    assert torch.equal(y_w, y_d)
+    ref = F.conv1d(dense.cpu().double(), w.cpu().double(), b.cpu().double(), stride=s, padding=p).clamp_min(0)
+    assert rel_err(y_w, ref) < 2e-5
+    dy = gen(*y_d.shape, seed=4).to(DEV)
+    if y_d.shape[2] >= 16:
+        dw_w, db_w = k.conv1d_bwd_weight_windows(track, T, hop, window, dy, ks, s, p, dy_mask=y_d, dy_mask_slope=0.0,
+                                                 with_bias=True)
+        dw_d, db_d = k.conv1d_bwd_weight(dense, dy, ks, s, p, dy_mask=y_d, dy_mask_slope=0.0, with_bias=True)
+        assert torch.equal(dw_w, dw_d) and torch.equal(db_w, db_d)
+    # rows of a larger tensor (row stride > row length) are accepted as tracks
+    big = gen(B, S + 13, seed=5).to(DEV)
+    y_big = k.conv1d_fwd_windows(big[:, :S], T, hop, window, w, b, s, p)
+    assert torch.equal(y_big, k.conv1d_fwd(big[:, :S].unfold(-1, window, hop).contiguous().view(B * T, 1, window), w, b, s, p))

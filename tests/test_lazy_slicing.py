@@ -1,0 +1,50 @@
+"""utils.slice_audio_batch fused into the generator's first conv. The lazy
+form returns the reference's slices as an in-place view of the padded track; the generator gives
+the same poses and the same gradients from the view as from the materialised tensor."""
+import pytest
+import torch
+
+from music2dance_amd import kernels
+from music2dance_amd.layers import WindowView
+from music2dance_amd.utils import slice_audio_batch
+
+
+def test_lazy_slices_are_the_same_values_and_a_view():
+    audio = torch.randn(3, 640 * 9, generator=torch.Generator().manual_seed(0))
+    dense = slice_audio_batch(audio, 3200, 640, 2560)
+    lazy = slice_audio_batch(audio, 3200, 640, 2560, lazy=True)
+    assert dense.shape == lazy.shape == (3, 9, 3200) and torch.equal(dense, lazy)
+    assert dense.is_contiguous() and lazy.stride() == (640 * 9 + 2560, 640, 1)
+    wv = WindowView.of(lazy)
+    assert wv is not None and (wv.T, wv.hop, wv.window) == (9, 640, 3200) and wv.track.shape == (3, 8 * 640 + 3200)
+    assert WindowView.of(dense) is None  # a dense tensor has no overlapping windows to exploit
+    assert torch.equal(wv.track.unfold(-1, 3200, 640), dense)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("enc", ["default", "unet", "wavegan"])
+def test_generator_reads_windows_in_place(enc):
+    from music2dance_amd.phase3.archis.default import SequenceGenerator
+    assert kernels.impl().name == "hip"
+    dev = torch.device("cuda:0")
+    B, T = 3, 20
+    torch.manual_seed(0)
+    gen = SequenceGenerator(3200, 250, 250, 256, 69, 10, 2, 3, enc, "id", dev)
+    audio = (0.1 * torch.randn(B, 640 * T, generator=torch.Generator().manual_seed(1))).to(dev)
+    noise = torch.randn(B, T, 10, generator=torch.Generator().manual_seed(2)).to(dev)
+    lazy = slice_audio_batch(audio, 3200, 640, 2560, lazy=True)
+    dense = lazy.contiguous()
+    sd0 = {k: v.clone() for k, v in gen.state_dict().items()}
+    outs, grads = [], []
+    for x in (dense, lazy):
+        gen.load_state_dict(sd0)  # same BatchNorm buffers for both passes
+        gen.train()
+        gen.zero_grad(set_to_none=True)
+        rows = gen(x, [T] * B, noise)
+        rows.square().mean().backward()
+        outs.append(rows.detach().clone())
+        grads.append([p.grad.clone() for p in gen.parameters() if p.grad is not None])
+    assert torch.equal(outs[0], outs[1])
+    assert len(grads[0]) == len(grads[1])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
