@@ -136,6 +136,51 @@ def self_launch(args):
         sys.exit("bench.py: ranks failed (rank, exit code): %s" % bad)
 
 
+PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FAMILIES = ["gemm", "bn", "gru", "pointwise", "reduce"]
+
+
+def hbm_table(launches, steps):
+    """launches: kernels.prof_dump() rows. -> ({tag: {...}} for the memory-bound families, per-shape rows)."""
+    import collections
+    agg = collections.OrderedDict()
+    for fam, tag, d0, d1, d2, ms, flops, nbytes in launches:
+        a = agg.setdefault((fam, tag, d0, d1, d2), [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += flops
+        a[3] += nbytes
+    shapes = []
+    for (fam, tag, d0, d1, d2), (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        shapes.append((FAMILIES[fam], tag, d0, d1, d2, round(n / steps, 2), round(ms / steps, 4), round(1e3 * ms / n, 2),
+                       round(fl / ms / 1e9, 2) if ms > 0 else 0.0, round(by / ms / 1e6, 1) if ms > 0 else 0.0))
+    hbm = {}
+    for fam, tag, d0, d1, d2, ms, flops, nbytes in launches:
+        if FAMILIES[fam] == "gemm" or FAMILIES[fam] == "gru" or nbytes <= 0:
+            continue
+        big = nbytes >= 64e6
+        h = hbm.setdefault(tag or FAMILIES[fam], {"large": [0, 0.0, 0.0], "small": [0, 0.0, 0.0]})
+        b = h["large" if big else "small"]
+        b[0] += 1
+        b[1] += ms
+        b[2] += nbytes
+    out = {}
+    for tag, h in hbm.items():
+        e = {}
+        n, ms, by = h["large"]
+        if n:
+            gbps = by / ms / 1e6
+            e.update({"launches_per_step": round(n / steps, 2), "MB_per_launch": round(by / n / 1e6, 1),
+                      "us_per_launch": round(1e3 * ms / n, 1), "GBps": round(gbps, 0),
+                      "frac": round(gbps / PEAK_HBM_GBPS, 3)})
+        n, ms, by = h["small"]
+        if n:
+            e["small"] = {"launches_per_step": round(n / steps, 2), "us_per_launch": round(1e3 * ms / n, 1),
+                          "MB_per_launch": round(by / n / 1e6, 2)}
+        out[tag] = e
+    return out, shapes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default=None, choices=sorted(PRESETS),
@@ -153,6 +198,8 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="debug: all ranks on cuda:0 (with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel profile")
+    ap.add_argument("--dump-shapes", default=None, metavar="CSV",
+                    help="write the roofline pass's per-shape table (family, tag, dims, launches, ms, TF/s or GB/s)")
     ap.add_argument("--graphs", default="off", choices=["on", "off"],
                     help="replay each loop body's forward/backward from a captured HIP graph (Phase3Engine.enable_graphs)")
     args = ap.parse_args()
@@ -219,6 +266,7 @@ def main():
             engine.train_step(real, audio, slices)
         engine.flush()
         barrier()
+        launches = K.prof_dump()
         prof = K.prof_end()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -247,6 +295,12 @@ def main():
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
             traffic, traffic_src = pmc_traffic()
+            hbm, shapes = hbm_table(launches, args.steps)
+            if args.dump_shapes:
+                with open(args.dump_shapes, "w") as f:
+                    f.write("family,tag,d0,d1,d2,launches_per_step,ms_per_step,us_per_launch,tflops,gbps\n")
+                    for row in shapes:
+                        f.write(",".join(str(v) for v in row) + "\n")
             out["roofline"] = {
                 "measured_over": "second pass of the same %d steps with HIP events around every launch, "
                                  "critic branches serialised (in the timed region the pose branch overlaps the "
@@ -260,6 +314,9 @@ def main():
                 # every engine FLOP of a step over the step's wall time (all other kernels and gaps included)
                 "whole_step_frac": round(g["flops"] / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+                # memory-bound kernel families: algorithmic bytes / event time against 8.0 TB/s, over the
+                # launches that move >= 64 MB (smaller ones are launch-bound, listed under "small")
+                "hbm": hbm,
                 # the reference's own formulation executes 31.10 GFLOP per sequence consumed
                 # (SURVEY.md 8(d)); the engine skips work the reference discards, so this is
                 # an equivalent-work rate, not a kernel rate

@@ -40,7 +40,7 @@ int m2d_version(void);
  * Families: 0 gemm engine, 1 batch-norm, 2 gru, 3 pointwise, 4 reductions. */
 int m2d_prof_begin(void);
 int m2d_prof_end(double* out, int n_out /* >= 20 */);
-/* per-launch CSV "family,tag,d0,d1,d2,ms,flops" of the current session; call before m2d_prof_end */
+/* per-launch CSV "family,tag,d0,d1,d2,ms,flops,bytes" of the current session; call before m2d_prof_end */
 int m2d_prof_dump(char* buf, int cap);
 /* GEMM-engine launch plans (tile height, split-K factor) come from a cost model; with M2D_AUTOTUNE=1
  * the best few are timed once per operand shape, on the caller's operands, and the fastest is cached.

@@ -329,7 +329,7 @@ int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* run
     r.B = B; r.C = C; r.L = L;
     r.mode = 0;
     {
-      M2dProfScope prof(M2D_FAM_BN, stream, 0.0, bytes);
+      M2dProfScope prof(M2D_FAM_BN, stream, 0.0, bytes, "bn_stats", B, C, L);
       int rc = launch_reduce(r, stream);
       if (rc) return rc;
       hipLaunchKernelGGL(m2d_bn_finalize_fwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
@@ -353,7 +353,7 @@ int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* run
   a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
   a.row_len = C * L;
   a.act = act; a.slope = slope;
-  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, (residual ? 3.0 : 2.0) * bytes);
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, (residual ? 3.0 : 2.0) * bytes, "bn_apply", B, C, L);
   return launch_apply(a, B, stream);
 }
 
@@ -379,7 +379,7 @@ int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float*
   r.B = B; r.C = C; r.L = L;
   r.mode = 1; r.act = act; r.slope = slope;
   {
-    M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.0 * bytes);
+    M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.0 * bytes, "bn_bwd_reduce", B, C, L);
     int rc = launch_reduce(r, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(m2d_bn_finalize_bwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
@@ -395,7 +395,7 @@ int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float*
   a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
   a.row_len = C * L;
   a.backward = 1; a.act = act; a.slope = slope;
-  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 3.0 * bytes);
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 3.0 * bytes, "bn_bwd_apply", B, C, L);
   return launch_apply(a, B, stream);
 }
 
@@ -413,7 +413,7 @@ int m2d_channel_sums(const float* x, const float* mask, float slope, float* out,
   r.acc = (double*)ws;
   r.B = B; r.C = C; r.L = L;
   r.mode = 2;
-  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, (mask ? 8.0 : 4.0) * B * C * (double)L);
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, (mask ? 8.0 : 4.0) * B * C * (double)L, "channel_sums", B, C, L);
   int rc = launch_reduce(r, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(m2d_acc_to_float_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,

@@ -79,7 +79,7 @@ int m2d_prof_begin(void) {
 }
 
 // Per-launch dump of the records collected since m2d_prof_begin (call BEFORE m2d_prof_end):
-// one line "family,tag,d0,d1,d2,ms,flops" per launch. Returns the number of bytes written.
+// one line "family,tag,d0,d1,d2,ms,flops,bytes" per launch. Returns the number of bytes written.
 int m2d_prof_dump(char* buf, int cap) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   int n = 0;
@@ -88,7 +88,8 @@ int m2d_prof_dump(char* buf, int cap) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
     if (cap - n < 160) break;
-    n += snprintf(buf + n, cap - n, "%d,%s,%d,%d,%d,%.6f,%.0f\n", r.fam, r.tag, r.d[0], r.d[1], r.d[2], ms, r.flops);
+    n += snprintf(buf + n, cap - n, "%d,%s,%d,%d,%d,%.6f,%.0f,%.0f\n", r.fam, r.tag, r.d[0], r.d[1], r.d[2], ms, r.flops,
+                  r.bytes);
   }
   return n;
 }

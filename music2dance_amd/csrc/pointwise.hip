@@ -271,7 +271,7 @@ int m2d_gp_interpolate(const float* real, const float* fake, const float* alpha,
                        void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || n <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_gp_interpolate: bad shape");
-  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * B * (double)n);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * B * (double)n, "gp_interpolate");
   unsigned gx = grid_for((size_t)n, 64);
   hipLaunchKernelGGL(m2d_gp_interpolate_kernel, dim3(gx, B), dim3(256), 0, stream, real, fake, alpha, out, B, n);
   M2D_CHECK_LAUNCH("m2d_gp_interpolate_kernel");
@@ -299,7 +299,7 @@ int m2d_gp_penalty_bwd(const float* g, const float* norms, const float* gout, fl
                        void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || n <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_gp_penalty_bwd: bad shape");
-  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 8.0 * B * (double)n);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 8.0 * B * (double)n, "gp_penalty_bwd");
   unsigned gx = grid_for((size_t)n, 64);
   hipLaunchKernelGGL(m2d_gp_penalty_bwd_kernel, dim3(gx, B), dim3(256), 0, stream, g, norms, gout, dg, B, n, lp);
   M2D_CHECK_LAUNCH("m2d_gp_penalty_bwd_kernel");
@@ -314,7 +314,7 @@ int m2d_l1_mean_fwd(const float* a, const float* b, float* out, size_t n, void* 
   hipStream_t stream = (hipStream_t)stream_;
   if (n == 0) M2D_FAIL(M2D_ERR_ARG, "m2d_l1_mean_fwd: empty");
   if (!ws || ws_bytes < m2d_reduce_workspace_bytes()) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_l1_mean_fwd: workspace");
-  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 8.0 * (double)n);
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 8.0 * (double)n, "l1_mean_fwd");
   const unsigned gx = grid_for(n);
   hipLaunchKernelGGL(m2d_absdiff_partial_kernel, dim3(gx), dim3(256), 0, stream, a, b, n, (double*)ws);
   hipLaunchKernelGGL(m2d_finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, (int)gx,
@@ -325,7 +325,7 @@ int m2d_l1_mean_fwd(const float* a, const float* b, float* out, size_t n, void* 
 
 int m2d_l1_mean_bwd(const float* a, const float* b, const float* gout, float* da, size_t n, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * (double)n);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * (double)n, "l1_mean_bwd");
   hipLaunchKernelGGL(m2d_absdiff_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, b, gout, da, n);
   M2D_CHECK_LAUNCH("m2d_l1_mean_bwd");
   return M2D_OK;
@@ -338,7 +338,7 @@ int m2d_tv_mean_fwd(const float* x, float* out, int B, int C, int T, long sb, lo
   if (B <= 0 || C <= 0 || T < 2) M2D_FAIL(M2D_ERR_ARG, "m2d_tv_mean_fwd: bad shape");
   if (!ws || ws_bytes < m2d_reduce_workspace_bytes()) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_tv_mean_fwd: workspace");
   const size_t total = (size_t)B * C * (T - 1);
-  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 4.0 * (double)total);
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 4.0 * (double)total, "tv_mean_fwd");
   const unsigned gx = grid_for(total);
   hipLaunchKernelGGL(m2d_tv_partial_kernel, dim3(gx), dim3(256), 0, stream, x, B, C, T, sb, sc, st, (double*)ws);
   hipLaunchKernelGGL(m2d_finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, (int)gx,
@@ -352,7 +352,7 @@ int m2d_tv_mean_bwd(const float* x, const float* gout, float* dx, int B, int C, 
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || C <= 0 || T < 2) M2D_FAIL(M2D_ERR_ARG, "m2d_tv_mean_bwd: bad shape");
   const size_t total = (size_t)B * C * T;
-  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 8.0 * (double)total);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 8.0 * (double)total, "tv_mean_bwd");
   hipLaunchKernelGGL(m2d_tv_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, gout, dx, B, C, T, sb, sc, st);
   M2D_CHECK_LAUNCH("m2d_tv_mean_bwd");
   return M2D_OK;
@@ -363,7 +363,7 @@ int m2d_maxpool2_fwd(const float* x, float* y, size_t rows, int L, void* stream_
   hipStream_t stream = (hipStream_t)stream_;
   const int Lout = L / 2;
   if (rows == 0 || Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_maxpool2_fwd: bad shape");
-  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 6.0 * rows * (double)L);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 6.0 * rows * (double)L, "maxpool2_fwd");
   hipLaunchKernelGGL(m2d_maxpool2_fwd_kernel, dim3(grid_for(rows * Lout, 4096)), dim3(256), 0, stream, x, y, rows, L, Lout);
   M2D_CHECK_LAUNCH("m2d_maxpool2_fwd");
   return M2D_OK;
@@ -373,7 +373,7 @@ int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, in
   hipStream_t stream = (hipStream_t)stream_;
   const int Lout = L / 2;
   if (rows == 0 || Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_maxpool2_bwd: bad shape");
-  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 10.0 * rows * (double)L);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 10.0 * rows * (double)L, "maxpool2_bwd");
   hipLaunchKernelGGL(m2d_maxpool2_bwd_kernel, dim3(grid_for(rows * L, 4096)), dim3(256), 0, stream, x, dy, dx, rows, L, Lout);
   M2D_CHECK_LAUNCH("m2d_maxpool2_bwd");
   return M2D_OK;
@@ -383,7 +383,7 @@ int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, in
 int m2d_upsample2_fwd(const float* x, float* y, size_t rows, int L, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (rows == 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_fwd: bad shape");
-  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L, "upsample2_fwd");
   hipLaunchKernelGGL(m2d_upsample2_fwd_kernel, dim3(grid_for(rows * 2 * L, 4096)), dim3(256), 0, stream, x, y, rows, L);
   M2D_CHECK_LAUNCH("m2d_upsample2_fwd");
   return M2D_OK;
@@ -392,7 +392,7 @@ int m2d_upsample2_fwd(const float* x, float* y, size_t rows, int L, void* stream
 int m2d_upsample2_bwd(const float* dy, float* dx, size_t rows, int L, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (rows == 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_bwd: bad shape");
-  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L);
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L, "upsample2_bwd");
   hipLaunchKernelGGL(m2d_upsample2_bwd_kernel, dim3(grid_for(rows * L, 4096)), dim3(256), 0, stream, dy, dx, rows, L);
   M2D_CHECK_LAUNCH("m2d_upsample2_bwd");
   return M2D_OK;

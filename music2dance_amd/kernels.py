@@ -507,14 +507,15 @@ class HipKernels:
         _lib.check(_lib.lib().m2d_prof_begin(), "m2d_prof_begin")
 
     def prof_dump(self):
-        """[(family, tag, d0, d1, d2, ms, flops)] per launch of the current profiling session."""
+        """[(family, tag, d0, d1, d2, ms, flops, bytes)] per launch of the current profiling session."""
         cap = 1 << 22
         buf = ctypes.create_string_buffer(cap)
         n = _lib.lib().m2d_prof_dump(buf, cap)
         rows = []
         for line in buf.raw[:n].decode().splitlines():
             f = line.split(",")
-            rows.append((int(f[0]), f[1], int(f[2]), int(f[3]), int(f[4]), float(f[5]), float(f[6])))
+            rows.append((int(f[0]), f[1], int(f[2]), int(f[3]), int(f[4]), float(f[5]), float(f[6]),
+                         float(f[7]) if len(f) > 7 else 0.0))
         return rows
 
     def prof_end(self):

@@ -37,7 +37,7 @@ for name, fn in (("critic", lambda: eng.critic_iteration(real, audio, slices)), 
     K.prof_begin(); fn(); eng.flush(); torch.cuda.synchronize()
     rows = K.prof_dump(); K.prof_end()
     agg = collections.OrderedDict()
-    for fam, tag, d0, d1, d2, ms, fl in rows:
+    for fam, tag, d0, d1, d2, ms, fl, _by in rows:
         if fam != 0 and not tag.startswith('thin'): continue
         k = (tag, d0, d1, d2)
         a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl

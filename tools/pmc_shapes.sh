@@ -1,8 +1,13 @@
+# PMC passes over tools/pmc_shapes.py (counters in their own runs: --kernel-trace + --pmc only).
 R=$GRAFT_REPO_ROOT
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_INSTS_SMEM" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_sum"; do
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_INSTS_SMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/shp_pmc/g$i -- python3 $R/tools/pmc_shapes.py > $R/gpurun_out/shp_pmc_g$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_shp_pmc/g$i -- python3 $R/tools/pmc_shapes.py > $R/gpurun_out/${TAG}_shp_pmc_g$i.log 2>&1
 done
-ls $R/gpurun_out/shp_pmc/*/* | head -30
+cd $R
+python3 tools/pmc_shapes_summary.py gpurun_out/${TAG}_shp_pmc > gpurun_out/${TAG}_pmc_shapes.json
+rm -rf gpurun_out/${TAG}_shp_pmc gpurun_out/${TAG}_shp_pmc_g*.log
+cat gpurun_out/${TAG}_pmc_shapes.json | head -60
