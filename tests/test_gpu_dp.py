@@ -63,3 +63,60 @@ def test_two_ranks_one_gpu(graphs):
     assert set(v0) == {"loss_critic", "gp", "w_dist", "loss_gen", "l1_loss_train"}
     for a, b in zip(s0, s1):  # parameters stay in lock-step across ranks
         assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (s0, s1)
+
+
+def _rccl_worker(port, q):
+    """backend "nccl" = RCCL: the exchange (fused pack, ReduceOp.AVG on the communication stream, gradient
+    views) and the deferred critic step on the real library, at world size 1 (one GPU per box here)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import bench
+    from music2dance_amd.dp import GradExchange
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+    dev = torch.device("cuda:0")
+    # the exchange alone: averaged over one rank = unchanged values, now views of the buckets
+    params = [torch.nn.Parameter(torch.randn(300, 7, device=dev)), torch.nn.Parameter(torch.randn(11, device=dev)),
+              torch.nn.Parameter(torch.randn(5, device=dev))]
+    params[0].grad, params[1].grad = torch.randn(300, 7, device=dev), torch.randn(11, device=dev)
+    want = [params[0].grad.clone(), params[1].grad.clone()]
+    ex = GradExchange(params, bucket_mb=1e-3, force=True)
+    assert ex.active and len(ex.buckets) >= 2
+    ex.exchange()
+    torch.cuda.synchronize()
+    ok = torch.equal(params[0].grad, want[0]) and torch.equal(params[1].grad, want[1]) and params[2].grad is None
+    flat_ptrs = {v.data_ptr() for views in ex._views for v in views}
+    ok = ok and params[0].grad.data_ptr() in flat_ptrs and params[1].grad.data_ptr() in flat_ptrs
+    # the engine with the exchange forced on: same losses and parameters as without it
+    sigs = []
+    for forced in (False, True):
+        gen, critic = bench.build_models(dev, 120)
+        eng = Phase3Engine(gen, critic, dict(bench.P3_DEFAULT, n_critic_steps=2))
+        eng.x_critic.force = eng.x_gen.force = forced
+        real, audio, slices = synthetic_phase3_batch(4, 120, dev, seed=60)
+        torch.manual_seed(9)
+        for _ in range(4):
+            out = eng.train_step(real, audio, slices)
+        eng.flush()
+        torch.cuda.synchronize()
+        sigs.append(([float(v) for v in out.values()],
+                     [float(p.detach().double().sum()) for p in list(critic.parameters())[:6] + list(gen.parameters())[:6]],
+                     int(next(iter(eng.optim_critic.state.values()))["step"])))
+    q.put((ok, sigs))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_exchange_world_size_one():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    ok, sigs = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0 and ok
+    (l0, s0, n0), (l1, s1, n1) = sigs
+    assert n0 == n1 == 4  # every critic step taken, deferred or not
+    for a, b in zip(l0 + s0, l1 + s1):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (sigs)
