@@ -51,10 +51,13 @@ int m2d_plan_cache_size(void);
  * reference: phase3/archis/default.py:64-70 (DefaultAudioEncoder), :90-97,216 (U-Net),
  * :117-128 (WaveGAN), :201-204 (TemporalBlock), :298-303 (AudioDiscriminator),
  * :326-333 (StickDiscriminator); phase2/archis/default.py:31-38,154-157. */
+/* `stats` (optional, 2*Cout doubles, zeroed by the call): stats[2c] += sum, stats[2c+1] += sum of squares of
+ * the stored y[:, c, :] - the batch statistics a following BatchNorm needs (m2d_bn_fwd_sums), taken in the
+ * conv's epilogue instead of a second pass over y. */
 int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
                    int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
-                   const float* residual, const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes,
-                   void* stream);
+                   const float* residual, const float* out_mask, float out_mask_slope, double* stats, void* ws,
+                   size_t ws_bytes, void* stream);
 /* `out_mask` (optional, shape of dx): the result is multiplied by (mask>0 ? 1 : out_mask_slope) in the
  * epilogue - the activation derivative of the layer that produced x, so that a chain of fused
  * conv + ReLU layers hands each other gradients that are already masked (no masked operand loads). */
@@ -73,7 +76,7 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbi
  * m2d_conv1d_workspace_bytes(0 / 2, B*T, 1, window, ...). */
 int m2d_conv1d_fwd_windows(const float* track, int B, int S, int T, int hop, int window, const float* w,
                            const float* bias, float* y, int Cout, int ks, int stride, int pad, int act, float slope,
-                           void* ws, size_t ws_bytes, void* stream);
+                           double* stats, void* ws, size_t ws_bytes, void* stream);
 int m2d_conv1d_bwd_weight_windows(const float* track, int B, int S, int T, int hop, int window, const float* dy,
                                   float* dw, float* dbias, int Cout, int ks, int stride, int pad,
                                   const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes, void* stream);
@@ -104,6 +107,23 @@ int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* run
 int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                const float* save_invstd, float* dx, float* dgamma, float* dbeta, int B, int C, int L, int act,
                float slope, void* ws, size_t ws_bytes, void* stream);
+/* The same in two halves, statistics as raw fp64 sums (sums[2c] = sum x, sums[2c+1] = sum x^2 over `count`
+ * elements per channel; backward: sum dz, sum dz*xhat). Lets a producing conv supply the forward sums
+ * (m2d_conv1d_fwd `stats`) and lets data-parallel ranks all-reduce them between the halves
+ * (synchronised BatchNorm: global-batch statistics; `count` is then the global element count,
+ * `sums_global` the all-reduced buffer, `sums_local` this rank's own for dgamma / dbeta). */
+int m2d_bn_stats(const float* x, double* sums, int B, int C, int L, void* stream);
+int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
+                    int C, int L, float eps, float momentum, int act, float slope, const float* residual,
+                    void* stream);
+int m2d_bn_bwd_stats(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                     const float* save_invstd, double* sums, int B, int C, int L, int act, float slope,
+                     void* stream);
+int m2d_bn_bwd_sums(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                    const float* save_invstd, const double* sums_local, const double* sums_global, double count,
+                    float* dx, float* dgamma, float* dbeta, int B, int C, int L, int act, float slope, void* ws,
+                    size_t ws_bytes, void* stream);
 int m2d_channel_sums(const float* x, const float* mask, float slope, float* out, int B, int C, int L, void* ws,
                      size_t ws_bytes, void* stream);
 

@@ -25,11 +25,11 @@ SIGNATURES = {
     "m2d_prof_end": (_I, [_c.POINTER(_c.c_double), _I]),
     "m2d_prof_dump": (_I, [_c.c_char_p, _I]),
     "m2d_plan_cache_size": (_I, []),
-    "m2d_conv1d_fwd": (_I, [_F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _I, _f, _F, _F, _f, _F, _S, _F]),
+    "m2d_conv1d_fwd": (_I, [_F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _I, _f, _F, _F, _f, _F, _F, _S, _F]),
     "m2d_conv1d_bwd_data": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _f, _F, _S, _F]),
     "m2d_conv1d_pack_weights": (_I, [_F, _F, _F, _I, _I, _I, _F]),
     "m2d_conv1d_bwd_weight": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _S, _F]),
-    "m2d_conv1d_fwd_windows": (_I, [_F, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _I, _f, _F, _S, _F]),
+    "m2d_conv1d_fwd_windows": (_I, [_F, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _I, _f, _F, _F, _S, _F]),
     "m2d_conv1d_bwd_weight_windows": (_I, [_F, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _F, _f, _F, _S, _F]),
     "m2d_conv1d_workspace_bytes": (_S, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "m2d_gemm": (_I, [_I, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _f, _F, _f, _F, _S, _F]),
@@ -37,6 +37,10 @@ SIGNATURES = {
     "m2d_bn_workspace_bytes": (_S, [_I]),
     "m2d_bn_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _I, _f, _F, _F, _S, _F]),
     "m2d_bn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F]),
+    "m2d_bn_stats": (_I, [_F, _F, _I, _I, _I, _F]),
+    "m2d_bn_fwd_sums": (_I, [_F, _F, _c.c_double, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _f, _F, _F]),
+    "m2d_bn_bwd_stats": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F]),
+    "m2d_bn_bwd_sums": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _c.c_double, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F]),
     "m2d_channel_sums": (_I, [_F, _F, _f, _F, _I, _I, _I, _F, _S, _F]),
     "m2d_gru_layer_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
     "m2d_gru_layer_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),

@@ -205,14 +205,16 @@ __global__ void m2d_bn_eval_stats_kernel(const float* running_mean, const float*
   invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-__global__ void m2d_bn_finalize_bwd_kernel(const double* acc, float* dgamma, float* dbeta, float* s_dz,
-                                           float* s_dzx, int C, double count) {
+// acc: this process's sums (parameter gradients); acc_g / count: the sums and element count the batch
+// statistics were taken over (the same buffer, or the all-reduced one under synchronised BatchNorm)
+__global__ void m2d_bn_finalize_bwd_kernel(const double* acc, const double* acc_g, float* dgamma, float* dbeta,
+                                           float* s_dz, float* s_dzx, int C, double count) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   dbeta[c] = (float)acc[2 * c];
   dgamma[c] = (float)acc[2 * c + 1];
-  s_dz[c] = (float)(acc[2 * c] / count);
-  s_dzx[c] = (float)(acc[2 * c + 1] / count);
+  s_dz[c] = (float)(acc_g[2 * c] / count);
+  s_dzx[c] = (float)(acc_g[2 * c + 1] / count);
 }
 
 __global__ void m2d_acc_to_float_kernel(const double* acc, float* out, int C) {
@@ -307,6 +309,60 @@ extern "C" {
 // bytes of scratch every bn / channel-sum call needs (fp64 accumulators + 2 float rows)
 size_t m2d_bn_workspace_bytes(int C) { return (size_t)C * (2 * sizeof(double) + 2 * sizeof(float)) + 64; }
 
+static int bn_check(const char* who, int B, int C, int L) {
+  if (B <= 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "%s: bad shape", who);
+  if ((long long)C * L >= 16777216LL) M2D_FAIL(M2D_ERR_RANGE, "%s: C*L too large", who);
+  return M2D_OK;
+}
+
+static int bn_apply_fwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                        float* y, int B, int C, int L, int act, float slope, const float* residual, hipStream_t stream) {
+  BnApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x;
+  a.residual = residual;
+  a.gamma = gamma; a.beta = beta;
+  a.mean = mean; a.invstd = invstd;
+  a.out = y;
+  a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
+  a.row_len = C * L;
+  a.act = act; a.slope = slope;
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, (residual ? 3.0 : 2.0) * 4.0 * B * C * (double)L, "bn_apply", B, C, L);
+  return launch_apply(a, B, stream);
+}
+
+// The batch statistics as raw sums: sums[2c] = sum x, sums[2c + 1] = sum x^2 over (batch, length), fp64.
+// Split from the normalisation so that (a) a producing conv can hand the sums over from its own
+// epilogue (m2d_conv1d_fwd's `stats`) and (b) data-parallel ranks can all-reduce them
+// (synchronised BatchNorm: global-batch statistics).
+int m2d_bn_stats(const float* x, double* sums, int B, int C, int L, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int rc = bn_check("m2d_bn_stats", B, C, L)) return rc;
+  BnReduceArgs r;
+  memset(&r, 0, sizeof(r));
+  r.x = x;
+  r.acc = sums;
+  r.B = B; r.C = C; r.L = L;
+  r.mode = 0;
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 4.0 * B * C * (double)L, "bn_stats", B, C, L);
+  return launch_reduce(r, stream);
+}
+
+// Training forward from given sums over `count` elements per channel (count = B*L, or the global
+// count under synchronised BatchNorm): mean / invstd, running statistics, then y = residual + act(bn(x)).
+int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
+                    int C, int L, float eps, float momentum, int act, float slope, const float* residual,
+                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int rc = bn_check("m2d_bn_fwd_sums", B, C, L)) return rc;
+  if (!sums || !(count > 0.0)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd_sums: no statistics");
+  hipLaunchKernelGGL(m2d_bn_finalize_fwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream, sums, save_mean,
+                     save_invstd, running_mean, running_var, C, count, eps, momentum);
+  M2D_CHECK_LAUNCH("m2d_bn_finalize_fwd_kernel");
+  return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream);
+}
+
 // Training / eval forward of nn.BatchNorm1d fused with ReLU (act=1) / LeakyReLU (act=2)
 // and an optional residual add: y = residual + act(bn(x)).
 // training != 0: batch statistics, running stats updated in place (may be NULL),
@@ -317,75 +373,54 @@ int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* run
                float eps, float momentum, int training, int act, float slope, const float* residual,
                void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (B <= 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd: bad shape");
-  if ((long long)C * L >= 16777216LL) M2D_FAIL(M2D_ERR_RANGE, "m2d_bn_fwd: C*L too large");
+  if (int rc = bn_check("m2d_bn_fwd", B, C, L)) return rc;
   if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_fwd: workspace too small");
-  const double bytes = 4.0 * B * C * (double)L;
   if (training) {
-    BnReduceArgs r;
-    memset(&r, 0, sizeof(r));
-    r.x = x;
-    r.acc = (double*)ws;
-    r.B = B; r.C = C; r.L = L;
-    r.mode = 0;
-    {
-      M2dProfScope prof(M2D_FAM_BN, stream, 0.0, bytes, "bn_stats", B, C, L);
-      int rc = launch_reduce(r, stream);
-      if (rc) return rc;
-      hipLaunchKernelGGL(m2d_bn_finalize_fwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
-                         (const double*)ws, save_mean, save_invstd, running_mean, running_var, C,
-                         (double)B * L, eps, momentum);
-      M2D_CHECK_LAUNCH("m2d_bn_finalize_fwd_kernel");
-    }
-  } else {
-    if (!running_mean || !running_var) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd: eval mode needs running stats");
-    hipLaunchKernelGGL(m2d_bn_eval_stats_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
-                       (const float*)running_mean, (const float*)running_var, save_mean, save_invstd, C, eps);
-    M2D_CHECK_LAUNCH("m2d_bn_eval_stats_kernel");
+    if (int rc = m2d_bn_stats(x, (double*)ws, B, C, L, stream_)) return rc;
+    return m2d_bn_fwd_sums(x, (const double*)ws, (double)B * L, gamma, beta, running_mean, running_var, y, save_mean,
+                           save_invstd, B, C, L, eps, momentum, act, slope, residual, stream_);
   }
-  BnApplyArgs a;
-  memset(&a, 0, sizeof(a));
-  a.x = x;
-  a.residual = residual;
-  a.gamma = gamma; a.beta = beta;
-  a.mean = save_mean; a.invstd = save_invstd;
-  a.out = y;
-  a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
-  a.row_len = C * L;
-  a.act = act; a.slope = slope;
-  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, (residual ? 3.0 : 2.0) * bytes, "bn_apply", B, C, L);
-  return launch_apply(a, B, stream);
+  if (!running_mean || !running_var) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd: eval mode needs running stats");
+  hipLaunchKernelGGL(m2d_bn_eval_stats_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
+                     (const float*)running_mean, (const float*)running_var, save_mean, save_invstd, C, eps);
+  M2D_CHECK_LAUNCH("m2d_bn_eval_stats_kernel");
+  return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream);
 }
 
-// Training-mode backward. dz = dy * act'(bn(x)) is recomputed from x (no y needed):
-//   dgamma = sum(dz * xhat), dbeta = sum(dz),
-//   dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)).
-int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
-               const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
-               int B, int C, int L, int act, float slope, void* ws, size_t ws_bytes, void* stream_) {
+// Backward reductions as raw sums: sums[2c] = sum dz, sums[2c + 1] = sum dz * xhat, with
+// dz = dy * act'(bn(x)) recomputed from x (no y needed).
+int m2d_bn_bwd_stats(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                     const float* save_invstd, double* sums, int B, int C, int L, int act, float slope,
+                     void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (B <= 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_bwd: bad shape");
-  if ((long long)C * L >= 16777216LL) M2D_FAIL(M2D_ERR_RANGE, "m2d_bn_bwd: C*L too large");
-  if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_bwd: workspace too small");
-  const double bytes = 4.0 * B * C * (double)L;
-  double* acc = (double*)ws;
-  float* s_dz = (float*)(acc + 2 * (size_t)C);
-  float* s_dzx = s_dz + C;
+  if (int rc = bn_check("m2d_bn_bwd_stats", B, C, L)) return rc;
   BnReduceArgs r;
   memset(&r, 0, sizeof(r));
   r.x = x; r.dy = dy;
   r.gamma = gamma; r.beta = beta; r.mean = save_mean; r.invstd = save_invstd;
-  r.acc = acc;
+  r.acc = sums;
   r.B = B; r.C = C; r.L = L;
   r.mode = 1; r.act = act; r.slope = slope;
-  {
-    M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.0 * bytes, "bn_bwd_reduce", B, C, L);
-    int rc = launch_reduce(r, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(m2d_bn_finalize_bwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
-                       (const double*)acc, dgamma, dbeta, s_dz, s_dzx, C, (double)B * L);
-    M2D_CHECK_LAUNCH("m2d_bn_finalize_bwd_kernel");
-  }
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.0 * 4.0 * B * C * (double)L, "bn_bwd_reduce", B, C, L);
+  return launch_reduce(r, stream);
+}
+
+// Training-mode backward from the sums: dgamma = sum(dz * xhat), dbeta = sum(dz) from THIS process's
+// sums, dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) with the means over the batch the
+// statistics were taken over (`sums_global` / `count`: the same buffer and B*L, or all-reduced).
+int m2d_bn_bwd_sums(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                    const float* save_invstd, const double* sums_local, const double* sums_global, double count,
+                    float* dx, float* dgamma, float* dbeta, int B, int C, int L, int act, float slope, void* ws,
+                    size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int rc = bn_check("m2d_bn_bwd_sums", B, C, L)) return rc;
+  if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_bwd_sums: workspace too small");
+  if (!sums_local || !sums_global || !(count > 0.0)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_bwd_sums: no sums");
+  float* s_dz = (float*)((double*)ws + 2 * (size_t)C);
+  float* s_dzx = s_dz + C;
+  hipLaunchKernelGGL(m2d_bn_finalize_bwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream, sums_local,
+                     sums_global, dgamma, dbeta, s_dz, s_dzx, C, count);
+  M2D_CHECK_LAUNCH("m2d_bn_finalize_bwd_kernel");
   BnApplyArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.dy = dy;
@@ -395,8 +430,20 @@ int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float*
   a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
   a.row_len = C * L;
   a.backward = 1; a.act = act; a.slope = slope;
-  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 3.0 * bytes, "bn_bwd_apply", B, C, L);
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 3.0 * 4.0 * B * C * (double)L, "bn_bwd_apply", B, C, L);
   return launch_apply(a, B, stream);
+}
+
+// Training-mode backward (single process): the two calls above on the workspace.
+int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
+               const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+               int B, int C, int L, int act, float slope, void* ws, size_t ws_bytes, void* stream_) {
+  if (int rc = bn_check("m2d_bn_bwd", B, C, L)) return rc;
+  if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_bwd: workspace too small");
+  if (int rc = m2d_bn_bwd_stats(dy, x, gamma, beta, save_mean, save_invstd, (double*)ws, B, C, L, act, slope, stream_))
+    return rc;
+  return m2d_bn_bwd_sums(dy, x, gamma, beta, save_mean, save_invstd, (const double*)ws, (const double*)ws,
+                         (double)B * L, dx, dgamma, dbeta, B, C, L, act, slope, ws, ws_bytes, stream_);
 }
 
 // out[c] = sum_{n,l} x[n,c,l] * (mask ? (mask[n,c,l] > 0 ? 1 : slope) : 1)

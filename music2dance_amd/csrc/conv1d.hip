@@ -27,9 +27,10 @@ struct M2dWinView {
 };
 bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride);
 size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout);
+size_t m2d_thin_fwd_stats_ws(int B, int Lout);
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
                  int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
-                 const M2dWinView* wv, hipStream_t stream);
+                 const M2dWinView* wv, double* stats, void* ws, size_t ws_bytes, hipStream_t stream);
 int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, int Cout, int ks, int stride,
                       int pad, int Lout, const float* dy_mask, float dy_mask_slope, hipStream_t stream);
 int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int L, int Cout, int ks,
@@ -157,7 +158,8 @@ int m2d_conv1d_pack_weights(const float* w, float* w_fwd, float* w_bwd, int Cout
 static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
                            int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
                            const float* residual, const float* out_mask, float out_mask_slope, void* ws,
-                           size_t ws_bytes, void* stream, const M2dWinView* wv) {
+                           size_t ws_bytes, void* stream, const M2dWinView* wv, double* stats) {
+
   if (B <= 0 || Cin <= 0 || Cout <= 0 || ks <= 0 || stride <= 0 || pad < 0 || L <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd: bad shape B=%d Cin=%d L=%d Cout=%d k=%d s=%d p=%d", B, Cin, L,
              Cout, ks, stride, pad);
@@ -167,7 +169,7 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd: tensor exceeds 2^31 elements");
   if (!residual && m2d_thin_applicable(Cin, Cout, ks, stride))
     return m2d_thin_fwd(x, w, bias, y, B, L, Cout, ks, stride, pad, Lout, act, slope, out_mask, out_mask_slope,
-                        wv, (hipStream_t)stream);
+                        wv, stats, ws, ws_bytes, (hipStream_t)stream);
   if (wv && (Cin != 1 || (Lout == 1 && pad == 0 && L == ks)))
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd_windows: window views are single-channel, non-degenerate convolutions");
   if (Lout == 1 && pad == 0 && L == ks) {
@@ -191,6 +193,11 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
     p.O.residual = residual;
     p.O.mask = out_mask;
     p.O.mask_slope = out_mask_slope;
+    if (stats) {
+      if (!ws || ws_bytes < m2d_rowstats_bytes(p.M, p.N)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd: no room for the statistics partials");
+      p.O.row_part = (float*)ws;
+      p.O.row_sums = stats;
+    }
     return m2d_gemm_launch(p, true, true, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_fwd");
   }
   if (conv_uses_packed(Cin) && !w_packed) {
@@ -211,16 +218,21 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
   p.O.residual = residual;
   p.O.mask = out_mask;
   p.O.mask_slope = out_mask_slope;
+  if (stats) {  // no split-K with statistics, so the slab room holds the partials
+    if (!ws || ws_bytes < m2d_rowstats_bytes(p.M, p.N)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd: no room for the statistics partials");
+    p.O.row_part = (float*)ws;
+    p.O.row_sums = stats;
+  }
   return m2d_gemm_launch(p, /*a_kfast=*/true, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
                          (hipStream_t)stream, "m2d_conv1d_fwd");
 }
 
 int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
                    int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
-                   const float* residual, const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes,
-                   void* stream) {
+                   const float* residual, const float* out_mask, float out_mask_slope, double* stats, void* ws,
+                   size_t ws_bytes, void* stream) {
   return conv1d_fwd_impl(x, w, w_packed, bias, y, B, Cin, L, Cout, ks, stride, pad, act, slope, residual, out_mask,
-                         out_mask_slope, ws, ws_bytes, stream, nullptr);
+                         out_mask_slope, ws, ws_bytes, stream, nullptr, stats);
 }
 
 // The first conv of an audio encoder applied to the windows of a padded track WITHOUT writing the
@@ -229,7 +241,7 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const 
 // track b = track[b, t*hop : t*hop + window]; y: (B*T, Cout, Lout).
 int m2d_conv1d_fwd_windows(const float* track, int B, int S, int T, int hop, int window, const float* w,
                            const float* bias, float* y, int Cout, int ks, int stride, int pad, int act, float slope,
-                           void* ws, size_t ws_bytes, void* stream) {
+                           double* stats, void* ws, size_t ws_bytes, void* stream) {
   if (B <= 0 || T <= 0 || hop <= 0 || window <= 0 || (long long)(T - 1) * hop + window > S)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd_windows: windows do not fit the track (S=%d T=%d hop=%d window=%d)", S, T,
              hop, window);
@@ -237,7 +249,7 @@ int m2d_conv1d_fwd_windows(const float* track, int B, int S, int T, int hop, int
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd_windows: tensor exceeds 2^31 elements");
   const M2dWinView wv = {T, S, hop};
   return conv1d_fwd_impl(track, w, nullptr, bias, y, B * T, 1, window, Cout, ks, stride, pad, act, slope, nullptr,
-                         nullptr, 0.f, ws, ws_bytes, stream, &wv);
+                         nullptr, 0.f, ws, ws_bytes, stream, &wv, stats);
 }
 
 // Replaces the input-gradient half of convolution_backward (autograd of nn.Conv1d), the
@@ -475,13 +487,19 @@ int m2d_conv1d_bwd_weight_windows(const float* track, int B, int S, int T, int h
 size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, int ks, int stride, int pad) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (Lout <= 0) return 0;
-  if (m2d_thin_applicable(Cin, Cout, ks, stride)) return which == 2 ? m2d_thin_bwd_weight_ws(B, Cout, ks, Lout) : 0;
+  if (m2d_thin_applicable(Cin, Cout, ks, stride))
+    return which == 2 ? m2d_thin_bwd_weight_ws(B, Cout, ks, Lout) : (which == 0 ? m2d_thin_fwd_stats_ws(B, Lout) : 0);
   if (which == 0) {
-    if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(Cout, B, m2d_chunks(1, Cin * ks), 1, true).ws_bytes;
+    // split-K slabs or (never both) the per-tile partials of the epilogue statistics
+    if (Lout == 1 && pad == 0 && L == ks) {
+      const size_t a = m2d_gemm_plan(Cout, B, m2d_chunks(1, Cin * ks), 1, true).ws_bytes, st = m2d_rowstats_bytes(Cout, B);
+      return a > st ? a : st;
+    }
     const bool packed = conv_uses_packed(Cin);
     const int nch = packed ? m2d_chunks(ks, Cin) : m2d_chunks(Cin, ks);
-    return m2d_gemm_plan(Cout, B * Lout, nch, 1, true, packed ? fwd_tile_penalty(stride) : 1.f).ws_bytes +
-           (packed ? pack_bytes(Cout, Cin, ks) : 0);
+    const size_t a = m2d_gemm_plan(Cout, B * Lout, nch, 1, true, packed ? fwd_tile_penalty(stride) : 1.f).ws_bytes;
+    const size_t st = m2d_rowstats_bytes(Cout, B * Lout);
+    return (a > st ? a : st) + (packed ? pack_bytes(Cout, Cin, ks) : 0);
   }
   if (which == 1) {
     if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(B, Cin * ks, m2d_chunks(1, Cout), 1, true).ws_bytes;

@@ -22,6 +22,7 @@ struct ThinArgs {
   const float* mask;   // optional
   float* out;          // fwd: y; bwd_data: dx; bwd_weight: partial slabs
   float* out2;         // bwd_weight: bias-gradient partial slabs (optional)
+  float* stats;        // fwd (optional): per-wave partial (sum, sum of squares) per channel: [(block * 4 + wave)][32][2]
   int xT, xS, xhop;    // window view of a padded track: sample n starts at (n / xT) * xS + (n % xT) * xhop (xT = 0: dense)
   int B, L, Cout, ks, stride, pad, Lout;
   int act;
@@ -298,12 +299,30 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
       *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
         if (p0 + 4 * cq + j < a.Lout) {
           float y = v[j];
           if (a.mask) y *= a.mask[o + j] > 0.f ? 1.f : a.mask_slope;
           a.out[o + j] = y;
+          v[j] = y;
+        } else {
+          v[j] = 0.f;
         }
+      }
+    }
+    if (a.stats) {  // wave-uniform: the LPR lanes of a channel row sum their stored values
+      float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+      float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+      for (int off = LPR / 2; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
+      if (cq == 0) {
+        float* dst = a.stats + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 64 + 2 * co;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
     }
   }
 }
@@ -312,12 +331,23 @@ struct M2dWinView {
   int T, S, hop;
 };
 
+int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, hipStream_t stream);  // gemm_engine.hip
+
+size_t m2d_thin_fwd_stats_ws(int B, int Lout) { return (size_t)B * m2d_ceil_div(Lout, 256) * 4 * 64 * sizeof(float); }
+
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
                  int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
-                 const M2dWinView* wv, hipStream_t stream) {
+                 const M2dWinView* wv, double* stats, void* ws, size_t ws_bytes, hipStream_t stream) {
   ThinArgs a;
   memset(&a, 0, sizeof(a));
   if (wv) { a.xT = wv->T; a.xS = wv->S; a.xhop = wv->hop; }
+  if (stats) {
+    if (!ws || ws_bytes < m2d_thin_fwd_stats_ws(B, Lout)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd (thin): no room for the statistics partials");
+    // waves that return early (past the end of the row) leave their slots untouched: zero them
+    if (hipMemsetAsync(ws, 0, m2d_thin_fwd_stats_ws(B, Lout), stream) != hipSuccess)
+      M2D_FAIL(M2D_ERR_HIP, "m2d_conv1d_fwd (thin): memset failed");
+    a.stats = (float*)ws;
+  }
   a.x = x; a.w = w; a.bias = bias; a.mask = out_mask; a.out = y;
   a.B = B; a.L = L; a.Cout = Cout; a.ks = ks; a.stride = stride; a.pad = pad; a.Lout = Lout;
   a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
@@ -325,6 +355,7 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
                     4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
   hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2>), dim3(m2d_ceil_div(Lout, 256), B), dim3(256), 0, stream, a);
   M2D_CHECK_LAUNCH("thin_fwd_mfma_kernel");
+  if (stats) return m2d_rowsums_reduce(a.stats, B * m2d_ceil_div(Lout, 256) * 4, 32, stats, stream);
   return M2D_OK;
 }
 

@@ -84,7 +84,19 @@ struct M2dOutMap {
   // column (redirect_col_p1 - 1) is written raw to col_out[row] instead of through the map (0 = none)
   float* col_out;
   int redirect_col_p1;
+  // optional per-row statistics of the stored values. Every wave writes, for each row of its
+  // sub-tile, (sum, sum of squares) over its columns to row_part[((n_tile * WN + wn) * M + row) * 2]
+  // (WN = wave columns of the tile: 2 for BM >= 64, 4 for BM = 32; plain stores - atomics onto a few
+  // hundred addresses from thousands of tiles serialise: measured 5 ms per step), and
+  // m2d_rowsums_reduce sums the partials per row in a fixed order into fp64 (sum, sum of squares):
+  // a conv that feeds a BatchNorm hands it the batch statistics instead of a second pass over the
+  // activation. Not available under split-K (the launcher then refuses to split).
+  float* row_part;
+  double* row_sums;  // [2 * M]: written by the launcher's reduction over row_part
 };
+// sums[2*row], sums[2*row + 1] (fp64) = fixed-order sums over the P partials part[p][row][0..1]
+int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, hipStream_t stream);
+static inline size_t m2d_rowstats_bytes(int M, int N) { return (size_t)((N + 127) / 128) * 4 * (size_t)M * 2 * sizeof(float); }
 
 struct M2dGemmParams {
   M2dOperand A, B;

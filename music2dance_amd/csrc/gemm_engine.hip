@@ -364,29 +364,55 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31,
   //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  int caddr[TN], colj[TN];
+  bool cvj[TN], cokj[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * (TN * 32) + j * 32 + l31;
     const bool cv = col < N;
     int chi, clo;
     m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
-    const int caddr = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
+    caddr[j] = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
     bool cok = cv;
     if (O.c_lim > 0) cok = cok && ((unsigned)(clo * O.c_pos_mul + O.c_pos_off) < (unsigned)O.c_lim);
+    colj[j] = col;
+    cvj[j] = cv;
+    cokj[j] = cok;
+  }
+  const bool stats = O.row_part != nullptr && p.splits <= 1;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M) {
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const bool rok = row < p.M;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (rok) {
           if (p.splits > 1) {
-            if (cv) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + col] = acc[i][j][r];
-          } else if (col + 1 == O.redirect_col_p1) {
+            if (cvj[j]) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + colj[j]] = acc[i][j][r];
+          } else if (colj[j] + 1 == O.redirect_col_p1) {
             O.col_out[row] = acc[i][j][r];
-          } else if (cok) {
-            const int addr = row * O.m_stride + caddr;
-            O.out[addr] = m2d_epilogue(O, acc[i][j][r], row, col, addr);
+          } else if (cokj[j]) {
+            const int addr = row * O.m_stride + caddr[j];
+            const float v = m2d_epilogue(O, acc[i][j][r], row, colj[j], addr);
+            O.out[addr] = v;
+            s1 += v;
+            s2 += v * v;
           }
+        }
+      }
+      if (stats) {  // wave-uniform: sum over the 32 lanes (columns) that share this row, one atomic pair per row
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        if (l31 == 0 && rok) {
+          float* dst = O.row_part + ((size_t)(blockIdx.x * WN + wn) * p.M + row) * 2;
+          dst[0] = s1;
+          dst[1] = s2;
         }
       }
     }
@@ -425,6 +451,41 @@ __global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmPar
       p.O.out[addr] = m2d_epilogue(p.O, s, row, col, addr);
     }
   }
+}
+
+// sums[2*row .. +1] = sum over p < P of part[(p * M + row) * 2 .. +1], fp64, fixed order: thread t adds
+// partials t, t + 256, ... and the block combines the 256 chains pairwise.
+__global__ void __launch_bounds__(256) m2d_rowsums_reduce_kernel(const float* __restrict__ part, int P, int M,
+                                                                 double* __restrict__ sums) {
+  __shared__ double sh[2][256];
+  const int row = blockIdx.x, t = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int q = t; q < P; q += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)q * M + row) * 2);
+    a += (double)v.x;
+    b += (double)v.y;
+  }
+  sh[0][t] = a;
+  sh[1][t] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      sh[0][t] += sh[0][t + s];
+      sh[1][t] += sh[1][t + s];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    sums[2 * row] = sh[0][0];
+    sums[2 * row + 1] = sh[1][0];
+  }
+}
+
+int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, hipStream_t stream) {
+  if (P <= 0 || M <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_rowsums_reduce: bad arguments");
+  hipLaunchKernelGGL(m2d_rowsums_reduce_kernel, dim3(M), dim3(256), 0, stream, part, P, M, sums);
+  M2D_CHECK_LAUNCH("m2d_rowsums_reduce_kernel");
+  return M2D_OK;
 }
 
 // Launch plans. A plan is (tile height BM, split-K factor). Candidates are ranked by a small cost
@@ -604,6 +665,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
   // bwd_data: the widest phase has ceil(ks / phases) taps
   const int nhi_max = p.bwd_data ? (p.ph_ks + p.phases - 1) / p.phases : p.nhi;
   const int nchunks = m2d_chunks(nhi_max, p.kdiv);
+  if (p.O.row_part) allow_split = false;  // the statistics come out of the tile epilogue
   PlanCand cand[M2D_MAX_CAND];
   int nc = plan_candidates(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, allow_split, p.small_tile_penalty, cand);
   {
@@ -695,6 +757,12 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
     if (plan_run(p, bm, splits, a_kfast, b_kfast, ws, stream))
       M2D_FAIL(M2D_ERR_ARG, "%s: unsupported operand map combination", what);
     M2D_CHECK_LAUNCH(what);
+    if (p.O.row_part) {
+      if (!p.O.row_sums) M2D_FAIL(M2D_ERR_ARG, "%s: row statistics without a destination", what);
+      const int wn = bm >= 64 ? 2 : 4;
+      const int rc = m2d_rowsums_reduce(p.O.row_part, m2d_ceil_div(p.N, 128) * wn, p.M, p.O.row_sums, stream);
+      if (rc) return rc;
+    }
   }
   return M2D_OK;
 }

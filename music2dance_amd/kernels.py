@@ -159,7 +159,9 @@ class HipKernels:
         return Cin == 1 and ks == 25 and stride == 4
 
     def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
-                   out_mask_slope=0.0):
+                   out_mask_slope=0.0, with_stats=False):
+        """-> y, or (y, sums) with `with_stats`: sums (2*Cout,) float64 = per-channel sum / sum of squares of y
+        from the conv's own epilogue (what a following BatchNorm needs: bn_fwd_sums)."""
         dev = _chk(x, w, bias, residual, out_mask)
         B, Cin, L = x.shape
         Cout, Cin2, ks = w.shape
@@ -170,12 +172,13 @@ class HipKernels:
         full_length = Lout == 1 and pad == 0 and L == ks
         wp = self.packed_weights(w)[0] if (Cin >= 16 and not full_length) else None
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 0, B, Cin, L, Cout, ks, stride, pad), dev)
+        sums = torch.empty((2 * Cout,), dtype=torch.float64, device=dev) if with_stats else None
         with _on(dev):
             rc = h.m2d_conv1d_fwd(_ptr(x), _ptr(w), _ptr(wp), _ptr(bias), _ptr(y), B, Cin, L, Cout, ks, stride, pad,
-                                  act, slope, _ptr(residual), _ptr(out_mask), out_mask_slope, _ptr(ws),
+                                  act, slope, _ptr(residual), _ptr(out_mask), out_mask_slope, _ptr(sums), _ptr(ws),
                                   0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_conv1d_fwd")
-        return y
+        return (y, sums) if with_stats else y
 
     def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0, out_mask=None,
                         out_mask_slope=0.0):
@@ -215,7 +218,7 @@ class HipKernels:
         return (dw, db) if with_bias else dw
 
     # ---------------------------------------------------------------- conv over the windows of a padded track
-    def conv1d_fwd_windows(self, track, T, hop, window, w, bias, stride, pad, act=0, slope=0.0):
+    def conv1d_fwd_windows(self, track, T, hop, window, w, bias, stride, pad, act=0, slope=0.0, with_stats=False):
         """track (B, S); logical input (B*T, 1, window), window t of track b = track[b, t*hop : t*hop + window]
         (never materialised). -> y (B*T, Cout, Lout)."""
         dev = _chk(w, bias)
@@ -226,12 +229,13 @@ class HipKernels:
         y = torch.empty((B * T, Cout, Lout), dtype=torch.float32, device=dev)
         h = _lib.lib()
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 0, B * T, 1, window, Cout, ks, stride, pad), dev)
+        sums = torch.empty((2 * Cout,), dtype=torch.float64, device=dev) if with_stats else None
         with _on(dev):
             rc = h.m2d_conv1d_fwd_windows(_ptr(track), B, S, T, hop, window, _ptr(w), _ptr(bias), _ptr(y), Cout, ks,
-                                          stride, pad, act, slope, _ptr(ws), 0 if ws is None else ws.numel() * 4,
-                                          _stream(dev))
+                                          stride, pad, act, slope, _ptr(sums), _ptr(ws),
+                                          0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_conv1d_fwd_windows")
-        return y
+        return (y, sums) if with_stats else y
 
     def conv1d_bwd_weight_windows(self, track, T, hop, window, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0,
                                   with_bias=False):
@@ -306,6 +310,70 @@ class HipKernels:
                               act, slope, _ptr(residual), _ptr(ws), ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_bn_fwd")
         return y, save_mean, save_invstd
+
+    @staticmethod
+    def _sums_ok(sums, C, dev):
+        if sums.dtype != torch.float64 or sums.numel() != 2 * C or not sums.is_contiguous() or sums.device != dev:
+            raise _lib.M2dError("BatchNorm sums must be a contiguous float64 tensor of 2*C elements on the device")
+
+    def bn_stats(self, x):
+        """(2C,) float64: per-channel sum and sum of squares of x (B, C[, L]) over batch and length."""
+        dev = _chk(x)
+        B, C = x.shape[0], x.shape[1]
+        L = x.shape[2] if x.dim() == 3 else 1
+        sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        with _on(dev):
+            rc = _lib.lib().m2d_bn_stats(_ptr(x), _ptr(sums), B, C, L, _stream(dev))
+        _lib.check(rc, "m2d_bn_stats")
+        return sums
+
+    def bn_fwd_sums(self, x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act=0, slope=0.0,
+                    residual=None):
+        """Training forward from batch sums over `count` elements per channel (bn_stats, a conv's epilogue, or
+        their all-reduce across data-parallel ranks). -> y, save_mean, save_invstd."""
+        dev = _chk(x, gamma, beta, running_mean, running_var, residual)
+        B, C = x.shape[0], x.shape[1]
+        L = x.shape[2] if x.dim() == 3 else 1
+        self._sums_ok(sums, C, dev)
+        y = torch.empty_like(x)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        with _on(dev):
+            rc = _lib.lib().m2d_bn_fwd_sums(_ptr(x), _ptr(sums), float(count), _ptr(gamma), _ptr(beta),
+                                            _ptr(running_mean), _ptr(running_var), _ptr(y), _ptr(save_mean),
+                                            _ptr(save_invstd), B, C, L, eps, momentum, act, slope, _ptr(residual),
+                                            _stream(dev))
+        _lib.check(rc, "m2d_bn_fwd_sums")
+        return y, save_mean, save_invstd
+
+    def bn_bwd_stats(self, dy, x, gamma, beta, save_mean, save_invstd, act=0, slope=0.0):
+        """(2C,) float64: sum dz and sum dz * xhat, dz = dy * act'(bn(x))."""
+        dev = _chk(dy, x, gamma, beta, save_mean, save_invstd)
+        B, C = x.shape[0], x.shape[1]
+        L = x.shape[2] if x.dim() == 3 else 1
+        sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        with _on(dev):
+            rc = _lib.lib().m2d_bn_bwd_stats(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(save_mean),
+                                             _ptr(save_invstd), _ptr(sums), B, C, L, act, slope, _stream(dev))
+        _lib.check(rc, "m2d_bn_bwd_stats")
+        return sums
+
+    def bn_bwd_sums(self, dy, x, gamma, beta, save_mean, save_invstd, sums_local, sums_global, count, act=0, slope=0.0):
+        dev = _chk(dy, x, gamma, beta, save_mean, save_invstd)
+        B, C = x.shape[0], x.shape[1]
+        L = x.shape[2] if x.dim() == 3 else 1
+        self._sums_ok(sums_local, C, dev), self._sums_ok(sums_global, C, dev)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        ws = _ws(_ws_bytes('m2d_bn_workspace_bytes', C), dev)
+        with _on(dev):
+            rc = _lib.lib().m2d_bn_bwd_sums(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(save_mean),
+                                            _ptr(save_invstd), _ptr(sums_local), _ptr(sums_global), float(count),
+                                            _ptr(dx), _ptr(dgamma), _ptr(dbeta), B, C, L, act, slope, _ptr(ws),
+                                            ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_bn_bwd_sums")
+        return dx, dgamma, dbeta
 
     def bn_bwd(self, dy, x, gamma, beta, save_mean, save_invstd, act=0, slope=0.0):
         dev = _chk(dy, x, gamma, beta, save_mean, save_invstd)

@@ -40,21 +40,22 @@ def to_device_async(t, device):
 class Conv1d(nn.Conv1d):
     """nn.Conv1d (dilation 1, groups 1, zero padding) on the implicit-GEMM engine."""
 
-    def forward(self, x, act=ops.ACT_NONE, slope=0.0, in_act=None, out_pm=False):
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0, in_act=None, out_pm=False, with_stats=False):
         """in_act / out_pm: the pre-masked gradient contract of ops.conv1d - only for a conv whose
         input comes straight from a fused conv + activation that has no other consumer (in_act, with
         out_pm on that producer)."""
         if self.dilation[0] != 1 or self.groups != 1 or self.padding_mode != "zeros":
             raise NotImplementedError("m2d Conv1d: dilation / groups / non-zero padding are not on the hot path")
-        return ops.conv1d(x, self.weight, self.bias, self.stride[0], self.padding[0], act, slope, in_act, out_pm)
+        return ops.conv1d(x, self.weight, self.bias, self.stride[0], self.padding[0], act, slope, in_act, out_pm,
+                          with_stats)
 
 
-    def forward_windows(self, track, T, hop, window, act=ops.ACT_NONE, slope=0.0):
+    def forward_windows(self, track, T, hop, window, act=ops.ACT_NONE, slope=0.0, with_stats=False):
         """This (single input channel) conv over the windows of a padded track (B, S), read in place."""
         if self.in_channels != 1 or self.dilation[0] != 1 or self.groups != 1 or self.padding_mode != "zeros":
             raise NotImplementedError("m2d Conv1d.forward_windows: single-channel, undilated convs only")
         return ops.conv1d_windows(track, T, hop, window, self.weight, self.bias, self.stride[0], self.padding[0],
-                                  act, slope)
+                                  act, slope, with_stats)
 
 
 class Linear(nn.Linear):
@@ -66,13 +67,14 @@ class BatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d on (N, C) / (N, C, L) with the following ReLU / LeakyReLU and an
     optional residual add fused into the normalisation pass."""
 
-    def forward(self, x, act=ops.ACT_NONE, slope=0.0, residual=None):
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0, residual=None, sums=None):
+        """sums: batch statistics of x from the producing conv's epilogue (Conv1d(..., with_stats=True))."""
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError("m2d BatchNorm1d: only the reference's configuration is supported")
         if self.training:
             self.num_batches_tracked.add_(1)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                              self.eps, self.momentum, act, slope, residual)
+                              self.eps, self.momentum, act, slope, residual, sums if self.training else None)
 
     @torch.no_grad()
     def observe(self, x):

@@ -101,18 +101,23 @@ def _slope_of(act, slope):
 
 class _Conv1dAct(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, slope, in_act, out_pm):
+    def forward(ctx, x, w, b, stride, pad, act, slope, in_act, out_pm, with_stats):
         ctx.set_materialize_grads(False)
         x, w, b = _c(x), _c(w), _c(b)
-        y = K().conv1d_fwd(x, w, b, stride, pad, act, slope)
+        sums = None
+        if with_stats:
+            y, sums = K().conv1d_fwd(x, w, b, stride, pad, act, slope, with_stats=True)
+            ctx.mark_non_differentiable(sums)
+        else:
+            y = K().conv1d_fwd(x, w, b, stride, pad, act, slope)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.cfg = (stride, pad, act, slope, b is not None, x.data_ptr(), in_act, bool(out_pm) and act != ACT_NONE)
-        return y
+        return y, sums
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _g_sums=None):
         if gy is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
-            return (None,) * 9
+            return (None,) * 10
         x, w, y = ctx.saved_tensors
         stride, pad, act, slope, has_bias, xkey, in_act, out_pm = ctx.cfg
         ymask, yslope = _mask_of(act, slope, y)
@@ -132,7 +137,7 @@ class _Conv1dAct(Function):
                     gb = _ChannelSum.apply(gy, hmask, ymask, yslope)
             elif want_b:
                 gb = _ChannelSum.apply(gy, hmask, ymask, yslope)
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 class _Conv1dBwdData(Function):
@@ -228,17 +233,21 @@ class _ChannelSum(Function):
         return out.contiguous(), None, None, None
 
 
-def conv1d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, in_act=None, out_pm=False):
+def conv1d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, in_act=None, out_pm=False,
+           with_stats=False):
     """nn.Conv1d forward with optional fused ReLU / LeakyReLU, twice differentiable.
-    in_act / out_pm: the pre-masked gradient contract described above (module-level promise)."""
+    in_act / out_pm: the pre-masked gradient contract described above (module-level promise).
+    with_stats: return (y, sums) - the per-channel sum / sum of squares of y (float64, 2*Cout) taken in the
+    conv's epilogue, for a BatchNorm that follows (batch_norm(..., sums=sums))."""
     if not _PREMASK:
         in_act, out_pm = None, False
     if in_act is not None:
         in_act = (int(in_act[0]), float(in_act[1]))
         if in_act[0] == ACT_NONE:
             in_act = None
-    return _Conv1dAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope), in_act,
-                            bool(out_pm))
+    y, sums = _Conv1dAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope), in_act,
+                               bool(out_pm), bool(with_stats))
+    return (y, sums) if with_stats else y
 
 
 class _Conv1dWindows(Function):
@@ -246,19 +255,24 @@ class _Conv1dWindows(Function):
     (kernels.conv1d_fwd_windows). First-order only (generator path); the track gets no gradient."""
 
     @staticmethod
-    def forward(ctx, track, w, b, T, hop, window, stride, pad, act, slope):
+    def forward(ctx, track, w, b, T, hop, window, stride, pad, act, slope, with_stats):
         ctx.set_materialize_grads(False)
-        track, w, b = _c(track), _c(w), _c(b)
-        y = K().conv1d_fwd_windows(track, T, hop, window, w, b, stride, pad, act, slope)
+        w, b = _c(w), _c(b)
+        sums = None
+        if with_stats:
+            y, sums = K().conv1d_fwd_windows(track, T, hop, window, w, b, stride, pad, act, slope, with_stats=True)
+            ctx.mark_non_differentiable(sums)
+        else:
+            y = K().conv1d_fwd_windows(track, T, hop, window, w, b, stride, pad, act, slope)
         ctx.save_for_backward(track, w, y if act else None)
         ctx.cfg = (T, hop, window, stride, pad, act, slope, b is not None)
-        return y
+        return y, sums
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, _g_sums=None):
         if gy is None:
-            return (None,) * 10
+            return (None,) * 11
         track, w, y = ctx.saved_tensors
         T, hop, window, stride, pad, act, slope, has_bias = ctx.cfg
         mask, mslope = _mask_of(act, slope, y)
@@ -269,15 +283,17 @@ class _Conv1dWindows(Function):
             out = K().conv1d_bwd_weight_windows(track, T, hop, window, gy, w.shape[2], stride, pad, mask, mslope,
                                                 with_bias=want_b)
             gw, gb = out if want_b else (out, None)
-        return (None, gw, gb) + (None,) * 7
+        return (None, gw, gb) + (None,) * 8
 
 
-def conv1d_windows(track, T, hop, window, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0):
+def conv1d_windows(track, T, hop, window, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0,
+                   with_stats=False):
     """conv1d over the (B*T, 1, window) windows of `track` (B, S) without materialising them."""
     if track.requires_grad:
         raise NotImplementedError("conv1d_windows: no gradient w.r.t. the audio track (materialise the slices)")
-    return _Conv1dWindows.apply(track, weight, bias, int(T), int(hop), int(window), int(stride), int(padding),
-                                int(act), float(slope))
+    y, sums = _Conv1dWindows.apply(track, weight, bias, int(T), int(hop), int(window), int(stride), int(padding),
+                                   int(act), float(slope), bool(with_stats))
+    return (y, sums) if with_stats else y
 
 
 # --------------------------------------------------------------------------------------- linear
@@ -371,36 +387,83 @@ def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
 
 
 # --------------------------------------------------------------------------------------- batch norm
+# Synchronised BatchNorm (optional): with a process group set here the batch
+# statistics (and the two backward sums) are all-reduced across the data-parallel ranks, so the
+# generator normalises over the GLOBAL batch exactly like a single process would. Off = per-rank
+# statistics (the torch-DDP default). The exchange is 2*C doubles per BatchNorm layer and pass.
+_sync_bn = {"group": None, "on": False}
+
+
+def set_sync_batchnorm(on=True, group=None):
+    import torch.distributed as dist
+    _sync_bn["on"] = bool(on) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    _sync_bn["group"] = group
+    return _sync_bn["on"]
+
+
+def _sync_world():
+    if not _sync_bn["on"]:
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size(_sync_bn["group"])
+
+
+def _all_reduce_sums(sums):
+    import torch.distributed as dist
+    out = sums.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=_sync_bn["group"])
+    return out
+
+
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, eps, momentum, act, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, eps, momentum, act, slope, sums):
         ctx.set_materialize_grads(False)
         x, residual = _c(x), _c(residual)
-        y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, training, eps, momentum, act,
-                                     slope, residual)
+        world = 1
+        if training:
+            # batch statistics as raw sums: from the producing conv's epilogue when it supplied them
+            if sums is None:
+                sums = K().bn_stats(x)
+            world = _sync_world()
+            if world > 1:
+                sums = _all_reduce_sums(sums)
+            count = float(world) * (x.numel() // x.shape[1])
+            y, mean, invstd = K().bn_fwd_sums(x, sums, count, gamma, beta, running_mean, running_var, eps, momentum,
+                                              act, slope, residual)
+        else:
+            y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, False, eps, momentum, act,
+                                         slope, residual)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
-        ctx.cfg = (training, act, slope, residual is not None)
+        ctx.cfg = (training, act, slope, residual is not None, world)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         if gy is None:  # no gradient reaches this node (e.g. the penalty pass's forward graph)
-            return (None,) * 11
+            return (None,) * 12
         x, gamma, beta, mean, invstd = ctx.saved_tensors
-        training, act, slope, has_res = ctx.cfg
+        training, act, slope, has_res, world = ctx.cfg
         if not training:
             raise NotImplementedError("m2d BatchNorm: backward in eval mode is not part of the training path")
         gy = _c(gy)
-        dx, dgamma, dbeta = K().bn_bwd(gy, x, gamma, beta, mean, invstd, act, slope)
-        return dx, dgamma, dbeta, None, None, (gy if has_res else None), None, None, None, None, None
+        if world > 1:
+            local = K().bn_bwd_stats(gy, x, gamma, beta, mean, invstd, act, slope)
+            glob = _all_reduce_sums(local)
+            dx, dgamma, dbeta = K().bn_bwd_sums(gy, x, gamma, beta, mean, invstd, local, glob,
+                                                float(world) * (x.numel() // x.shape[1]), act, slope)
+        else:
+            dx, dgamma, dbeta = K().bn_bwd(gy, x, gamma, beta, mean, invstd, act, slope)
+        return dx, dgamma, dbeta, None, None, (gy if has_res else None), None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=ACT_NONE,
-               slope=0.0, residual=None):
-    """y = residual + act(batch_norm(x)); running buffers are updated in place when training."""
+               slope=0.0, residual=None, sums=None):
+    """y = residual + act(batch_norm(x)); running buffers are updated in place when training.
+    sums: the batch statistics of x as raw sums (conv1d(..., with_stats=True)), else computed here."""
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps),
-                               float(momentum), int(act), float(slope))
+                               float(momentum), int(act), float(slope), sums)
 
 
 # --------------------------------------------------------------------------------------- GRU

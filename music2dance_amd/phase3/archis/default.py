@@ -29,14 +29,21 @@ def _descending(lengths):
     return ls
 
 
+_FUSED_BN_STATS = os.environ.get("M2D_FUSED_BN_STATS", "1") != "0"  # dev switch for A/B timing
 RELU_IN = (ops.ACT_RELU, 0.0)  # "my input is the sole-consumer output of a fused conv + ReLU" (ops.conv1d)
 
 
-def _first_conv(conv, x):
-    """first encoder conv on dense (N, 1, window) windows or, in place, on a WindowView of the padded track"""
+def _conv_bn(conv, bn, x, act, slope=0.0):
+    """bn(conv(x)) + activation. In training mode the conv's epilogue hands the BatchNorm its batch
+    statistics (no second pass over the activation); x may be a WindowView of the padded track
+    (first encoder conv: the audio windows are read in place)."""
+    stats = bn.training and _FUSED_BN_STATS
     if isinstance(x, WindowView):
-        return conv.forward_windows(x.track, x.T, x.hop, x.window)
-    return conv(x)
+        out = conv.forward_windows(x.track, x.T, x.hop, x.window, with_stats=stats)
+    else:
+        out = conv(x, with_stats=stats)
+    y, sums = out if stats else (out, None)
+    return bn(y, act=act, slope=slope, sums=sums)
 
 
 def _head(module, conv, x, in_act=None):
@@ -129,8 +136,8 @@ class DefaultAudioEncoder(nn.Module):
         self.activations.append(mod)
 
     def forward(self, x):
-        for i, (conv, post) in enumerate(zip(self.conv_layers[:-1], self.activations[:-1])):
-            x = post[0](_first_conv(conv, x) if i == 0 else conv(x), act=ops.ACT_RELU)
+        for conv, post in zip(self.conv_layers[:-1], self.activations[:-1]):
+            x = _conv_bn(conv, post[0], x, ops.ACT_RELU)
         return _head(self, self.conv_layers[-1], x).squeeze()
 
 
@@ -142,7 +149,7 @@ class BasisConvBlock(nn.Module):
         self.relu = nn.LeakyReLU(0.2)
 
     def forward(self, x):
-        return self.bn(self.conv(x), act=ops.ACT_LEAKY, slope=0.2)
+        return _conv_bn(self.conv, self.bn, x, ops.ACT_LEAKY, 0.2)
 
 
 class UBlock(nn.Module):
@@ -186,8 +193,8 @@ class UNetAudioEncoder(nn.Module):
         self.activ, self._head_act, self._head_tanh = head_activation(activ)
 
     def forward(self, x):
-        for i, (conv, post) in enumerate(zip(self.conv_layers, self.activations)):
-            x = post[0](_first_conv(conv, x) if i == 0 else conv(x), act=ops.ACT_LEAKY, slope=0.2)
+        for conv, post in zip(self.conv_layers, self.activations):
+            x = _conv_bn(conv, post[0], x, ops.ACT_LEAKY, 0.2)
         return _head(self, self.fc, self.ublock(x)).squeeze()
 
 
@@ -211,7 +218,7 @@ class WaveGANAudioEncoder(nn.Module):
 
     def forward(self, x):
         for conv, bn in ((self.l1, self.bn1), (self.l2, self.bn2), (self.l3, self.bn3), (self.l4, self.bn4)):
-            x = bn(_first_conv(conv, x) if conv is self.l1 else conv(x), act=ops.ACT_RELU)
+            x = _conv_bn(conv, bn, x, ops.ACT_RELU)
         return _head(self, self.l5, x).squeeze(-1)
 
 

@@ -36,13 +36,13 @@ class FakeKernels:
         pass
 
     def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
-                   out_mask_slope=0.0):
+                   out_mask_slope=0.0, with_stats=False):
         y = _act(F.conv1d(x, w, bias, stride=stride, padding=pad), act, slope)
         if residual is not None:
             y = y + residual
         if out_mask is not None:
             y = y * _mf(out_mask, out_mask_slope)
-        return y
+        return (y, self.bn_stats(y)) if with_stats else y
 
     def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0, out_mask=None,
                         out_mask_slope=0.0):
@@ -59,9 +59,9 @@ class FakeKernels:
         dw = torch.nn.grad.conv1d_weight(x, (dy.shape[1], x.shape[1], ks), dy, stride=stride, padding=pad)
         return (dw, dy.sum((0, 2))) if with_bias else dw
 
-    def conv1d_fwd_windows(self, track, T, hop, window, w, bias, stride, pad, act=0, slope=0.0):
+    def conv1d_fwd_windows(self, track, T, hop, window, w, bias, stride, pad, act=0, slope=0.0, with_stats=False):
         x = track.unfold(-1, window, hop)[:, :T].reshape(-1, 1, window)
-        return self.conv1d_fwd(x, w, bias, stride, pad, act, slope)
+        return self.conv1d_fwd(x, w, bias, stride, pad, act, slope, with_stats=with_stats)
 
     def conv1d_bwd_weight_windows(self, track, T, hop, window, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0,
                                   with_bias=False):
@@ -108,6 +108,54 @@ class FakeKernels:
         if residual is not None:
             y = y + residual
         return y, mean, invstd
+
+    @staticmethod
+    def _interleave(a, b):
+        return torch.stack((a.double(), b.double()), 1).reshape(-1)
+
+    def bn_stats(self, x):
+        dims = (0,) if x.dim() == 2 else (0, 2)
+        xd = x.double()
+        return self._interleave(xd.sum(dims), (xd * xd).sum(dims))
+
+    def bn_fwd_sums(self, x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act=0, slope=0.0,
+                    residual=None):
+        shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
+        mean64 = sums[0::2] / count
+        var64 = (sums[1::2] / count - mean64 * mean64).clamp_min(0.0)
+        mean, var = mean64.float(), var64.float()
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * mean)
+            running_var.mul_(1 - momentum).add_(momentum * var * (count / (count - 1) if count > 1 else 1.0))
+        invstd = (1.0 / torch.sqrt(var64 + eps)).float()
+        y = _act((x - mean.view(shape)) * invstd.view(shape) * gamma.view(shape) + beta.view(shape), act, slope)
+        if residual is not None:
+            y = y + residual
+        return y, mean, invstd
+
+    def _bn_dz(self, dy, x, gamma, beta, save_mean, save_invstd, act, slope):
+        shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
+        xh = (x - save_mean.view(shape)) * save_invstd.view(shape)
+        z = gamma.view(shape) * xh + beta.view(shape)
+        dz = dy
+        if act == 1:
+            dz = dy * (z > 0).to(dy.dtype)
+        elif act == 2:
+            dz = dy * _mf(z, slope)
+        return dz, xh
+
+    def bn_bwd_stats(self, dy, x, gamma, beta, save_mean, save_invstd, act=0, slope=0.0):
+        dims = (0,) if x.dim() == 2 else (0, 2)
+        dz, xh = self._bn_dz(dy, x, gamma, beta, save_mean, save_invstd, act, slope)
+        return self._interleave(dz.double().sum(dims), (dz.double() * xh.double()).sum(dims))
+
+    def bn_bwd_sums(self, dy, x, gamma, beta, save_mean, save_invstd, sums_local, sums_global, count, act=0, slope=0.0):
+        shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
+        dz, xh = self._bn_dz(dy, x, gamma, beta, save_mean, save_invstd, act, slope)
+        m1 = (sums_global[0::2] / count).float()
+        m2 = (sums_global[1::2] / count).float()
+        dx = gamma.view(shape) * save_invstd.view(shape) * (dz - m1.view(shape) - xh * m2.view(shape))
+        return dx, sums_local[1::2].float(), sums_local[0::2].float()
 
     def bn_bwd(self, dy, x, gamma, beta, save_mean, save_invstd, act=0, slope=0.0):
         dims = (0,) if x.dim() == 2 else (0, 2)

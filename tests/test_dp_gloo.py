@@ -220,3 +220,85 @@ def test_deferred_critic_step_is_taken_every_iteration():
             assert torch.allclose(a, b, rtol=0, atol=2e-4), (rank, float((a - b).abs().max()))
     for a, b in zip(res[0][2], res[1][2]):
         assert (a == b).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# Synchronised BatchNorm (ops.set_sync_batchnorm): with the batch statistics and the two backward
+# sums all-reduced, a generator sharded over two ranks produces the poses and (averaged) gradients of
+# the single-process global batch - the BatchNorm deviation of plain data parallelism disappears.
+def _p2_gen(seed=0):
+    from music2dance_amd.phase2.archis.default import SequenceGenerator
+    torch.manual_seed(seed)
+    return SequenceGenerator(8, 8, 16, 69, 2, 1, "cpu")
+
+
+def _gen_loss(gen, noise, target):
+    rows = gen(noise, [noise.shape[1]] * noise.shape[0])
+    return rows, ((rows - target) ** 2).mean()
+
+
+def _syncbn_worker(rank, world, port, q, noise, target, sync):
+    _setup(rank, world, port)
+    from music2dance_amd import ops
+    from music2dance_amd.dp import GradExchange
+    assert ops.set_sync_batchnorm(sync) == sync
+    gen = _p2_gen()
+    gen.train()
+    B = noise.shape[0]
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    T = noise.shape[1]
+    rows, loss = _gen_loss(gen, noise[lo:hi], target[lo * T:hi * T])
+    loss.backward()
+    ex = GradExchange(gen.parameters())
+    ex.exchange()
+    q.put((rank, rows.detach().numpy().copy(), {n: (None if p.grad is None else p.grad.numpy().copy())
+                                                for n, p in gen.named_parameters()},
+           {n: b.numpy().copy() for n, b in gen.named_buffers() if "running" in n}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sync", [True, False], ids=["sync-bn", "per-rank-bn"])
+def test_sync_batchnorm_reproduces_the_global_batch(sync):
+    from music2dance_amd import kernels
+    from tests.fake_backend import FakeKernels
+    B, T = 4, 12
+    g = torch.Generator().manual_seed(11)
+    noise = torch.randn(B, T, 8, generator=g)
+    noise[B // 2:] += 0.7  # the two shards have different statistics
+    target = torch.rand(B * T, 69, generator=g)
+    prev = kernels.set_impl(FakeKernels())
+    try:
+        gen = _p2_gen()
+        gen.train()
+        rows_full, loss = _gen_loss(gen, noise, target)
+        loss.backward()
+        full_grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in gen.named_parameters()}
+        full_bufs = {n: b.clone() for n, b in gen.named_buffers() if "running" in n}
+    finally:
+        kernels.set_impl(prev)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q, noise, target, sync)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    rows = torch.cat([torch.from_numpy(r[1]) for r in res], 0)
+    err_rows = float((rows - rows_full.detach()).abs().max())
+    worst = 0.0
+    gmax = max(float(g_.abs().max()) for g_ in full_grads.values() if g_ is not None)
+    for n, gfull in full_grads.items():
+        if gfull is None:
+            continue
+        # mean over ranks of (per-shard mean loss) gradients = global-batch gradient of the mean loss
+        # (relative to the largest gradient: biases in front of a BatchNorm have exactly-zero gradients)
+        got = torch.from_numpy(res[0][2][n])
+        worst = max(worst, float((got - gfull).abs().max()) / gmax)
+    if sync:
+        assert err_rows < 1e-5 and worst < 1e-4, (err_rows, worst)
+        for n, b in full_bufs.items():
+            assert torch.allclose(torch.from_numpy(res[0][3][n]), b, atol=1e-6), n
+    else:
+        # documents the deviation the default (per-rank statistics, torch-DDP semantics) has
+        assert err_rows > 1e-3

@@ -23,7 +23,7 @@ def K():
 
 def rel_err(got, ref64):
     got = got.detach().cpu().double()
-    ref64 = ref64.detach().double()
+    ref64 = ref64.detach().cpu().double()
     assert got.shape == ref64.shape, (got.shape, ref64.shape)
     denom = max(1.0, ref64.abs().max().item())
     return (got - ref64).abs().max().item() / denom
@@ -121,7 +121,7 @@ def test_conv1d_cabi_without_packed_weights():
     ws = torch.empty(nws // 4 + 1, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     rc = h.m2d_conv1d_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, Cin, L, Cout, ks, s, p, 0, 0.0,
-                          None, None, 0.0, ws.data_ptr(), nws, st)
+                          None, None, 0.0, None, ws.data_ptr(), nws, st)
     assert rc == 0, h.m2d_last_error()
     ref = F.conv1d(x.cpu().double(), w.cpu().double(), None, stride=s, padding=p)
     assert rel_err(y, ref) < 2e-5
@@ -137,7 +137,7 @@ def test_conv1d_cabi_without_packed_weights():
     assert rel_err(dx, gx) < 2e-5
     # too small a workspace is refused, not overrun
     rc = h.m2d_conv1d_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, Cin, L, Cout, ks, s, p, 0, 0.0,
-                          None, None, 0.0, ws.data_ptr(), 16, st)
+                          None, None, 0.0, None, ws.data_ptr(), 16, st)
     assert rc != 0
 
 
@@ -571,3 +571,42 @@ def test_conv1d_over_track_windows_equals_conv_on_materialised_slices(case):
     big = gen(B, S + 13, seed=5).to(DEV)
     y_big = k.conv1d_fwd_windows(big[:, :S], T, hop, window, w, b, s, p)
     assert torch.equal(y_big, k.conv1d_fwd(big[:, :S].unfold(-1, window, hop).contiguous().view(B * T, 1, window), w, b, s, p))
+
+
+# ----------------------------------------------------------------------------------- BN statistics from the conv epilogue
+@pytest.mark.parametrize("case", [("enc.c1", 96, 32, 64, 64, 4, 2, 1), ("enc.c0-k250", 40, 1, 3200, 32, 250, 50, 124),
+                                  ("wavegan.l1-thin", 12, 1, 3200, 32, 25, 4, 0), ("wavegan.l2", 6, 32, 794, 64, 25, 4, 0),
+                                  ("unet.cb", 5, 128, 200, 128, 3, 1, 1), ("odd", 7, 19, 37, 21, 5, 2, 2)],
+                         ids=lambda c: c[0])
+def test_conv1d_epilogue_statistics_and_bn_from_sums(case):
+    """conv1d_fwd(with_stats) returns the per-channel sum / sum of squares of what it stored; BatchNorm
+    from those sums equals BatchNorm that reads the activation itself; backward halves equal the fused call."""
+    _, B, Cin, L, Cout, ks, s, p = case
+    k = K()
+    x = gen(B, Cin, L, seed=1).to(DEV)
+    w = gen(Cout, Cin, ks, seed=2, scale=1.0 / math.sqrt(Cin * ks)).to(DEV)
+    b = gen(Cout, seed=3, scale=0.1).to(DEV)
+    y, sums = k.conv1d_fwd(x, w, b, s, p, with_stats=True)
+    y_plain = k.conv1d_fwd(x, w, b, s, p)
+    assert sums.dtype == torch.float64 and sums.shape == (2 * Cout,)
+    y64 = y.double()
+    assert rel_err(sums[0::2], y64.sum((0, 2))) < 1e-6 and rel_err(sums[1::2], (y64 * y64).sum((0, 2))) < 1e-6
+    assert rel_err(y, y_plain.double()) < 1e-6
+    assert rel_err(k.bn_stats(y), torch.stack((y64.sum((0, 2)), (y64 * y64).sum((0, 2))), 1).reshape(-1)) < 1e-6
+    g, bt = gen(Cout, seed=5).abs().add(0.5).to(DEV), gen(Cout, seed=6, scale=0.2).to(DEV)
+    rm1, rv1 = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    n = y.numel() // Cout
+    o1, m1, i1 = k.bn_fwd(y, g, bt, rm1, rv1, True, 1e-5, 0.1, act=2, slope=0.2)
+    o2, m2, i2 = k.bn_fwd_sums(y, sums, n, g, bt, rm2, rv2, 1e-5, 0.1, act=2, slope=0.2)
+    for a_, b_ in ((o1, o2), (m1, m2), (i1, i2), (rm1, rm2), (rv1, rv2)):
+        assert rel_err(a_, b_.double()) < 2e-6
+    dy = gen(*y.shape, seed=7).to(DEV)
+    dx1, dg1, db1 = k.bn_bwd(dy, y, g, bt, m1, i1, act=2, slope=0.2)
+    loc = k.bn_bwd_stats(dy, y, g, bt, m1, i1, act=2, slope=0.2)
+    dx2, dg2, db2 = k.bn_bwd_sums(dy, y, g, bt, m1, i1, loc, loc, n, act=2, slope=0.2)
+    for a_, b_ in ((dx1, dx2), (dg1, dg2), (db1, db2)):
+        assert rel_err(a_, b_.double()) < 2e-6
+    # "two ranks": statistics over twice the data = the sums doubled, count doubled -> same normalisation
+    o3, _, _ = k.bn_fwd_sums(y, 2 * sums, 2 * n, g, bt, None, None, 1e-5, 0.1, act=2, slope=0.2)
+    assert rel_err(o3, o1.double()) < 2e-6
