@@ -37,8 +37,11 @@ class WganGpEngine:
     """Common machinery: optimisers, n_critic gating, data-parallel gradient exchange with
     the critic's optimiser step deferred behind the next generator forward."""
 
-    def __init__(self, gen, critic, lr_gen, lr_critic, n_critic_steps, data_parallel=True, fused_adam=None):
+    def __init__(self, gen, critic, lr_gen, lr_critic, n_critic_steps, data_parallel=True, fused_adam=None,
+                 sync_bn=False):
         self.gen, self.critic = gen, critic
+        # sync_bn: BatchNorm statistics over the global batch (all-reduced sums) instead of per rank
+        self.sync_bn = bool(sync_bn) and ops.set_sync_batchnorm(True)
         self.n_critic_steps = int(n_critic_steps)
         dev = next(critic.parameters()).device
         kw = {}

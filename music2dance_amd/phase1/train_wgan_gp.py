@@ -26,6 +26,7 @@ def main(argv=None):
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--no-run-dir", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch")
     opts = ap.parse_args(argv)
 
     rank, world, local = dp.init_from_env()
@@ -37,7 +38,7 @@ def main(argv=None):
     np.random.seed(37)
     gen = Generator(cfg["latent_vector_size"], cfg["size"], cfg["output_size"], cfg["nblocks_gen"]).to(device)
     critic = Discriminator(cfg["output_size"], cfg["size"], cfg["nblocks_critic"]).to(device)
-    engine = Phase1Engine(gen, critic, cfg)
+    engine = Phase1Engine(gen, critic, cfg, sync_bn=opts.sync_bn)
     if world > 1:  # identical weights must come from a common seed; the reference (single process) sets none
         for m in (gen, critic):
             for t in list(m.parameters()) + list(m.buffers()):

@@ -26,6 +26,7 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--no-run-dir", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch")
     opts = ap.parse_args(argv)
     if opts.framework != "wgangp":
         raise ValueError("Please state existing framework")
@@ -44,7 +45,7 @@ def main(argv=None):
                             cfg["nblocks_gen"], cfg["n_cells"], device)
     critic = SequenceDiscriminator(cfg["output_size"], cfg["channels"], stick_length, cfg["init_kernel"],
                                    cfg["nblocks_critic"], device)
-    engine = Phase2Engine(gen, critic, cfg)
+    engine = Phase2Engine(gen, critic, cfg, sync_bn=opts.sync_bn)
     torch.manual_seed(rank)  # identical weights (seed 0 above), rank-distinct noise / alpha draws
     engine.host_noise = False  # phase2/train.py:139-140 draws the noise on the device
     log = runner.ScalarLog(logdir, opts.log_every)

@@ -40,6 +40,7 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=None, help="override batch_size (per GPU)")
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--no-run-dir", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch")
     ap.add_argument("--val-batches", type=int, default=1, help="held-out synthetic batches for l1_loss_val")
     opts = ap.parse_args(argv)
 
@@ -55,7 +56,7 @@ def main(argv=None):
     batch_size = opts.batch_size or cfg["batch_size"]
     logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
     gen, critic = build(cfg, device, stick_length)
-    engine = Phase3Engine(gen, critic, cfg, ablated=cfg["ablated"])
+    engine = Phase3Engine(gen, critic, cfg, ablated=cfg["ablated"], sync_bn=opts.sync_bn)
     # seed 0 built identical weights on every rank; the in-loop host draws (generator noise,
     # penalty alpha) must differ between ranks, as they do between samples of one global batch
     torch.manual_seed(rank)
