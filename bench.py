@@ -206,6 +206,8 @@ def main():
     if args.config:
         for k, v in PRESETS[args.config].items():
             setattr(args, k, v)
+    if args.same_device:
+        os.environ["M2D_PERSISTENT_GRU"] = "0"  # ranks sharing one GPU: persistent kernels could starve each other
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)  # before anything touches the GPU
 
@@ -269,6 +271,7 @@ def main():
         launches = K.prof_dump()
         prof = K.prof_end()
 
+    K.check_async_errors()
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

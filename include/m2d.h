@@ -139,9 +139,18 @@ int m2d_gru_layer_bwd(const float* dout, const float* out, const float* r_s, con
 /* Whole L-layer stack (L <= 4, equal hidden sizes) on the (layer, t) diagonal: T + L - 1 launches
  * instead of L * T. Pointer arrays have L entries; w_ih_t[0] / b_ih[0] / w_ih[0] are ignored (layer 0's
  * projection gi0 comes from m2d_gemm). saved[l]: (4, B, T, H) = r, z, n, W_hn h + b_hn (or saved == NULL). */
+/* `counters` (optional): m2d_gru_stack_counters(B, L) unsigneds of device scratch owned by this call. With it, and
+ * when every (layer, batch tile, hidden tile) workgroup fits on the chip at once, the whole recurrence runs as ONE
+ * persistent launch (weight slices resident in LDS, per-step hand-off between CUs through write-through stores
+ * and agent-scope counters); results are bit-identical to the per-step launches. Spins are bounded: a timeout
+ * raises a flag readable through m2d_gru_persist_error() after a stream synchronisation (outputs then invalid).
+ * M2D_PERSISTENT_GRU=0 disables the persistent form (needed when several processes share one GPU: their
+ * persistent kernels could starve each other of CUs). */
+int m2d_gru_stack_counters(int B, int L);
 int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float* const* b_ih,
                       const float* const* w_hh_t, const float* const* b_hh, float* const* out, float* const* saved,
-                      const int* lengths, int B, int T, int H, int L, void* stream);
+                      const int* lengths, int B, int T, int H, int L, unsigned* counters, void* stream);
+int m2d_gru_persist_error(void);
 int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* const* saved,
                       const float* const* w_hh, const float* const* w_ih, float* const* dgi, float* const* dgh,
                       float* const* dh_buf, const int* lengths, int B, int T, int H, int L, void* stream);

@@ -44,7 +44,9 @@ SIGNATURES = {
     "m2d_channel_sums": (_I, [_F, _F, _f, _F, _I, _I, _I, _F, _S, _F]),
     "m2d_gru_layer_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
     "m2d_gru_layer_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
-    "m2d_gru_stack_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F]),
+    "m2d_gru_stack_counters": (_I, [_I, _I]),
+    "m2d_gru_stack_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F, _F]),
+    "m2d_gru_persist_error": (_I, []),
     "m2d_gru_stack_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F]),
     "m2d_gp_interpolate": (_I, [_F, _F, _F, _F, _I, _I, _F]),
     "m2d_gp_penalty_workspace_bytes": (_S, [_I]),

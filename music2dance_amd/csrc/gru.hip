@@ -12,6 +12,7 @@
 // The step is latency-bound (<= 22 MFLOP), not roofline-bound; the grid is sized to put
 // every (row-group, unit-slice) on its own CU.
 #include "m2d_common.h"
+#include <mutex>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -326,14 +327,8 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_stack_fwd_kernel(cons
         bi[i][j] = (oki && cok) ? wi[wo + j * H] : 0.f;
       }
     }
-    if (use_h) {
-#pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][1], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][2], acc[2], 0, 0, 0);
-      }
-    }
+    // input part first, hidden part second: the persistent kernel (below) can then multiply the layer
+    // below's output while it still waits for its own layer's previous step; same order = same bits
     if (use_i) {
 #pragma unroll
       for (int i = 0; i < UN; ++i) {
@@ -342,18 +337,26 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_stack_fwd_kernel(cons
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][2], acc[3], 0, 0, 0);
       }
     }
-  } else {
     if (use_h) {
-      f32x4 h3[3] = {acc[0], acc[1], acc[2]};
-      const int cols[3] = {0, 1, 2};
-      gru_mac<3, NW>(a.out[l] + ((size_t)arow * T + (t - 1)) * H, rok, a.w_hh_t[l], H, 3 * H, bcol, cok, wave, lane, h3, cols);
-      acc[0] = h3[0]; acc[1] = h3[1]; acc[2] = h3[2];
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][1], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][2], acc[2], 0, 0, 0);
+      }
     }
+  } else {
     if (use_i) {
       f32x4 i3[3] = {acc[0], acc[1], acc[3]};
       const int cols[3] = {0, 1, 2};
       gru_mac<3, NW>(a.out[l - 1] + ((size_t)arow * T + t) * H, rok, a.w_ih_t[l], H, 3 * H, bcol, cok, wave, lane, i3, cols);
       acc[0] = i3[0]; acc[1] = i3[1]; acc[3] = i3[2];
+    }
+    if (use_h) {
+      f32x4 h3[3] = {acc[0], acc[1], acc[2]};
+      const int cols[3] = {0, 1, 2};
+      gru_mac<3, NW>(a.out[l] + ((size_t)arow * T + (t - 1)) * H, rok, a.w_hh_t[l], H, 3 * H, bcol, cok, wave, lane, h3, cols);
+      acc[0] = h3[0]; acc[1] = h3[1]; acc[2] = h3[2];
     }
   }
 #pragma unroll
@@ -397,6 +400,197 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_stack_fwd_kernel(cons
     sv[plane + bt * H + u] = z;
     sv[2 * plane + bt * H + u] = n;
     sv[3 * plane + bt * H + u] = hn;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// Persistent forward: ONE launch for the whole L-layer, T-step recurrence.
+// Workgroup (hidden tile, batch tile, layer) keeps its weight slices - W_hh^T[:, 16 units x 3 gates]
+// and, for layers >= 1, W_ih^T likewise: 2 x H x 48 floats = 92 KB at H = 240 - in LDS for all T
+// steps (the per-step launches re-read them from L2 every step), and loops over t:
+//   wait    own layer finished step t-1 and the layer below finished step t for this batch tile:
+//           one lane polls two agent-scope counters (relaxed `sc1` loads, s_sleep back-off, bounded);
+//   load    the 16 x H rows of h_l[t-1] and h_{l-1}[t] with `sc1` loads (they were written by other
+//           CUs in this launch: plain loads could hit stale L1 lines);
+//   compute the same MFMA / reduction order as m2d_gru_stack_fwd_kernel (bit-identical results);
+//   publish h_l[t] with `sc1` (write-through) stores, every storing wave drains (s_waitcnt
+//           vmcnt(0)), workgroup barrier, ONE lane adds 1 to the layer's counter.
+// This is row 1 of the guide's table of hand-offs that need no acquire fence (one signalling lane per
+// storing workgroup after drain + barrier; consumer: sc1 poll, barrier, sc1 loads; one workgroup per
+// CU - the LDS footprint enforces it). All workgroups must be resident at once (L x ceil(B/16) x
+// ceil(H/16) <= CUs, checked by the launcher); every spin is bounded: on a timeout the workgroup
+// raises `*error` (pinned host memory) and every workgroup leaves, so the kernel always terminates.
+#define GRU_CNT_STRIDE 64  // one counter per 256-byte line: pollers of different tiles do not share a memory channel line
+struct GruPersistArgs {
+  GruStackFwdArgs s;
+  unsigned* counters;  // [L][nbt], zeroed before the launch
+  unsigned* error;     // host-visible word
+  unsigned spin_limit;
+};
+
+typedef __attribute__((address_space(1))) unsigned gru_gu32;
+typedef __attribute__((address_space(1))) float gru_gf32;
+
+__device__ __forceinline__ float gru_ld_sc1(const float* p) {
+  return __hip_atomic_load((gru_gf32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gru_st_sc1(float* p, float v) {
+  __hip_atomic_store((gru_gf32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one lane: wait until *cnt >= want, or somebody raised the error word; false on timeout / error
+__device__ __forceinline__ bool gru_wait_ge(unsigned* cnt, unsigned want, unsigned* error, unsigned limit) {
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load((gru_gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    if ((spins & 63u) == 63u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
+    if (spins >= limit) {
+      __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+__global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(const GruPersistArgs pa) {
+  constexpr int NW = GRU_FWD_NW;
+  constexpr int UN = GRU_UNROLL * 4 / NW;  // k-steps per wave: covers H <= 256
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GruStackFwdArgs& a = pa.s;
+  const int H = a.H, T = a.T;
+  float* wh = lds;                       // [H][48]: column g * 16 + c = gate g, unit u0 + c
+  float* wi = wh + (size_t)H * 48;       // [H][48] (layers >= 1)
+  float (*red)[4][256] = reinterpret_cast<float (*)[4][256]>(wi + (size_t)H * 48);
+  __shared__ int go;
+  const int l = blockIdx.z, bt = blockIdx.y;
+  const int nth = gridDim.x, nbt = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * 16, b0 = bt * 16;
+  const bool use_i = l > 0;
+  // weight slices -> LDS (once)
+  for (int e = tid; e < H * 48; e += 64 * NW) {
+    const int k = e / 48, c = e - k * 48;
+    const int g = c >> 4, u = u0 + (c & 15);
+    const size_t src = (size_t)k * 3 * H + (size_t)g * H + u;
+    wh[e] = u < H ? a.w_hh_t[l][src] : 0.f;
+    wi[e] = (use_i && u < H) ? a.w_ih_t[l][src] : 0.f;
+  }
+  __syncthreads();
+  const int arow = b0 + (lane & 15);
+  const bool rok = arow < a.B;
+  const int nsteps = (H + 3) / 4;
+  const int row = (tid & 255) >> 4, col = tid & 15;
+  const int b = b0 + row, u = u0 + col;
+  const bool owner = tid < 256 && b < a.B && u < H;
+  float hprev = 0.f;  // this thread's own previous output (owner threads)
+  float bhr = 0.f, bhz = 0.f, bhn = 0.f, bir = 0.f, biz = 0.f, bin = 0.f;
+  if (owner) {
+    bhr = a.b_hh[l][u]; bhz = a.b_hh[l][H + u]; bhn = a.b_hh[l][2 * H + u];
+    if (use_i) { bir = a.b_ih[l][u]; biz = a.b_ih[l][H + u]; bin = a.b_ih[l][2 * H + u]; }
+  }
+  unsigned* my_cnt = pa.counters + ((size_t)l * nbt + bt) * GRU_CNT_STRIDE;
+  unsigned* lo_cnt = pa.counters + ((size_t)(use_i ? l - 1 : 0) * nbt + bt) * GRU_CNT_STRIDE;
+
+  for (int t = 0; t < T; ++t) {
+    const bool use_h = t > 0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // layer 0: this step's input projection (written before the launch) is fetched under the waits
+    float gir = bir, giz = biz, gin = bin;
+    if (owner && l == 0) {
+      const float* gi = a.gi0 + ((size_t)b * T + t) * 3 * H;
+      gir = gi[u]; giz = gi[H + u]; gin = gi[2 * H + u];
+    }
+    // ---- input part: needs step t of the layer below, which usually finished a step ago
+    if (use_i) {
+      if (tid == 0) go = gru_wait_ge(lo_cnt, (unsigned)nth * (unsigned)(t + 1), pa.error, pa.spin_limit) ? 1 : 0;
+      __syncthreads();
+      if (!go) return;  // timeout or error elsewhere: every workgroup leaves
+      float ai[UN];
+      const float* irow = a.out[l - 1] + ((size_t)arow * T + t) * H;
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int st = wave + NW * i;
+        const int k = 4 * st + (lane >> 4);
+        ai[i] = (st < nsteps && k < H && rok) ? gru_ld_sc1(irow + k) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int st = wave + NW * i;
+        const int k = 4 * st + (lane >> 4);
+        const bool kok = st < nsteps && k < H;
+        const float* wr = wi + (size_t)(kok ? k : 0) * 48 + (lane & 15);
+        const float b0v = kok ? wr[0] : 0.f, b1v = kok ? wr[16] : 0.f, b2v = kok ? wr[32] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], b0v, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], b1v, acc[1], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], b2v, acc[3], 0, 0, 0);
+      }
+    }
+    // ---- hidden part: needs step t-1 of every hidden tile of this layer (the critical dependency)
+    if (use_h) {
+      if (nth > 1) {  // a workgroup that is its layer's only hidden tile depends on nobody but itself
+        __syncthreads();  // everybody is past the previous read of `go`
+        if (tid == 0) go = gru_wait_ge(my_cnt, (unsigned)nth * (unsigned)t, pa.error, pa.spin_limit) ? 1 : 0;
+        __syncthreads();
+        if (!go) return;
+      }
+      float ah[UN];
+      const float* hrow = a.out[l] + ((size_t)arow * T + (t - 1)) * H;
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int st = wave + NW * i;
+        const int k = 4 * st + (lane >> 4);
+        ah[i] = (st < nsteps && k < H && rok) ? gru_ld_sc1(hrow + k) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int st = wave + NW * i;
+        const int k = 4 * st + (lane >> 4);
+        const bool kok = st < nsteps && k < H;
+        const float* wr = wh + (size_t)(kok ? k : 0) * 48 + (lane & 15);
+        const float b0v = kok ? wr[0] : 0.f, b1v = kok ? wr[16] : 0.f, b2v = kok ? wr[32] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], b0v, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], b1v, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], b2v, acc[2], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][g][((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[g][r];
+    __syncthreads();
+    if (owner) {
+      float sg[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][g][tid];
+        sg[g] = v;
+      }
+      const size_t bt_ = (size_t)b * T + t;
+      if (l != 0) gin = sg[3] + bin;
+      const float hn = sg[2] + bhn;
+      const float r = gru_sigmoid(gir + sg[0] + bhr);
+      const float z = gru_sigmoid(giz + sg[1] + bhz);
+      const float n = tanhf(gin + r * hn);
+      float h = (1.f - z) * n + z * hprev;
+      if (a.lengths && t >= a.lengths[b]) h = 0.f;
+      hprev = h;
+      gru_st_sc1(a.out[l] + bt_ * H + u, h);
+      if (a.saved[l]) {
+        const size_t plane = (size_t)a.B * T * H;
+        float* sv = a.saved[l];
+        sv[bt_ * H + u] = r;
+        sv[plane + bt_ * H + u] = z;
+        sv[2 * plane + bt_ * H + u] = n;
+        sv[3 * plane + bt_ * H + u] = hn;
+      }
+    }
+    // publish: every storing wave drains its write-through stores, then ONE lane signals
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add((gru_gu32*)my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -478,14 +672,78 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_stack_bwd_kernel(cons
   a.dh_buf[l][((size_t)(t & 1) * a.B + b) * H + u] = dh;
 }
 
+// ---- persistent-launch state (per device): counters, host-visible error word, limits -------------
+struct GruPersistState {
+  unsigned* error_host = nullptr;  // hipHostMalloc (mapped): the kernel raises it, the host reads it
+  unsigned* error_dev = nullptr;
+  unsigned spin_limit = 0;
+  int cus = 0;
+  int max_lds = 0;
+  bool usable = false;
+};
+static GruPersistState g_gru_ps[16];
+static bool g_gru_ps_init[16];
+static std::mutex g_gru_mu;
+
+static GruPersistState* gru_persist_state_peek() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_gru_mu);
+  return g_gru_ps_init[dev] ? &g_gru_ps[dev] : nullptr;
+}
+
+static GruPersistState* gru_persist_state() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_gru_mu);
+  GruPersistState& ps = g_gru_ps[dev];
+  if (!g_gru_ps_init[dev]) {
+    g_gru_ps_init[dev] = true;
+    const char* e = getenv("M2D_PERSISTENT_GRU");
+    if (e && e[0] == '0') return &ps;  // usable stays false
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return &ps;
+    ps.cus = prop.multiProcessorCount;
+    ps.max_lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (hipHostMalloc((void**)&ps.error_host, 64, hipHostMallocMapped) != hipSuccess) return &ps;
+    *ps.error_host = 0u;
+    if (hipHostGetDevicePointer((void**)&ps.error_dev, ps.error_host, 0) != hipSuccess) return &ps;
+    // ~0.4 us per poll with s_sleep(4): 2^21 polls ~ 1 s before a workgroup gives up
+    ps.spin_limit = 1u << 21;
+    if (hipFuncSetAttribute((const void*)m2d_gru_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            140 * 1024) != hipSuccess)
+      return &ps;
+    ps.usable = true;
+  }
+  return ps.usable ? &ps : nullptr;
+}
+
+static size_t gru_persist_lds(int H) { return ((size_t)2 * H * 48 + (size_t)GRU_FWD_NW * 4 * 256) * sizeof(float); }
+
+// every workgroup must be resident at once: one per CU (the LDS footprint allows no second one)
+static bool gru_persist_ok(dim3 grid, int H, int T) {
+  if (H > 256 || T < 4) return false;
+  GruPersistState* ps = gru_persist_state();
+  if (!ps) return false;
+  const size_t lds = gru_persist_lds(H);
+  if (lds > 140 * 1024 || (int)lds > ps->max_lds) return false;
+  const int per_cu = lds > 0 ? (int)((size_t)ps->max_lds / lds) : 1;
+  const long long blocks = (long long)grid.x * grid.y * grid.z;
+  // leave a margin: other streams' kernels (the noise GRU) need a place to run too
+  return blocks <= (long long)ps->cus * (per_cu > 0 ? per_cu : 1) * 3 / 4;
+}
+
 extern "C" {
+
+// scratch words m2d_gru_stack_fwd needs for its persistent form (multiple of 4: the memset stays 16-byte sized)
+int m2d_gru_stack_counters(int B, int L) { return L * m2d_ceil_div(B, 16) * GRU_CNT_STRIDE; }
 
 // L-layer GRU forward on the (layer, t) diagonal. Pointer arrays have L entries; entry 0 of
 // w_ih_t / b_ih is ignored (layer 0's projection gi0 is precomputed by m2d_gemm).
 // saved[l]: (4, B, T, H) or all NULL.
 int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float* const* b_ih,
                       const float* const* w_hh_t, const float* const* b_hh, float* const* out, float* const* saved,
-                      const int* lengths, int B, int T, int H, int L, void* stream_) {
+                      const int* lengths, int B, int T, int H, int L, unsigned* counters, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || T <= 0 || H <= 0 || L <= 0 || L > GRU_MAX_LAYERS) M2D_FAIL(M2D_ERR_ARG, "m2d_gru_stack_fwd: bad shape");
   GruStackFwdArgs a;
@@ -498,12 +756,40 @@ int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float*
   a.B = B; a.T = T; a.H = H; a.L = L;
   dim3 grid(m2d_ceil_div(H, 16), m2d_ceil_div(B, 16), L);
   M2dProfScope prof(M2D_FAM_GRU, stream, 2.0 * B * 3.0 * H * H * (double)T * (2 * L - 1), 0.0, "gru_stack_fwd", B, T, H);
+  // `counters` (optional: m2d_gru_stack_counters(B, L) unsigneds of scratch owned by this call): run the
+  // recurrence as ONE persistent launch when every workgroup fits on the chip at once
+  if (counters && gru_persist_ok(grid, H, T)) {
+    GruPersistState* ps = gru_persist_state();
+    if (ps) {
+      const size_t cbytes = sizeof(unsigned) * (size_t)m2d_gru_stack_counters(B, L);
+      if (hipMemsetAsync(counters, 0, cbytes, stream) == hipSuccess) {
+        GruPersistArgs pa;
+        pa.s = a;
+        pa.counters = counters;
+        pa.error = ps->error_dev;
+        pa.spin_limit = ps->spin_limit;
+        hipLaunchKernelGGL(m2d_gru_persist_fwd_kernel, grid, dim3(64 * GRU_FWD_NW), gru_persist_lds(H), stream, pa);
+        M2D_CHECK_LAUNCH("m2d_gru_persist_fwd_kernel");
+        return M2D_OK;
+      }
+    }
+  }
   for (int d = 0; d < T + L - 1; ++d) {
     a.d = d;
     hipLaunchKernelGGL(m2d_gru_stack_fwd_kernel, grid, dim3(64 * GRU_FWD_NW), 0, stream, a);
   }
   M2D_CHECK_LAUNCH("m2d_gru_stack_fwd_kernel");
   return M2D_OK;
+}
+
+// 1 when a persistent GRU launch timed out since the last call (and clears the flag): the outputs
+// of that call are invalid. 0 otherwise. Does not synchronise: call it after a stream sync.
+int m2d_gru_persist_error(void) {
+  GruPersistState* ps = gru_persist_state_peek();
+  if (!ps || !ps->error_host) return 0;
+  const unsigned e = *(volatile unsigned*)ps->error_host;
+  if (e) *(volatile unsigned*)ps->error_host = 0u;
+  return e ? 1 : 0;
 }
 
 // BPTT for the whole stack on the anti-diagonal. dgi[l], dgh[l]: (B, T, 3H); dh_buf[l]: 2*B*H floats.

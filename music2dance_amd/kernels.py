@@ -429,7 +429,7 @@ class HipKernels:
         arr = (ctypes.c_void_p * len(tensors))(*[_ptr(t) for t in tensors])
         return arr, ctypes.cast(arr, ctypes.c_void_p)
 
-    def gru_stack_fwd(self, gi0, w_ih_t, b_ih, w_hh_t, b_hh, lengths=None, save=True):
+    def gru_stack_fwd(self, gi0, w_ih_t, b_ih, w_hh_t, b_hh, lengths=None, save=True, persistent=True):
         """L-layer GRU on the (layer, t) diagonal. Lists have L entries (entry 0 of w_ih_t / b_ih may
         be None). Returns ([out_l (B,T,H)], [saved_l (4,B,T,H)] or None)."""
         L = len(w_hh_t)
@@ -440,11 +440,23 @@ class HipKernels:
         saved = [torch.empty((4, B, T, H), dtype=torch.float32, device=dev) for _ in range(L)] if save else None
         keep = [self._ptr_array(v) for v in (w_ih_t, b_ih, w_hh_t, b_hh, outs)]
         sv = self._ptr_array(saved) if save else (None, None)
+        h = _lib.lib()
+        # scratch for the persistent form (one launch for the whole recurrence); the library decides
+        counters = (torch.empty((h.m2d_gru_stack_counters(B, L),), dtype=torch.int32, device=dev)
+                    if persistent else None)
         with _on(dev):
-            rc = _lib.lib().m2d_gru_stack_fwd(_ptr(gi0), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
-                                              sv[1], _ptr(lengths), B, T, H, L, _stream(dev))
+            rc = h.m2d_gru_stack_fwd(_ptr(gi0), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
+                                     sv[1], _ptr(lengths), B, T, H, L, _ptr(counters), _stream(dev))
         _lib.check(rc, "m2d_gru_stack_fwd")
         return outs, saved
+
+    @staticmethod
+    def check_async_errors():
+        """Raise if a persistent GRU launch timed out (another process holding the CUs it waits for).
+        Call after a stream synchronisation; cheap (reads one pinned host word)."""
+        if _lib.lib().m2d_gru_persist_error():
+            raise _lib.M2dError("persistent GRU launch timed out: outputs of that call are invalid "
+                                "(several processes on one GPU? set M2D_PERSISTENT_GRU=0)")
 
     def gru_stack_bwd(self, dout, outs, saved, w_hh, w_ih, lengths=None):
         """BPTT of the stack; returns ([dgi_l (B,T,3H)], [dgh_l (B,T,3H)])."""

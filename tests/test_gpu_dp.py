@@ -22,6 +22,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, graphs, q):
+    os.environ["M2D_PERSISTENT_GRU"] = "0"  # two processes on ONE GPU: persistent kernels could starve each other
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

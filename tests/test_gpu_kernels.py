@@ -610,3 +610,37 @@ def test_conv1d_epilogue_statistics_and_bn_from_sums(case):
     # "two ranks": statistics over twice the data = the sums doubled, count doubled -> same normalisation
     o3, _, _ = k.bn_fwd_sums(y, 2 * sums, 2 * n, g, bt, None, None, 1e-5, 0.1, act=2, slope=0.2)
     assert rel_err(o3, o1.double()) < 2e-6
+
+
+# ----------------------------------------------------------------------------------- persistent GRU
+@pytest.mark.parametrize("dims", [(64, 120, 240, 3), (16, 300, 240, 3), (32, 120, 50, 3), (64, 120, 10, 1), (5, 7, 33, 2)],
+                         ids=lambda d: "B%d-T%d-H%d-L%d" % d)
+def test_persistent_gru_is_bit_identical_to_the_step_launches(dims):
+    """One persistent launch (weights in LDS, cross-CU hand-off per step through write-through stores and
+    agent-scope counters) against T + L - 1 dependent step launches: same MFMA and reduction order, so every
+    word must be equal - outputs and the gates saved for BPTT. Run twice more under a concurrent stream of
+    large GEMMs (uneven load, other CUs' L1 / L2 busy) to stress the hand-off."""
+    B, T, H, L = dims
+    k = K()
+    g = torch.Generator().manual_seed(3)
+    gi0 = (torch.randn(B, T, 3 * H, generator=g) * 0.5).to(DEV)
+    w_hh_t = [(torch.randn(H, 3 * H, generator=g) / math.sqrt(H)).to(DEV) for _ in range(L)]
+    w_ih_t = [None] + [(torch.randn(H, 3 * H, generator=g) / math.sqrt(H)).to(DEV) for _ in range(L - 1)]
+    b_hh = [(torch.randn(3 * H, generator=g) * 0.1).to(DEV) for _ in range(L)]
+    b_ih = [None] + [(torch.randn(3 * H, generator=g) * 0.1).to(DEV) for _ in range(L - 1)]
+    lens = None if B != 5 else torch.tensor([7, 6, 4, 2, 1], dtype=torch.int32, device=DEV)
+    ref_o, ref_s = k.gru_stack_fwd(gi0, w_ih_t, b_ih, w_hh_t, b_hh, lens, True, persistent=False)
+    a = torch.randn(4096, 4096, device=DEV)
+    side = torch.cuda.Stream()
+    for trial in range(3):
+        if trial:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    k.gemm(0, a, a)
+        out, saved = k.gru_stack_fwd(gi0, w_ih_t, b_ih, w_hh_t, b_hh, lens, True, persistent=True)
+        torch.cuda.synchronize()
+        k.check_async_errors()
+        for l in range(L):
+            assert torch.equal(out[l], ref_o[l]), (trial, l)
+            assert torch.equal(saved[l], ref_s[l]), (trial, l)
