@@ -63,6 +63,30 @@ class Linear(nn.Linear):
         return ops.linear(x, self.weight, self.bias, act, slope)
 
 
+_BN_COUNT_BATCHED = [False]
+
+
+class batched_bn_counters:
+    """Inside: the training-mode BatchNorm layers of `module` do not launch one `num_batches_tracked += 1`
+    each; all counters are advanced by ONE fused multi-tensor add on entry (a generator forward has 12 of
+    them). Every BatchNorm1d of the module that is in training mode must run exactly once inside."""
+
+    def __init__(self, module):
+        self.counters = [m.num_batches_tracked for m in module.modules()
+                         if isinstance(m, BatchNorm1d) and m.training and m.num_batches_tracked is not None]
+
+    def __enter__(self):
+        self.prev = _BN_COUNT_BATCHED[0]
+        if self.counters and not self.prev:
+            torch._foreach_add_(self.counters, 1)
+            _BN_COUNT_BATCHED[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _BN_COUNT_BATCHED[0] = self.prev
+        return False
+
+
 class BatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d on (N, C) / (N, C, L) with the following ReLU / LeakyReLU and an
     optional residual add fused into the normalisation pass."""
@@ -71,7 +95,7 @@ class BatchNorm1d(nn.BatchNorm1d):
         """sums: batch statistics of x from the producing conv's epilogue (Conv1d(..., with_stats=True))."""
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError("m2d BatchNorm1d: only the reference's configuration is supported")
-        if self.training:
+        if self.training and not _BN_COUNT_BATCHED[0]:
             self.num_batches_tracked.add_(1)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                               self.eps, self.momentum, act, slope, residual, sums if self.training else None)
@@ -81,7 +105,8 @@ class BatchNorm1d(nn.BatchNorm1d):
         """Advance the running statistics with a batch without producing an output graph
         (the dead fc1 -> bn1 branch of LinearBlock, phase3/archis/default.py:184-187)."""
         if self.training:
-            self.num_batches_tracked.add_(1)
+            if not _BN_COUNT_BATCHED[0]:
+                self.num_batches_tracked.add_(1)
             ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, True, self.eps,
                            self.momentum)
 

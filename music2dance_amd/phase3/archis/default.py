@@ -17,8 +17,8 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...layers import (GRU, BatchNorm1d, Conv1d, Linear, WindowView, head_activation, lengths_tensor,
-                       to_device_async)
+from ...layers import (GRU, BatchNorm1d, Conv1d, Linear, WindowView, batched_bn_counters, head_activation,
+                       lengths_tensor, to_device_async)
 from ...utils import initialize_weights
 
 
@@ -264,6 +264,10 @@ class SequenceGenerator(nn.Module):
 
     def forward(self, x, lengths, noise=None):
         # x: (batch, frames, window)
+        with batched_bn_counters(self):  # one fused add for the 12 BatchNorm step counters
+            return self._forward(x, lengths, noise)
+
+    def _forward(self, x, lengths, noise=None):
         frames = x.size(1)
         # an overlapping-window view of the padded track (utils.slice_audio_batch(..., lazy=True)) is read
         # in place by the first encoder conv; a dense (B, T, window) tensor is used as the reference does
