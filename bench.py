@@ -63,7 +63,7 @@ def pmc_traffic():
     return d.get("hbm_bytes_per_launch_fetch_x2", d.get("hbm_bytes_per_launch_uncorrected")), os.path.basename(files[-1])
 
 
-def cpu_baseline(sample_b=16, T=120, threads=None):
+def cpu_baseline(sample_b=32, T=120, threads=None):
     """Oracle (CPU port of the reference path) on the host cores: 1 warm-up + 2 timed critic
     iterations + 1 generator iteration at batch `sample_b`, extrapolated to seq/s of a
     full 8+1 cycle (the path is linear in the batch). Thread count: the op sizes at this

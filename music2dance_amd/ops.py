@@ -34,7 +34,8 @@ def K():
 
 # ---------------------------------------------------------------------------------------
 # backward-pass pruning switches (results are unchanged; they only skip work whose result
-# the caller discards)
+# the caller discards). Process-global on purpose: they are set by the thread that calls
+# backward() / autograd.grad() and read by autograd's device worker thread while that call blocks.
 _state = {"inputs_only": False, "dead_inputs": set()}
 
 
@@ -57,13 +58,15 @@ def no_input_grad_for(*tensors):
     """Inside: ops whose input is one of `tensors` (matched by storage address) do not
     compute that input's gradient. The training engine uses it for the raw audio, whose
     gradient the reference computes and throws away."""
-    keys = {t.data_ptr() for t in tensors if t is not None}
+    alive = [t for t in tensors if t is not None]  # held for the whole scope: a live tensor's address is unique
+    keys = {t.data_ptr() for t in alive}
     prev = _state["dead_inputs"]
     _state["dead_inputs"] = prev | keys
     try:
         yield
     finally:
         _state["dead_inputs"] = prev
+        del alive
 
 
 def _mask_of(act, slope, y):

@@ -235,3 +235,36 @@ def test_graph_mode_matches_eager():
             assert abs(e[k] - g[k]) <= 1e-5 * max(1.0, abs(e[k])), (k, e[k], g[k])
     for pe, pg in zip(*params):
         assert rel(pg, pe) < 1e-5
+
+
+def test_graph_mode_with_two_input_shapes():
+    """Captured graphs are kept per input shape and each writes its gradients into the tensors it was
+    captured with (p.grad is re-bound before every replay): alternating between two batch sizes gives
+    the eager path's losses and parameters (round-1 advisor finding: the second capture used to orphan
+    the first graph's gradient buffers)."""
+    import bench
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+    dev = torch.device(DEV)
+    t = 120
+    batches = [synthetic_phase3_batch(4, t, dev, seed=30), synthetic_phase3_batch(2, t, dev, seed=31)]
+    order = [0, 1, 0, 0, 1, 0, 1, 1, 0, 1]
+    traces, params = [], []
+    for use_graphs in (False, True):
+        gen, critic = bench.build_models(dev, t)
+        eng = Phase3Engine(gen, critic, dict(bench.P3_DEFAULT, n_critic_steps=3))
+        if use_graphs:
+            eng.enable_graphs()
+        torch.manual_seed(78)
+        tr = []
+        for i in order:
+            out = eng.train_step(*batches[i])
+            tr.append({k: float(v) for k, v in out.items()})
+        eng.flush()
+        traces.append(tr)
+        params.append([p.detach().clone() for p in list(critic.parameters()) + list(gen.parameters())])
+    for e, g in zip(*traces):
+        assert set(e) == set(g)
+        for k in e:
+            assert abs(e[k] - g[k]) <= 1e-5 * max(1.0, abs(e[k])), (k, e[k], g[k])
+    for pe, pg in zip(*params):
+        assert rel(pg, pe) < 1e-5
