@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int i31 = lane & 31, h = lane >> 5;
   const int lq = 4 * (lane & 15);
-  const bool vec = (a.Lout % 4) == 0;
+  const bool vec = (a.Lout % 4) == 0, vec2 = (a.Lout % 2) == 0;
   float4 dv[8], mv[8];
   // fetch(lt): this lane's 8 x float4 of the dy tile (and mask) starting at position lt
   auto fetch = [&](int lt) {
@@ -117,6 +117,17 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
       if (vec && lt + lq + 3 < l1) {
         dv[i] = *reinterpret_cast<const float4*>(dyn + g);
         mv[i] = mkn ? *reinterpret_cast<const float4*>(mkn + g) : make_float4(1.f, 1.f, 1.f, 1.f);
+      } else if (vec2 && lt + lq + 3 < l1 && ((l0 & 1) == 0)) {
+        const float2 d0 = *reinterpret_cast<const float2*>(dyn + g);
+        const float2 d1 = *reinterpret_cast<const float2*>(dyn + g + 2);
+        dv[i] = make_float4(d0.x, d0.y, d1.x, d1.y);
+        if (mkn) {
+          const float2 m0 = *reinterpret_cast<const float2*>(mkn + g);
+          const float2 m1 = *reinterpret_cast<const float2*>(mkn + g + 2);
+          mv[i] = make_float4(m0.x, m0.y, m1.x, m1.y);
+        } else {
+          mv[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        }
       } else {
         float d[4], m[4];
 #pragma unroll
@@ -274,7 +285,9 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const bool full = (a.Lout % 4 == 0) && (p0 + NP <= a.Lout);
+  // Row starts are Lout floats apart: 16-byte stores need Lout % 4 == 0, 8-byte ones Lout % 2 == 0
+  // (WaveGAN's 794-position rows take the float2 path; odd lengths store scalars).
+  const int valign = (a.Lout % 4 == 0) ? 4 : (a.Lout % 2 == 0) ? 2 : 1;
   const int cq = lane % LPR;
 #pragma unroll 4
   for (int i = 0; i < 32 / RPI; ++i) {
@@ -288,7 +301,8 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
       if (a.act == 1) v[j] = v[j] > 0.f ? v[j] : 0.f;
       else if (a.act == 2) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
     }
-    if (full) {
+    const bool whole = p0 + 4 * cq + 4 <= a.Lout;
+    if (whole && valign == 4) {
       if (a.mask) {
         const float4 m = *reinterpret_cast<const float4*>(a.mask + o);
         v[0] *= m.x > 0.f ? 1.f : a.mask_slope;
@@ -297,6 +311,17 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
         v[3] *= m.w > 0.f ? 1.f : a.mask_slope;
       }
       *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (whole && valign == 2) {
+      if (a.mask) {
+        const float2 m0 = *reinterpret_cast<const float2*>(a.mask + o);
+        const float2 m1 = *reinterpret_cast<const float2*>(a.mask + o + 2);
+        v[0] *= m0.x > 0.f ? 1.f : a.mask_slope;
+        v[1] *= m0.y > 0.f ? 1.f : a.mask_slope;
+        v[2] *= m1.x > 0.f ? 1.f : a.mask_slope;
+        v[3] *= m1.y > 0.f ? 1.f : a.mask_slope;
+      }
+      *reinterpret_cast<float2*>(a.out + o) = make_float2(v[0], v[1]);
+      *reinterpret_cast<float2*>(a.out + o + 2) = make_float2(v[2], v[3]);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

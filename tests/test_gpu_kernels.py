@@ -55,6 +55,8 @@ CONV_CASES = [
     ("enc.c5", 6, 512, 4, 1024, 4, 2, 1),
     ("enc.c6", 6, 1024, 2, 250, 2, 1, 0),
     ("wg.l1", 3, 1, 3200, 32, 25, 4, 0),
+    ("wg.l1-odd-lout", 3, 1, 3204, 32, 25, 4, 0),
+    ("wg.l1-pad-even", 2, 1, 3210, 32, 25, 4, 3),
     ("wg.l2", 3, 32, 794, 64, 25, 4, 0),
     ("wg.l3", 3, 64, 193, 128, 25, 4, 0),
     ("wg.l4", 3, 128, 43, 256, 25, 4, 0),
