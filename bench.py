@@ -233,6 +233,10 @@ def main():
         engine.enable_graphs()
     real, audio, slices = synthetic_phase3_batch(args.batch, args.frames, device, seed=100 + rank)
     gen.train(), critic.train()
+    # the synthetic batch is resident and complete from here on: lets the engine start an iteration's
+    # generator forward on its second stream while the previous iteration's critic kernels still run
+    torch.cuda.synchronize(device)
+    ready = torch.cuda.current_stream(device).record_event()
 
     def barrier():
         if world > 1:
@@ -241,16 +245,24 @@ def main():
 
     torch.manual_seed(1234 + rank)
     for _ in range(args.warmup):
-        engine.train_step(real, audio, slices)
+        engine.train_step(real, audio, slices, inputs_ready=ready)
     engine.flush()
     K = kernels.impl()
     barrier()
+    step_events = [] if os.environ.get("M2D_STEP_TIMES") else None  # dev aid: per-step GPU time to stderr
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        engine.train_step(real, audio, slices)
+        engine.train_step(real, audio, slices, inputs_ready=ready)
+        if step_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_events.append(ev)
     engine.flush()
     barrier()
     elapsed = time.perf_counter() - t0
+    if step_events:
+        print("step ms:", " ".join("%.2f" % a.elapsed_time(b) for a, b in zip(step_events, step_events[1:])),
+              file=sys.stderr)
     # Per-launch HIP events for the roofline: a SECOND pass over the same K steps. Two event
     # records around each of the ~680 launches of a step cost ~8 % of wall time (measured:
     # 20.3 vs 18.7 ms per step), so they stay out of the region `value` is timed on; the kernels,
@@ -263,6 +275,7 @@ def main():
         # event pair around a launch would then also count the other stream's kernels, so the roofline
         # pass runs the two branches one after the other: each duration is the launch's own
         type(critic).overlap_branches = False
+        engine.pipeline_generator = False  # likewise the generator forward: in line for the per-launch pass
         K.prof_begin()
         for _ in range(args.steps):
             engine.train_step(real, audio, slices)

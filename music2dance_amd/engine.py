@@ -9,12 +9,15 @@ the raw-audio gradient is not formed outside the penalty, and during generator s
 critic's parameters are frozen instead of receiving gradients that the next zero_grad
 throws away.
 """
+import contextlib
+import os
+
 import torch
 import torch.optim as optim
 
 from . import kernels, ops
 from .dp import GradExchange
-from .layers import to_device_async
+from .layers import copy_stream, to_device_async
 from .losses import gradient_penalty, tv_loss
 
 
@@ -57,6 +60,13 @@ class WganGpEngine:
         self._critic_step_pending = False
         self.last = {}
         self.last_full = {}  # most recent value of every scalar (generator scalars persist between G steps)
+        # generator-forward pipelining (see _generator_forward_nograd)
+        self.pipeline_generator = os.environ.get("M2D_GEN_PIPELINE", "1") != "0"
+        self._inputs_ready = None
+        self._gen_stream = None
+        self._gen_params_ready = None
+        self._main_mark = None
+        self._fake_pending = None
 
     # -- critic optimiser step, possibly deferred so its all-reduce overlaps the next G forward
     def _finish_critic_step(self):
@@ -80,14 +90,61 @@ class WganGpEngine:
             self.x_gen.exchange()
         self.optim_gen.step()
         kernels.impl().invalidate_packed()
+        if self._gen_stream is not None:
+            self._gen_params_ready = torch.cuda.current_stream().record_event()
+
+    def _generator_forward_nograd(self, fn, inputs):
+        """The generator forward of a critic iteration (no autograd graph: the reference builds one and
+        drops it). It reads the generator's weights and the batch, nothing the critic's optimizer
+        touches, so it need not wait for the previous critic iteration: when the caller passes
+        `inputs_ready` (an event after which the batch tensors are complete - a copy stream's, or one
+        recorded before the loop for resident data) it runs on a second stream and the launch-bound
+        part of the generator (the recurrent layers, the decoder's small layers) executes underneath
+        the previous iteration's critic GEMMs. Same kernels, same operands, same results; without
+        `inputs_ready` the forward runs in line."""
+        ready = self._inputs_ready
+        dev = inputs[0].device
+        if ready is None or not self.pipeline_generator or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            with torch.no_grad():
+                return fn()
+        main = torch.cuda.current_stream(dev)
+        if self._gen_stream is None:
+            self._gen_stream = torch.cuda.Stream(dev)  # default priority: a high-priority queue preempts (measured +25 %)
+            self._gen_params_ready = main.record_event()  # weights as initialised / loaded on the main stream
+        gs = self._gen_stream
+        gs.wait_event(ready)
+        gs.wait_event(self._gen_params_ready)
+        if self._main_mark is not None:
+            # at most one iteration ahead: not before the main stream has taken delivery of the previous result
+            gs.wait_event(self._main_mark)
+        with torch.cuda.stream(gs), torch.no_grad():
+            out = fn()
+            done = gs.record_event()
+        for t in inputs:
+            t.record_stream(gs)
+        self._fake_pending = (out, done)  # the consumer calls _join_generator_forward before reading `out`
+        return out
+
+    def _join_generator_forward(self, out):
+        pend, self._fake_pending = self._fake_pending, None
+        if pend is None:
+            return
+        assert pend[0] is out
+        main = torch.cuda.current_stream(out.device)
+        main.wait_event(pend[1])
+        self._main_mark = main.record_event()
+        out.record_stream(main)
 
     def flush(self):
         self._finish_critic_step()
 
-    def train_step(self, *batch):
+    def train_step(self, *batch, inputs_ready=None):
         """One loop body of the reference: a critic iteration, plus a generator iteration every
-        n_critic_steps-th call. Returns a dict of 0-dim device tensors (no host sync)."""
+        n_critic_steps-th call. Returns a dict of 0-dim device tensors (no host sync).
+        inputs_ready: optional event after which the batch tensors are complete; lets the generator
+        forward start before the previous iteration has drained (_generator_forward_nograd)."""
         self.total_iterations += 1
+        self._inputs_ready = inputs_ready
         # weights only change in the optimizer steps, which drop the packed conv-weight images
         with kernels.impl().weight_cache():
             out = self.critic_iteration(*batch)
@@ -123,15 +180,20 @@ class Phase3Engine(WganGpEngine):
         """Forward / backward of the critic iteration up to the gradients (no optimizer step).
         noise / alpha: None = drawn from the host generator where the reference draws them."""
         B, T = self._shapes(real)
-        with torch.no_grad():  # the reference builds and drops this graph (phase3/train.py:195)
-            fake_rows = self.gen(audio_slices, [T] * B, noise)
+        # the reference builds and drops this graph (phase3/train.py:195)
+        fake_rows = self._generator_forward_nograd(lambda: self.gen(audio_slices, [T] * B, noise), (audio_slices,))
         if finish_inside:
             self._finish_critic_step()
         # only after the deferred step has consumed the previous iteration's gradients
         self.optim_critic.zero_grad(set_to_none=True)
-        fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         audio_c = audio.unsqueeze(1)
+        with self.critic.shared_audio() if not self.ablated else contextlib.nullcontext():
+            self._join_generator_forward(fake_rows)
+            return self._critic_passes(B, T, real, real_c, fake_rows, audio_c, alpha)
+
+    def _critic_passes(self, B, T, real, real_c, fake_rows, audio_c, alpha):
+        fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         if self.ablated:
             gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=False, device=real.device, alpha=alpha)
             s_real, s_fake = self.critic.score_pair(real_c, fake)
@@ -139,14 +201,13 @@ class Phase3Engine(WganGpEngine):
             err_critic = err_fake - err_real + self.gamma * gp
             err_critic.backward()
         else:
-            with self.critic.shared_audio():
-                gp = gradient_penalty(self.critic, B, real_c, fake, audio_c, is_seq=True, lp=False,
-                                      device=real.device, alpha=alpha)
-                s_real, s_fake = self.critic.score_pair(real_c, fake, audio_c)
-                err_real, err_fake = s_real.mean(), s_fake.mean()
-                err_critic = err_fake - err_real + self.gamma * gp
-                with ops.no_input_grad_for(audio_c):
-                    err_critic.backward()
+            gp = gradient_penalty(self.critic, B, real_c, fake, audio_c, is_seq=True, lp=False,
+                                  device=real.device, alpha=alpha)
+            s_real, s_fake = self.critic.score_pair(real_c, fake, audio_c)
+            err_real, err_fake = s_real.mean(), s_fake.mean()
+            err_critic = err_fake - err_real + self.gamma * gp
+            with ops.no_input_grad_for(audio_c):
+                err_critic.backward()
             audio_c.requires_grad_(False)
         return {"loss_critic": err_critic.detach(), "gp": gp.detach(), "w_dist": (err_fake - err_real).detach()}
 
@@ -198,9 +259,9 @@ class Phase3Engine(WganGpEngine):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         return self
 
-    def train_step(self, real, audio, audio_slices):
+    def train_step(self, real, audio, audio_slices, inputs_ready=None):
         if not getattr(self, "_use_graphs", False) or real.device.type != "cuda":
-            return super().train_step(real, audio, audio_slices)
+            return super().train_step(real, audio, audio_slices, inputs_ready=inputs_ready)
         self.total_iterations += 1
         self._finish_critic_step()
         g = self._graph_for(real, audio, audio_slices)
@@ -409,17 +470,33 @@ class Phase1Engine(WganGpEngine):
 
 
 # =========================================================================================== synthetic data
-def synthetic_phase3_batch(B, T, device, seed=0, audio_rate=16000, video_rate=25, window_s=0.2, lazy=None):
+def synthetic_phase3_batch(B, T, device, seed=0, audio_rate=16000, video_rate=25, window_s=0.2, lazy=None,
+                           with_event=False):
     """Random poses / audio of the dataset's shapes: poses U[0,1) (B, T, 69),
     audio N(0, 0.1^2) (B, T*640), windows of 3200 samples every 640. On a HIP device the windows are
-    the in-place view of the padded track (lazy slicing: the generator's first conv gathers them)."""
+    the in-place view of the padded track (lazy slicing: the generator's first conv gathers them).
+    with_event: stage the batch on the copy stream (no host sync with the compute stream) and also return
+    the event after which it is complete - what `train_step(..., inputs_ready=)` takes."""
     from .utils import slice_audio_batch
     g = torch.Generator().manual_seed(seed)
     hop = audio_rate // video_rate
     window = int(window_s * audio_rate)
-    real = torch.rand(B, T, 69, generator=g).to(device)
-    audio = (0.1 * torch.randn(B, hop * T, generator=g)).to(device)
+    real_h = torch.rand(B, T, 69, generator=g)
+    audio_h = 0.1 * torch.randn(B, hop * T, generator=g)
+    device = torch.device(device)
     if lazy is None:
-        lazy = torch.device(device).type == "cuda"
-    slices = slice_audio_batch(audio, window, hop, window - hop, lazy=lazy)
-    return real, audio, slices
+        lazy = device.type == "cuda"
+    if not with_event or device.type != "cuda":
+        real, audio = real_h.to(device), audio_h.to(device)
+        slices = slice_audio_batch(audio, window, hop, window - hop, lazy=lazy)
+        return (real, audio, slices, None) if with_event else (real, audio, slices)
+    cur = torch.cuda.current_stream(device)
+    cs = copy_stream(device)
+    with torch.cuda.stream(cs):
+        real, audio = real_h.to(device), audio_h.to(device)
+        slices = slice_audio_batch(audio, window, hop, window - hop, lazy=lazy)
+        ready = cs.record_event()
+    cur.wait_event(ready)
+    for t in (real, audio, slices):
+        t.record_stream(cur)
+    return real, audio, slices, ready

@@ -15,6 +15,15 @@ from . import ops
 _COPY_STREAMS = {}
 
 
+def copy_stream(device):
+    """The per-device stream host -> device staging runs on."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cs = _COPY_STREAMS.get(idx)
+    if cs is None:
+        cs = _COPY_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return cs
+
+
 def to_device_async(t, device):
     """Move a HOST tensor (random draws from the host generator, as the reference makes them)
     to `device` without draining the compute stream. A copy from pageable memory blocks the
@@ -25,10 +34,7 @@ def to_device_async(t, device):
     device = torch.device(device)
     if device.type != "cuda":
         return t.to(device)
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    cs = _COPY_STREAMS.get(idx)
-    if cs is None:
-        cs = _COPY_STREAMS[idx] = torch.cuda.Stream(device=device)
+    cs = copy_stream(device)
     cur = torch.cuda.current_stream(device)
     with torch.cuda.stream(cs):
         out = t.to(device)

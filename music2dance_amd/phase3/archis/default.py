@@ -361,6 +361,10 @@ class SequenceDiscriminator(nn.Module):
         finally:
             self._share = prev
 
+    def audio_code(self, c):
+        """Evaluate (and, inside shared_audio(), cache) the audio branch for `c` ahead of the calls that use it."""
+        return self._audio_code(c)
+
     def _audio_code(self, c):
         if self._share is None:
             return self.audio_d(c)

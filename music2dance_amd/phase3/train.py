@@ -83,11 +83,12 @@ def main(argv=None):
     for epoch in range(cfg["num_epochs"]):
         gen.train()
         for b in range(batches_per_epoch):
-            real, audio, slices = synthetic_phase3_batch(batch_size, stick_length, device,
-                                                         seed=1 + (epoch * batches_per_epoch + b) * world + rank,
-                                                         audio_rate=ds["audio_rate"], video_rate=ds["video_rate"],
-                                                         window_s=cfg["window_size"])
-            out = engine.train_step(real, audio, slices)
+            # staged on the copy stream: the engine may start this batch's generator forward while the
+            # previous iteration's critic kernels are still running
+            real, audio, slices, ready = synthetic_phase3_batch(
+                batch_size, stick_length, device, seed=1 + (epoch * batches_per_epoch + b) * world + rank,
+                audio_rate=ds["audio_rate"], video_rate=ds["video_rate"], window_s=cfg["window_size"], with_event=True)
+            out = engine.train_step(real, audio, slices, inputs_ready=ready)
             it = engine.total_iterations
             if "loss_gen" in out:
                 log.scalars({"loss_critic": -out["loss_critic"], "loss_gen": out["loss_gen"], "gp": out["gp"],

@@ -268,3 +268,48 @@ def test_graph_mode_with_two_input_shapes():
             assert abs(e[k] - g[k]) <= 1e-5 * max(1.0, abs(e[k])), (k, e[k], g[k])
     for pe, pg in zip(*params):
         assert rel(pg, pe) < 1e-5
+
+
+def test_pipelined_generator_forward_is_bit_identical():
+    """train_step(..., inputs_ready=event): the critic iterations' generator forward runs on the engine's
+    second stream, ahead of the previous iteration's critic kernels (the host is not synchronised inside
+    the loop, so the streams really overlap). Same kernels on the same operands: losses, parameters and
+    BatchNorm running statistics are bit-equal to the in-line order, also across generator steps (which
+    change the weights the second stream reads) and with the batch alternating between two tensors."""
+    import bench
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+    dev = torch.device(DEV)
+    b, t = 8, 120
+    batches = [synthetic_phase3_batch(b, t, dev, seed=40 + i) for i in range(2)]
+    torch.cuda.synchronize(dev)
+    ready = torch.cuda.current_stream(dev).record_event()
+    traces, params = [], []
+    for pipelined in (False, True, "staged"):
+        gen, critic = bench.build_models(dev, t)
+        eng = Phase3Engine(gen, critic, dict(bench.P3_DEFAULT, n_critic_steps=3))
+        assert eng.pipeline_generator
+        torch.manual_seed(79)
+        outs = []
+        for i in range(10):
+            if pipelined == "staged":
+                # a fresh batch per iteration, staged on the copy stream and dropped right after the call
+                # (what phase3/train.py does): the second stream still reads it after the host let go
+                *bt, ev = synthetic_phase3_batch(b, t, dev, seed=40 + i % 2, with_event=True)
+                outs.append(eng.train_step(*bt, inputs_ready=ev))
+                del bt, ev
+            else:
+                outs.append(eng.train_step(*batches[i % 2], inputs_ready=ready if pipelined else None))
+        eng.flush()
+        assert (eng._gen_stream is not None) == bool(pipelined)
+        traces.append([{k: v.clone() for k, v in o.items()} for o in outs])
+        params.append([p.detach().clone() for p in list(critic.parameters()) + list(gen.parameters())]
+                      + [bf.detach().clone() for bf in gen.buffers()])
+    from music2dance_amd import kernels
+    kernels.impl().check_async_errors()
+    for other in (1, 2):
+        for e, g in zip(traces[0], traces[other]):
+            assert set(e) == set(g)
+            for k in e:
+                assert torch.equal(e[k], g[k]), (other, k, float(e[k]), float(g[k]))
+        for pe, pg in zip(params[0], params[other]):
+            assert torch.equal(pe, pg)
