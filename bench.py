@@ -319,8 +319,9 @@ def main():
                         f.write(",".join(str(v) for v in row) + "\n")
             out["roofline"] = {
                 "measured_over": "second pass of the same %d steps with HIP events around every launch, "
-                                 "critic branches serialised (in the timed region the pose branch overlaps the "
-                                 "audio branch on a side stream)" % args.steps,
+                                 "all work on one stream (in the timed region the critic's pose branch runs on a side "
+                                 "stream under its audio branch, and the critic iterations' generator forward on a "
+                                 "second stream under the previous iteration's critic kernels)" % args.steps,
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "m2d_gemm_kernel (separable-gather fp32 MFMA engine; conv1d fwd/bwd_data/bwd_weight + linear)",

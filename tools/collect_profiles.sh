@@ -14,12 +14,12 @@ python3 bench.py --config c5 --no-cpu-baseline --dump-shapes $O/${TAG}_shapes_c5
 python3 bench.py --gpus 2 --backend gloo --same-device --batch 16 --steps 8 --warmup 8 --no-cpu-baseline --no-prof > $O/${TAG}_bench_dp2_gloo_1gpu.json 2>> $O/${TAG}_bench_c3.err
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-prof"
-# serialised critic branches: a kernel's duration is then its own (as in bench.py's roofline pass)
-M2D_BRANCH_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 $ARGS > $O/${TAG}_prof.log 2>&1
+# one stream (no branch overlap, no generator pipelining): a kernel's duration is then its own, as in bench.py's roofline pass
+M2D_BRANCH_OVERLAP=0 M2D_GEN_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 $ARGS > $O/${TAG}_prof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_overlap -- python3 $ARGS > $O/${TAG}_prof_overlap.log 2>&1
 python3 $R/tools/gap_analysis.py $O/${TAG}_prof_overlap > $O/${TAG}_gaps.txt 2>&1
-M2D_BRANCH_OVERLAP=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $ARGS > /dev/null 2>&1
-M2D_BRANCH_OVERLAP=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python3 $ARGS > /dev/null 2>&1
+M2D_BRANCH_OVERLAP=0 M2D_GEN_PIPELINE=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $ARGS > /dev/null 2>&1
+M2D_BRANCH_OVERLAP=0 M2D_GEN_PIPELINE=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python3 $ARGS > /dev/null 2>&1
 cd $R
 find $O/${TAG}_prof $O/${TAG}_prof_overlap -name "*kernel_trace.csv" -delete
 python3 tools/pmc_summary.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write > $O/${TAG}_pmc_traffic.json
