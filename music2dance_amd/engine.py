@@ -245,9 +245,10 @@ class Phase3Engine(WganGpEngine):
     def enable_graphs(self, on=True):
         """Replay each loop body's forward / backward as one captured HIP graph (per input shape):
         ~680 kernel launches become one graph launch, which takes the host off the critical path.
-        (On the MI355X host the eager path is already GPU-bound down to batch 16 - measured 18.7 vs
-        18.7 ms per step at batch 64, 14.8 vs 14.9 at batch 16 - so this is off by default; it is
-        for slower hosts and smaller batches.)
+        (Measured on the MI355X host: batch 8, 8.5 ms per body eager -> 5.9 ms replayed; at batch 64 the eager
+        path is GPU-bound and, with the generator forward pipelined one iteration ahead, faster than
+        the single-queue replay - 15.0 vs 16.5 ms - so this is off by default: it is for small
+        batches and slow hosts.)
         The optimizer steps and the data-parallel gradient exchange stay eager. The random draws
         the reference makes inside the loop (generator noise, interpolation weights) are made on
         the host generator in the same order before each replay and fed through static buffers,

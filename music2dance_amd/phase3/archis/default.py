@@ -383,8 +383,8 @@ class SequenceDiscriminator(nn.Module):
 
     def _stick_code(self, x):
         dev = x.device
-        if dev.type != "cuda" or not self.overlap_branches or torch.cuda.is_current_stream_capturing():
-            return self.stick_d(x)
+        if dev.type != "cuda" or not self.overlap_branches:
+            return self.stick_d(x)  # (under graph capture the fork / join below is captured as such)
         if getattr(self, "_stick_stream", None) is None:
             self._stick_stream = torch.cuda.Stream(device=dev)
         side, cur = self._stick_stream, torch.cuda.current_stream(dev)

@@ -1,19 +1,6 @@
-B="python3 bench.py --no-cpu-baseline --no-prof --steps 96 --warmup 16"
-export M2D_STEP_TIMES=1
-summ() { python3 -c "
-import sys
-for l in sys.stdin:
-    if l.startswith('step ms'):
-        v=[float(x) for x in l.split()[2:]]
-        s=sorted(v); n=len(v)
-        print('n',n,'mean %.3f'%(sum(v)/n),'median %.2f'%s[n//2],' cycle:',' '.join('%.1f'%x for x in v[8:17]))
-"; }
-timeout 300 python -m pytest tests/test_gpu_full_size.py -x -q -k "pipelined or graph" 2>&1 | tail -3
-for r in 1 2 3; do
-  echo -n "A   : "; M2D_GEN_PIPELINE=1 $B 2>&1 >/dev/null | summ
-  echo -n "off : "; M2D_GEN_PIPELINE=0 $B 2>&1 >/dev/null | summ
-done
-for c in c4 c5; do
-  echo -n "$c A   : "; M2D_GEN_PIPELINE=1 $B --config $c 2>&1 >/dev/null | summ
-  echo -n "$c off : "; M2D_GEN_PIPELINE=0 $B --config $c 2>&1 >/dev/null | summ
+ms() { python3 -c "import sys,json; print(json.loads([l for l in sys.stdin if l.startswith('{')][-1])['ms_per_step'])"; }
+B="python3 bench.py --no-cpu-baseline --no-prof --steps 32 --warmup 16"
+M2D_CAPTURE_FORK=1 timeout 300 python -m pytest tests/test_gpu_full_size.py -x -q -k "graph" 2>&1 | tail -5
+for b in 8 64; do
+echo "batch$b eager: $($B --batch $b 2>/dev/null | ms)  graphs: $($B --batch $b --graphs on 2>/dev/null | ms)  graphs+fork: $(M2D_CAPTURE_FORK=1 $B --batch $b --graphs on 2>&1 | ms)"
 done
