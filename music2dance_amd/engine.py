@@ -164,6 +164,7 @@ class Phase3Engine(WganGpEngine):
         self.gamma, self.beta, self.eta = float(cfg["gamma"]), float(cfg["beta"]), float(cfg["eta"])
         self.output_size = int(cfg.get("output_size", 69))
         self.ablated = bool(ablated)
+        self.early_pair_pass = os.environ.get("M2D_EARLY_PAIR", "1") != "0"
 
     def _shapes(self, real):
         B = real.size(0)
@@ -201,6 +202,8 @@ class Phase3Engine(WganGpEngine):
             err_critic = err_fake - err_real + self.gamma * gp
             err_critic.backward()
         else:
+            if self.early_pair_pass:
+                self.critic.begin_pair(real_c, fake)  # pose branch of the real / fake pass: see begin_pair
             gp = gradient_penalty(self.critic, B, real_c, fake, audio_c, is_seq=True, lp=False,
                                   device=real.device, alpha=alpha)
             s_real, s_fake = self.critic.score_pair(real_c, fake, audio_c)

@@ -387,21 +387,21 @@ class SequenceDiscriminator(nn.Module):
             return self.stick_d(x)  # (under graph capture the fork / join below is captured as such)
         if getattr(self, "_stick_stream", None) is None:
             self._stick_stream = torch.cuda.Stream(device=dev)
+            self._joins = {}
         side, cur = self._stick_stream, torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             code = self.stick_d(x)
         x.record_stream(side)
-        self._join = (side, cur, code)
+        self._joins[id(code)] = (side, code)  # holds `code`, so the id stays unique until the join
         return code
 
     def _joined(self, code):
-        j = getattr(self, "_join", None)
-        if j is not None and j[2] is code:
-            side, cur, _ = j
-            cur.wait_stream(side)
+        j = self._joins.pop(id(code), None) if getattr(self, "_joins", None) else None
+        if j is not None:
+            cur = torch.cuda.current_stream(code.device)
+            cur.wait_stream(j[0])
             code.record_stream(cur)
-            self._join = None
         return code
 
     def forward(self, x, c):
@@ -410,12 +410,22 @@ class SequenceDiscriminator(nn.Module):
         code = torch.cat((self._joined(stick), acode), -1)
         return self.fc2(self.fc1(code, act=ops.ACT_RELU))
 
+    def begin_pair(self, x_a, x_b):
+        """Start the pose branch of a later score_pair(x_a, x_b, c) now. It needs the two pose batches and the
+        branch's weights only, so the training loop issues it BEFORE the gradient penalty: the side stream then
+        runs it underneath the penalty pass's audio-branch kernels instead of after them with the main stream idle."""
+        self._pair = (x_a, x_b, self._stick_code(torch.cat((x_a, x_b), 0)))
+
     def score_pair(self, x_a, x_b, c):
         """critic(x_a, c), critic(x_b, c) from ONE pass over the concatenated poses (the critic
         has no cross-sample coupling, so the scores are the per-call ones; twice the columns
         per launch fill the chip better) and one evaluation of the audio branch."""
         n = x_a.size(0)
-        stick = self._stick_code(torch.cat((x_a, x_b), 0))
+        pre, self._pair = getattr(self, "_pair", None), None
+        if pre is not None and pre[0] is x_a and pre[1] is x_b:
+            stick = pre[2]
+        else:
+            stick = self._stick_code(torch.cat((x_a, x_b), 0))
         acode = self._audio_code(c)
         stick = self._joined(stick)
         code = torch.cat((stick, torch.cat((acode, acode), 0)), -1)
