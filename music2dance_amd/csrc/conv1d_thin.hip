@@ -87,11 +87,13 @@ __global__ void __launch_bounds__(256) thin_bwd_data_kernel(const ThinArgs a) {
 // global memory (lanes 0-31 read 32 consecutive samples). HBM-bound: dy (+ mask) is read once.
 typedef float thin_f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KS, int S>
+template <int KS, int S, bool MASKED>
 __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArgs a) {
-  constexpr int LD = 65;  // [co][l] image, odd stride: fragment reads (lanes along co) are conflict-free
-  __shared__ float tile[4][32 * LD];
-  __shared__ float red[4][32 * 32];
+  constexpr int LD = 65;             // [co][l] image, odd stride: fragment reads (lanes along co) are conflict-free
+  constexpr int XW = 64 * S + 32;    // x window of one 64-position tile: positions S*lt - pad + [0, XW)
+  constexpr int DEPTH = MASKED ? 1 : 2;  // dy tiles in flight per wave beyond the one being multiplied (the loop is
+                                         // latency-bound: one 8 KB tile in flight per wave reached 1.9 TB/s)
+  __shared__ float smem[4][32 * LD + XW];  // wave-private; reused for the cross-wave reduction at the end
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.y;
   const int l0 = blockIdx.x * a.chunk;
@@ -99,34 +101,39 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
   if (l1 > a.Lout) l1 = a.Lout;
   const float* xr = a.xT > 0 ? a.x + (size_t)(n / a.xT) * a.xS + (size_t)(n % a.xT) * a.xhop : a.x + (size_t)n * a.L;
   const float* dyn = a.dy + (size_t)n * 32 * a.Lout;
-  const float* mkn = a.mask ? a.mask + (size_t)n * 32 * a.Lout : nullptr;
-  float* tl = tile[wave];
+  const float* mkn = (MASKED && a.mask) ? a.mask + (size_t)n * 32 * a.Lout : nullptr;
+  float* tl = smem[wave];
+  float* xw = tl + 32 * LD;
   thin_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int i31 = lane & 31, h = lane >> 5;
   const int lq = 4 * (lane & 15);
-  const bool vec = (a.Lout % 4) == 0, vec2 = (a.Lout % 2) == 0;
-  float4 dv[8], mv[8];
-  // fetch(lt): this lane's 8 x float4 of the dy tile (and mask) starting at position lt
-  auto fetch = [&](int lt) {
+  const bool vec = (a.Lout % 4) == 0, vec2 = (a.Lout % 2) == 0 && (l0 & 1) == 0;
+  float4 dv[DEPTH][8], mv[MASKED ? 8 : 1];
+  float xs[DEPTH][(XW + 63) / 64];
+  // fetch(d, lt): this lane's 8 x float4 of the dy tile starting at position lt (and its mask), and its share of the
+  // tile's x window; positions past the chunk / outside the sample read as zero
+  auto fetch = [&](float4 (&d4)[8], float (&xq)[(XW + 63) / 64], int lt) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int co = (lane >> 4) + 4 * i;
       const size_t g = (size_t)co * a.Lout + lt + lq;
       if (vec && lt + lq + 3 < l1) {
-        dv[i] = *reinterpret_cast<const float4*>(dyn + g);
-        mv[i] = mkn ? *reinterpret_cast<const float4*>(mkn + g) : make_float4(1.f, 1.f, 1.f, 1.f);
-      } else if (vec2 && lt + lq + 3 < l1 && ((l0 & 1) == 0)) {
+        d4[i] = *reinterpret_cast<const float4*>(dyn + g);
+        if (MASKED) mv[i] = mkn ? *reinterpret_cast<const float4*>(mkn + g) : make_float4(1.f, 1.f, 1.f, 1.f);
+      } else if (vec2 && lt + lq + 3 < l1) {
         const float2 d0 = *reinterpret_cast<const float2*>(dyn + g);
         const float2 d1 = *reinterpret_cast<const float2*>(dyn + g + 2);
-        dv[i] = make_float4(d0.x, d0.y, d1.x, d1.y);
-        if (mkn) {
-          const float2 m0 = *reinterpret_cast<const float2*>(mkn + g);
-          const float2 m1 = *reinterpret_cast<const float2*>(mkn + g + 2);
-          mv[i] = make_float4(m0.x, m0.y, m1.x, m1.y);
-        } else {
-          mv[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        d4[i] = make_float4(d0.x, d0.y, d1.x, d1.y);
+        if (MASKED) {
+          if (mkn) {
+            const float2 m0 = *reinterpret_cast<const float2*>(mkn + g);
+            const float2 m1 = *reinterpret_cast<const float2*>(mkn + g + 2);
+            mv[i] = make_float4(m0.x, m0.y, m1.x, m1.y);
+          } else {
+            mv[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+          }
         }
       } else {
         float d[4], m[4];
@@ -134,82 +141,104 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
         for (int j = 0; j < 4; ++j) {
           const bool ok = lt + lq + j < l1;
           d[j] = ok ? dyn[g + j] : 0.f;
-          m[j] = (ok && mkn) ? mkn[g + j] : 1.f;
+          m[j] = (MASKED && ok && mkn) ? mkn[g + j] : 1.f;
         }
-        dv[i] = make_float4(d[0], d[1], d[2], d[3]);
-        mv[i] = make_float4(m[0], m[1], m[2], m[3]);
+        d4[i] = make_float4(d[0], d[1], d[2], d[3]);
+        if (MASKED) mv[i] = make_float4(m[0], m[1], m[2], m[3]);
       }
     }
+#pragma unroll
+    for (int i = 0; i < (XW + 63) / 64; ++i) {
+      const int e = lane + 64 * i;
+      const int pos = lt * S - a.pad + e;
+      xq[i] = (e < XW && lt < l1 && pos >= 0 && pos < a.L) ? xr[pos] : 0.f;
+    }
   };
-  int lt = l0 + wave * 64;
-  if (lt < l1) fetch(lt);
-  for (; lt < l1; lt += 256) {
-    // land the prefetched tile in the wave-private LDS image (mask applied here)
+  const int lt0 = l0 + wave * 64;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (lt0 + 256 * d < l1) fetch(dv[d], xs[d], lt0 + 256 * d);
+  for (int lt = lt0; lt < l1; lt += 256) {
+    // land the oldest prefetched tile in the wave-private LDS image (mask applied here)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int co = (lane >> 4) + 4 * i;
       const float ms = a.mask_slope;
-      tl[co * LD + lq + 0] = dv[i].x * (mv[i].x > 0.f ? 1.f : ms);
-      tl[co * LD + lq + 1] = dv[i].y * (mv[i].y > 0.f ? 1.f : ms);
-      tl[co * LD + lq + 2] = dv[i].z * (mv[i].z > 0.f ? 1.f : ms);
-      tl[co * LD + lq + 3] = dv[i].w * (mv[i].w > 0.f ? 1.f : ms);
+      tl[co * LD + lq + 0] = dv[0][i].x * ((!MASKED || mv[i].x > 0.f) ? 1.f : ms);
+      tl[co * LD + lq + 1] = dv[0][i].y * ((!MASKED || mv[i].y > 0.f) ? 1.f : ms);
+      tl[co * LD + lq + 2] = dv[0][i].z * ((!MASKED || mv[i].z > 0.f) ? 1.f : ms);
+      tl[co * LD + lq + 3] = dv[0][i].w * ((!MASKED || mv[i].w > 0.f) ? 1.f : ms);
     }
+#pragma unroll
+    for (int i = 0; i < (XW + 63) / 64; ++i)
+      if (lane + 64 * i < XW) xw[lane + 64 * i] = xs[0][i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lt + 256 < l1) fetch(lt + 256);  // next tile's loads fly under this tile's MFMAs
-    float av[32];
+    // keep DEPTH tiles in flight under this tile's MFMAs
+    if (DEPTH == 2) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int l = lt + 2 * j + h;
-      const int pos = l * S - a.pad + i31;
-      av[j] = (i31 < KS && l < l1 && pos >= 0 && pos < a.L) ? xr[pos] : 0.f;  // A[kk = i31][k = h]
-      if (KS < 32 && i31 == 31) av[j] = l < l1 ? 1.f : 0.f;  // spare row 31 = ones: C[31][co] = sum_l dy (bias gradient)
+      for (int i = 0; i < 8; ++i) dv[0][i] = dv[DEPTH - 1][i];
+#pragma unroll
+      for (int i = 0; i < (XW + 63) / 64; ++i) xs[0][i] = xs[DEPTH - 1][i];
     }
-#pragma unroll
+    if (lt + 256 * DEPTH < l1) fetch(dv[DEPTH - 1], xs[DEPTH - 1], lt + 256 * DEPTH);
+    // A[kk = i31][k = h] = x[S * l - pad + kk], l = lt + 2 j + h: window element S * (2 j + h) + kk. Rows KS..30 hold
+    // neighbouring samples (their outputs are never read); the spare row 31 = ones: C[31][co] = sum_l dy (bias gradient).
+    // dy past the chunk was staged as zero, so no position test is needed here.
+    const float* xa = xw + S * h + i31;
+    const float* bb = tl + i31 * LD + h;
+#pragma unroll 8
     for (int j = 0; j < 32; ++j) {
-      const float bv = tl[i31 * LD + 2 * j + h];  // B[k = h][co = i31]
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv, acc, 0, 0, 0);
+      float av = xa[2 * S * j];
+      if (KS < 32) av = i31 == 31 ? 1.f : av;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[2 * j], acc, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
   }
   // C[i = kk][j = co]: col = lane & 31 (co), row = (r & 3) + 8 * (r >> 2) + 4 * h (kk)
+  __syncthreads();
+  float* red = &smem[0][0];  // [4][32 * 32] fits: 4 * (32 * LD + XW) floats
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i31] = acc[r];
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i31] = acc[r];
   __syncthreads();
   const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   for (int o = threadIdx.x; o < 32 * KS; o += 256) {
     const int co = o / KS, kk = o % KS;
     const int idx = kk * 32 + co;
-    a.out[blk * 32 * KS + o] = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+    a.out[blk * 32 * KS + o] = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx];
   }
   if (a.out2 && threadIdx.x < 32) {
     const int idx = 31 * 32 + threadIdx.x;
-    a.out2[blk * 32 + threadIdx.x] = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+    a.out2[blk * 32 + threadIdx.x] = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx];
   }
 }
 
-// dw[o] = sum over the nblk partial slabs, fixed order: 16 groups of slabs per output (group g takes
-// slabs g, g + 16, ...) summed in fp64, then combined in group order. One chain over all slabs per
-// thread was latency-bound (77 us for 320 slabs of 800 outputs).
-__global__ void __launch_bounds__(1024) thin_sum_partials_kernel(const float* partial, float* dw, int nblk, int n_out,
-                                                                   const float* partial2, float* out2, int n_out2) {
-  __shared__ double part[16][64];
-  const int ox = threadIdx.x & 63, g = threadIdx.x >> 6;
-  if (partial2 && blockIdx.x == gridDim.x - 1) {  // the extra block sums the bias partials the same way
+// dw[o] = sum over the nblk partial slabs, fixed order: 32 groups of slabs per output (group g takes
+// slabs g, g + 32, ...) summed in fp64, then combined in group order. A block owns 8 outputs, so a
+// 32 x 25 weight gradient is summed by 100 blocks (one chain over all slabs per thread was latency-bound:
+// 77 us for 320 slabs; 13 blocks of 16 groups: 24 us for 1 216 slabs).
+__global__ void __launch_bounds__(256) thin_sum_partials_kernel(const float* partial, float* dw, int nblk, int n_out,
+                                                                  const float* partial2, float* out2, int n_out2) {
+  __shared__ double part[32][8];
+  const int ox = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int nb1 = (n_out + 7) / 8;
+  int blk = blockIdx.x;
+  if (blk >= nb1) {  // the trailing blocks sum the bias partials the same way
+    blk -= nb1;
     partial = partial2;
     dw = out2;
     n_out = n_out2;
   }
-  const int o = (partial == partial2 && partial2 ? 0 : blockIdx.x * 64) + ox;
+  const int o = blk * 8 + ox;
   double s = 0.0;
   if (o < n_out)
-    for (int b = g; b < nblk; b += 16) s += (double)partial[(size_t)b * n_out + o];
+    for (int b = g; b < nblk; b += 32) s += (double)partial[(size_t)b * n_out + o];
   part[g][ox] = s;
   __syncthreads();
   if (g == 0 && o < n_out) {
     double t = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) t += part[j][ox];
+    for (int j = 0; j < 32; ++j) t += part[j][ox];
     dw[o] = (float)t;
   }
 }
@@ -221,10 +250,19 @@ static bool thin_ok(int Cin, int Cout, int ks, int stride) {
 
 bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride) { return thin_ok(Cin, Cout, ks, stride); }
 
-static const int THIN_BW_CHUNK = 1024;
+// backward-weight: positions per block. About two blocks per CU of work (512 blocks: measured best at
+// B = 64, Lout = 19 200: 52 us at 2 560 positions against 65 us at 1 024 and 54 us at 4 864), whole 256-position
+// rounds of the block's four waves.
+static int thin_bw_chunk(int B, int Lout) {
+  const long long per = ((long long)B * Lout + 511) / 512;
+  long long c = (per + 255) / 256 * 256;
+  if (c < 1024) c = 1024;
+  if (c > 8192) c = 8192;
+  return (int)c;
+}
 
 size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout) {
-  const size_t nblk = (size_t)B * m2d_ceil_div(Lout, THIN_BW_CHUNK);
+  const size_t nblk = (size_t)B * m2d_ceil_div(Lout, thin_bw_chunk(B, Lout));
   return nblk * (Cout * ks + Cout) * sizeof(float);  // weight partials + bias partials
 }
 
@@ -410,16 +448,19 @@ int m2d_thin_bwd_weight(const float* x, const float* dy, float* dw, float* dbias
   a.x = x; a.dy = dy; a.mask = dy_mask; a.out = (float*)ws;
   a.B = B; a.L = L; a.Cout = Cout; a.ks = ks; a.stride = stride; a.pad = pad; a.Lout = Lout;
   a.mask_slope = dy_mask_slope;
-  a.chunk = THIN_BW_CHUNK;
-  const int nchunk = m2d_ceil_div(Lout, THIN_BW_CHUNK);
+  a.chunk = thin_bw_chunk(B, Lout);
+  const int nchunk = m2d_ceil_div(Lout, a.chunk);
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (dy_mask ? 2 : 1)), "thin_conv_bwd_weight", Cout, ks, B * Lout);
   // bias partials (row 31 of the MFMA tile = ones) sit behind the weight partials in the workspace
   const size_t nblk = (size_t)nchunk * B;
   a.out2 = dbias ? (float*)ws + nblk * Cout * ks : nullptr;
-  hipLaunchKernelGGL((thin_bwd_weight_mfma_kernel<25, 4>), dim3(nchunk, B), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(thin_sum_partials_kernel, dim3(m2d_ceil_div(Cout * ks, 64) + (dbias ? 1 : 0)), dim3(1024), 0,
-                     stream, (const float*)ws, dw, nchunk * B, Cout * ks, (const float*)a.out2, dbias, Cout);
+  if (dy_mask)
+    hipLaunchKernelGGL((thin_bwd_weight_mfma_kernel<25, 4, true>), dim3(nchunk, B), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((thin_bwd_weight_mfma_kernel<25, 4, false>), dim3(nchunk, B), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(thin_sum_partials_kernel, dim3(m2d_ceil_div(Cout * ks, 8) + (dbias ? m2d_ceil_div(Cout, 8) : 0)),
+                     dim3(256), 0, stream, (const float*)ws, dw, nchunk * B, Cout * ks, (const float*)a.out2, dbias, Cout);
   M2D_CHECK_LAUNCH("thin_bwd_weight_mfma_kernel");
   return M2D_OK;
 }

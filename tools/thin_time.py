@@ -17,10 +17,12 @@ for _ in range(5):
     K.conv1d_fwd(x, w, None, 4, 11, out_mask=mask, out_mask_slope=0.0)
     K.conv1d_bwd_data(dy, w, 76800, 4, 11, dy_mask=mask)
     K.conv1d_bwd_weight(x, dy, 25, 4, 11, dy_mask=mask)
+    K.conv1d_bwd_weight(x, dy, 25, 4, 11, with_bias=True)
+    K.conv1d_bwd_data(dy, w, 76800, 4, 11)
 torch.cuda.synchronize()
 rows = K.prof_dump(); K.prof_end()
 import collections
 agg = collections.OrderedDict()
-for fam, tag, d0, d1, d2, ms, fl in rows:
-    a = agg.setdefault(tag, []); a.append(ms)
-for k, v in agg.items(): print("%-24s n=%d min %.1f us  median %.1f us" % (k, len(v), 1e3 * min(v), 1e3 * sorted(v)[len(v) // 2]))
+for fam, tag, d0, d1, d2, ms, fl, by in rows:
+    a = agg.setdefault((tag, int(by / 1e6)), []); a.append(ms)
+for k, v in agg.items(): print("%-24s %4d MB n=%d min %.1f us  median %.1f us" % (k[0], k[1], len(v), 1e3 * min(v), 1e3 * sorted(v)[len(v) // 2]))
