@@ -211,7 +211,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)  # before anything touches the GPU
 
-    from music2dance_amd import dp, kernels
+    from music2dance_amd import dp, kernels, runner
     from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
 
     rank, world, local = dp.init_from_env(args.backend)
@@ -247,6 +247,9 @@ def main():
     for _ in range(args.warmup):
         engine.train_step(real, audio, slices, inputs_ready=ready)
     engine.flush()
+    # host hygiene, as the train scripts do after building their engine: a generation-2 garbage collection over
+    # the module graph stalls the launch thread for 60-80 ms (tools/spike_probe.py)
+    runner.settle_garbage_collector()
     K = kernels.impl()
     barrier()
     step_events = [] if os.environ.get("M2D_STEP_TIMES") else None  # dev aid: per-step GPU time to stderr

@@ -54,6 +54,11 @@ class WganGpEngine:
             kw["fused"] = True
         self.optim_critic = optim.Adam(critic.parameters(), lr=lr_critic, **kw)
         self.optim_gen = optim.Adam(gen.parameters(), lr=lr_gen, **kw)
+        # an optimizer step only invalidates the packed conv-weight images of ITS parameters (the generator's
+        # stay valid through the critic iterations of a cycle)
+        self._keep_packs = os.environ.get("M2D_KEEP_PACKS", "1") != "0"
+        self._critic_params = [p for p in critic.parameters() if p.dim() == 3] if self._keep_packs else None
+        self._gen_params = [p for p in gen.parameters() if p.dim() == 3] if self._keep_packs else None
         self.total_iterations = 0
         self.x_critic = GradExchange(critic.parameters()) if data_parallel else None
         self.x_gen = GradExchange(gen.parameters()) if data_parallel else None
@@ -74,7 +79,7 @@ class WganGpEngine:
             if self.x_critic is not None:
                 self.x_critic.finish()
             self.optim_critic.step()
-            kernels.impl().invalidate_packed()
+            kernels.impl().invalidate_packed(self._critic_params)
             self._critic_step_pending = False
 
     def _begin_critic_step(self):
@@ -83,13 +88,13 @@ class WganGpEngine:
             self._critic_step_pending = True
         else:
             self.optim_critic.step()
-            kernels.impl().invalidate_packed()
+            kernels.impl().invalidate_packed(self._critic_params)
 
     def _gen_step(self):
         if self.x_gen is not None:
             self.x_gen.exchange()
         self.optim_gen.step()
-        kernels.impl().invalidate_packed()
+        kernels.impl().invalidate_packed(self._gen_params)
         if self._gen_stream is not None:
             self._gen_params_ready = torch.cuda.current_stream().record_event()
 
@@ -146,7 +151,7 @@ class WganGpEngine:
         self.total_iterations += 1
         self._inputs_ready = inputs_ready
         # weights only change in the optimizer steps, which drop the packed conv-weight images
-        with kernels.impl().weight_cache():
+        with kernels.impl().weight_cache(keep=self._keep_packs):
             out = self.critic_iteration(*batch)
             if self.total_iterations % self.n_critic_steps == 0:
                 out.update(self.generator_iteration(*batch))

@@ -113,22 +113,31 @@ class HipKernels:
         self.pack_launches = 0
 
     @contextlib.contextmanager
-    def weight_cache(self):
+    def weight_cache(self, keep=False):
         """Scope in which conv weights are promised constant except where invalidate_packed() is
         called (right after an optimizer step): the packed images the forward / backward-data
         GEMMs read are built once per weight tensor instead of once per call. Outside a scope every
         call packs afresh - a tensor's version counter is no proof of constancy (fused optimizers
-        update parameters without moving it)."""
+        update parameters without moving it).
+        keep: leave the images in place when the scope closes, for the next scope of the same owner (the
+        training engine: the generator's weights do not change during the critic iterations of a cycle).
+        The owner then vouches that between its scopes parameters only change through operations that move
+        the version counter (copy_, load_state_dict, in-place math) or are announced with invalidate_packed()."""
         self._cache_depth += 1
         try:
             yield self
         finally:
             self._cache_depth -= 1
-            if self._cache_depth == 0:
+            if self._cache_depth == 0 and not keep:
                 self._packed.clear()
 
-    def invalidate_packed(self):
-        self._packed.clear()
+    def invalidate_packed(self, tensors=None):
+        """Drop the packed images of `tensors` (the parameters an optimizer step just changed), or all of them."""
+        if tensors is None:
+            self._packed.clear()
+        else:
+            for w in tensors:
+                self._packed.pop(id(w), None)
 
     def packed_weights(self, w):
         """(w_fwd (Cout, ks, Cin), w_bwd (Cin, ks, Cout)) of a conv weight (written on the current stream)."""

@@ -48,6 +48,7 @@ def main(argv=None):
     log = runner.ScalarLog(logdir, opts.log_every)
     B = cfg["batch_size"]
     batches_per_epoch = max(cfg["num_train"] // B, 1)
+    runner.settle_garbage_collector()
     print("Start training..")
     done = False
     for epoch in range(cfg["num_epochs"]):

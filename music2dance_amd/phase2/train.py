@@ -51,6 +51,7 @@ def main(argv=None):
     log = runner.ScalarLog(logdir, opts.log_every)
     runner.dump_architectures(logdir, gen, critic)
     batches_per_epoch = max(cfg["num_train"] // cfg["batch_size"], 1)
+    runner.settle_garbage_collector()
     print("Start training..")
     done = False
     for epoch in range(cfg["num_epochs"]):

@@ -77,6 +77,7 @@ def main(argv=None):
                                                      window_s=cfg["window_size"])
             yield real, slices
 
+    runner.settle_garbage_collector()
     print("Start training..")
     done = False
     e_val_loss = float("nan")

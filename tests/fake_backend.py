@@ -29,10 +29,10 @@ class FakeKernels:
     name = "fake-cpu"
 
     @contextlib.contextmanager
-    def weight_cache(self):
+    def weight_cache(self, keep=False):
         yield self
 
-    def invalidate_packed(self):
+    def invalidate_packed(self, tensors=None):
         pass
 
     def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
