@@ -2,14 +2,13 @@
 // (AudioDiscriminator.l1, phase3/archis/default.py:298, and WaveGAN l1, :117:
 // Conv1d(1, 32, 25, stride=4)). With Cin = 1 the contraction length is only k = 25, the
 // arithmetic intensity is ~11 flop/B and the op is HBM-bound: the 157 MB
-// activation / gradient tensor must be streamed once, everything else fits in cache. A
-// 32x32 MFMA tile would be >80 % padding here, so these use the vector ALU:
-//   forward        : thread = one output position l, all Cout channels from ONE window
-//   backward-data  : thread = one q, the `stride` outputs j = s*q + r - pad of that q
-//   backward-weight: thread = one l per step, 4 channels x k taps of register partials,
-//                    block-reduced, deterministic two-stage sum (no atomics)
-// Weights sit in LDS and are read as broadcasts. Masks (activation derivative) follow the
-// convention of gemm_engine.h: value *= (mask > 0 ? 1 : slope).
+// activation / gradient tensor must be streamed once, everything else fits in cache. The
+// GEMM engine's 128-wide tiles would be >80 % padding here; all three directions run on
+// v_mfma_f32_32x32x2_f32 with the 32 channels as one tile dimension:
+//   forward        : C[channel][position], K = taps, x windows gathered per lane, LDS transpose for 16-byte stores
+//   backward-data  : Z[tap][position] = W^T dy (K = channels), then the overlap-add of the taps
+//   backward-weight: C[tap][channel], K = positions (deterministic two-stage sum of per-block slabs, no atomics)
+// Masks (activation derivative) follow the convention of gemm_engine.h: value *= (mask > 0 ? 1 : slope).
 #include "m2d_common.h"
 
 #define THIN_MAX_K 32
@@ -29,55 +28,6 @@ struct ThinArgs {
   float slope, mask_slope;
   int chunk;           // bwd_weight: positions per block
 };
-
-// dx[n, s*q + r - pad] = sum_co sum_t W[co, r + s*t] * dy[n, co, q - t]; thread = P consecutive q
-template <int KS, int S, int P>
-__global__ void __launch_bounds__(256) thin_bwd_data_kernel(const ThinArgs a) {
-  const float* __restrict__ wl = a.w;  // wave-uniform indices -> scalar loads (a broadcast through the scalar cache)
-  constexpr int T = (KS + S - 1) / S;
-  constexpr int DW = T + P - 1;  // dy window: l in [q0 - (T-1), q0 + P - 1]
-  const int n = blockIdx.y;
-  const int q0 = (blockIdx.x * 256 + threadIdx.x) * P;
-  const int nq = (a.L - 1 + a.pad) / S + 1;
-  if (q0 >= nq) return;
-  float acc[P][S];
-#pragma unroll
-  for (int j = 0; j < P; ++j)
-#pragma unroll
-    for (int r = 0; r < S; ++r) acc[j][r] = 0.f;
-  const float* dyn = a.dy + (size_t)n * a.Cout * a.Lout;
-  const float* mkn = a.mask ? a.mask + (size_t)n * a.Cout * a.Lout : nullptr;
-  for (int co = 0; co < a.Cout; ++co) {
-    float v[DW];
-#pragma unroll
-    for (int i = 0; i < DW; ++i) {
-      const int l = q0 - (T - 1) + i;
-      float d = 0.f;
-      if (l >= 0 && l < a.Lout) {
-        d = dyn[(size_t)co * a.Lout + l];
-        if (mkn) d *= (mkn[(size_t)co * a.Lout + l] > 0.f ? 1.f : a.mask_slope);
-      }
-      v[i] = d;
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int r = 0; r < S; ++r)
-        if (r + S * t < KS) {
-          const float wv = wl[co * KS + r + S * t];
-#pragma unroll
-          for (int j = 0; j < P; ++j) acc[j][r] += wv * v[(T - 1) + j - t];  // l = q0 + j - t
-        }
-  }
-  float* dxn = a.out + (size_t)n * a.L;
-#pragma unroll
-  for (int j = 0; j < P; ++j)
-#pragma unroll
-    for (int r = 0; r < S; ++r) {
-      const int jj = S * (q0 + j) + r - a.pad;
-      if (jj >= 0 && jj < a.L) dxn[jj] = acc[j][r];
-    }
-}
 
 // Backward-weight on the matrix pipe for Cout == 32: dW^T[kk, co] = sum_l x[n, s*l - pad + kk] * dy[n, co, l]
 // is a 32 x 32 (25 valid rows) tile accumulated over a very long K = l, i.e. one
@@ -210,6 +160,172 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
   if (a.out2 && threadIdx.x < 32) {
     const int idx = 31 * 32 + threadIdx.x;
     a.out2[blk * 32 + threadIdx.x] = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx];
+  }
+}
+
+// Backward-data on the matrix pipe (KS = 25, S = 4, Cout = 32): per position l the 32 x 25 product
+//   Z[l][kk] = sum_co dy[n, co, l] * W[co, kk]                  (one 32x32 MFMA tile per 32 positions, K = co)
+// followed by the overlap-add  dx[n, S*q + rho - pad] = sum_t Z[q - t][rho + S*t]  (rho + S*t < KS).
+// A wave walks a run of positions in 64-wide tiles: the dy tile goes through a wave-private LDS image (coalesced
+// 16-byte loads, mask applied on the way in, one or two tiles in flight as in backward-weight), Z comes back
+// through the same image as [position][tap] rows (stride 33: lanes along positions are conflict-free), each lane
+// sums the <= 7 x 4 taps of its q and the 256 outputs of the tile leave as four coalesced dword stores. The six Z rows
+// a tile needs from its predecessor travel in three registers per lane; a run starts with one 32-position tile for them.
+template <int KS, int S, bool MASKED>
+__global__ void __launch_bounds__(256) thin_bwd_data_mfma_kernel(const ThinArgs a) {
+  constexpr int LD = 65;   // dy image [co][64 positions]
+  constexpr int ZLD = 33;  // Z image [6 + 64 positions][32 taps]
+  constexpr int T = (KS + S - 1) / S;  // 7
+  constexpr int HALO = T - 1;          // 6
+  constexpr int DEPTH = MASKED ? 1 : 2;
+  __shared__ float smem[4][(64 + HALO) * ZLD];  // >= 32 * LD
+  static_assert((64 + HALO) * ZLD >= 32 * LD, "image size");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const int nq = (a.L - 1 + a.pad) / S + 1;  // q in [0, nq)
+  const int run = a.chunk / 4;               // positions per wave (multiple of 64)
+  const int qa = blockIdx.x * a.chunk + wave * run;
+  int qb = qa + run;
+  if (qb > nq) qb = nq;
+  if (qa >= nq) return;
+  const float* dyn = a.dy + (size_t)n * 32 * a.Lout;
+  const float* mkn = (MASKED && a.mask) ? a.mask + (size_t)n * 32 * a.Lout : nullptr;
+  float* dxn = a.out + (size_t)n * a.L;
+  float* buf = smem[wave];
+  float wa[16];  // A[row = kk][k = co]: W[co][kk], co = 2 s + h
+#pragma unroll
+  for (int s2 = 0; s2 < 16; ++s2) wa[s2] = l31 < KS ? a.w[(2 * s2 + h) * KS + l31] : 0.f;
+  const int lq = 4 * (lane & 15);
+  const bool vec = (a.Lout % 4) == 0, vec2 = (a.Lout % 2) == 0;
+  float4 dv[DEPTH][8], mv[MASKED ? 8 : 1];
+  // this lane's 8 x float4 of the dy tile [32 co][64 positions from lt]; positions outside [0, Lout) read as zero
+  auto fetch = [&](float4 (&d4)[8], int lt) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int co = (lane >> 4) + 4 * i;
+      const int l = lt + lq;
+      const size_t g = (size_t)co * a.Lout + l;
+      if (vec && l >= 0 && l + 3 < a.Lout) {
+        d4[i] = *reinterpret_cast<const float4*>(dyn + g);
+        if (MASKED) mv[i] = mkn ? *reinterpret_cast<const float4*>(mkn + g) : make_float4(1.f, 1.f, 1.f, 1.f);
+      } else if (vec2 && l >= 0 && l + 3 < a.Lout) {
+        const float2 d0 = *reinterpret_cast<const float2*>(dyn + g);
+        const float2 d1 = *reinterpret_cast<const float2*>(dyn + g + 2);
+        d4[i] = make_float4(d0.x, d0.y, d1.x, d1.y);
+        if (MASKED) {
+          if (mkn) {
+            const float2 m0 = *reinterpret_cast<const float2*>(mkn + g);
+            const float2 m1 = *reinterpret_cast<const float2*>(mkn + g + 2);
+            mv[i] = make_float4(m0.x, m0.y, m1.x, m1.y);
+          } else {
+            mv[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+          }
+        }
+      } else {
+        float d[4], m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = l + j >= 0 && l + j < a.Lout;
+          d[j] = ok ? dyn[(ptrdiff_t)g + j] : 0.f;
+          m[j] = (MASKED && ok && mkn) ? mkn[(ptrdiff_t)g + j] : 1.f;
+        }
+        d4[i] = make_float4(d[0], d[1], d[2], d[3]);
+        if (MASKED) mv[i] = make_float4(m[0], m[1], m[2], m[3]);
+      }
+    }
+  };
+  // registers -> dy image (mask applied)
+  auto land = [&](const float4 (&d4)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int co = (lane >> 4) + 4 * i;
+      const float ms = a.mask_slope;
+      buf[co * LD + lq + 0] = d4[i].x * ((!MASKED || mv[i].x > 0.f) ? 1.f : ms);
+      buf[co * LD + lq + 1] = d4[i].y * ((!MASKED || mv[i].y > 0.f) ? 1.f : ms);
+      buf[co * LD + lq + 2] = d4[i].z * ((!MASKED || mv[i].z > 0.f) ? 1.f : ms);
+      buf[co * LD + lq + 3] = d4[i].w * ((!MASKED || mv[i].w > 0.f) ? 1.f : ms);
+    }
+  };
+  auto sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // Z tile of 32 positions starting at image column c0: D[row = kk][col = position]
+  auto zmma = [&](int c0) {
+    thin_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s2], buf[(2 * s2 + h) * LD + c0 + l31], acc, 0, 0, 0);
+    return acc;
+  };
+  // carry: Z rows of the HALO positions before the tile, element e = lane + 64 k -> (row e / 32, tap e % 32)
+  float carry[3] = {0.f, 0.f, 0.f};
+  if (qa > 0) {
+    // positions [qa - 32, qa): only the last HALO columns are kept
+    fetch(dv[0], qa - 64);  // the 64-wide fetch ending at qa; columns 32..63 are the ones multiplied
+    land(dv[0]);
+    sync();
+    const thin_f32x16 z = zmma(32);
+    sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (l31 >= 32 - HALO) buf[(l31 - (32 - HALO)) * ZLD + (r & 3) + 8 * (r >> 2) + 4 * h] = z[r];
+    sync();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) carry[k] = buf[((lane + 64 * k) >> 5) * ZLD + ((lane + 64 * k) & 31)];
+    sync();
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (qa + 64 * d < qb) fetch(dv[d], qa + 64 * d);
+  for (int l0 = qa; l0 < qb; l0 += 64) {
+    land(dv[0]);
+    sync();
+    if (DEPTH == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dv[0][i] = dv[1][i];
+    }
+    if (l0 + 64 * DEPTH < qb) fetch(dv[DEPTH - 1], l0 + 64 * DEPTH);
+    const thin_f32x16 z0 = zmma(0), z1 = zmma(32);
+    sync();
+    // Z image: rows 0..HALO-1 from the carry, rows HALO.. = this tile's 64 positions
+#pragma unroll
+    for (int k = 0; k < 3; ++k) buf[((lane + 64 * k) >> 5) * ZLD + ((lane + 64 * k) & 31)] = carry[k];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = (r & 3) + 8 * (r >> 2) + 4 * h;
+      buf[(HALO + l31) * ZLD + kk] = z0[r];
+      buf[(HALO + 32 + l31) * ZLD + kk] = z1[r];
+    }
+    sync();
+    // lane = q - l0: dx[S q + rho - pad] = sum_t Z[q - t][rho + S t]
+    float o[S];
+#pragma unroll
+    for (int rho = 0; rho < S; ++rho) {
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (rho + S * t < KS) acc += buf[(HALO + lane - t) * ZLD + rho + S * t];
+      o[rho] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) carry[k] = buf[(64 + ((lane + 64 * k) >> 5)) * ZLD + ((lane + 64 * k) & 31)];
+    sync();
+#pragma unroll
+    for (int rho = 0; rho < S; ++rho) buf[S * lane + rho] = o[rho];
+    sync();
+    const int j0 = S * l0 - a.pad;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      const int e = lane + 64 * k;  // output S * (l0 + e / S) + e % S - pad, q = l0 + e / S < qb
+      const int j = j0 + e;
+      if (j >= 0 && j < a.L && l0 + e / S < qb) dxn[j] = buf[e];
+    }
+    sync();
   }
 }
 
@@ -432,8 +548,11 @@ int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, 
   const int nq = (L - 1 + pad) / stride + 1;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (dy_mask ? 2 : 1)), "thin_conv_bwd_data", 1, B * L, Cout * ks);
-  hipLaunchKernelGGL((thin_bwd_data_kernel<25, 4, 4>), dim3(m2d_ceil_div(nq, 1024), B), dim3(256), 0, stream, a);
-  M2D_CHECK_LAUNCH("thin_bwd_data_kernel");
+  a.chunk = thin_bw_chunk(B, nq);
+  const dim3 grid(m2d_ceil_div(nq, a.chunk), B);
+  if (dy_mask) hipLaunchKernelGGL((thin_bwd_data_mfma_kernel<25, 4, true>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((thin_bwd_data_mfma_kernel<25, 4, false>), grid, dim3(256), 0, stream, a);
+  M2D_CHECK_LAUNCH("thin_bwd_data_mfma_kernel");
   return M2D_OK;
 }
 
