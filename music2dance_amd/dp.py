@@ -9,9 +9,12 @@ Gradients are packed into a few persistent flat fp32 buckets (xGMI is point-to-p
 large messages beat many small ones) with one fused multi-tensor copy per bucket and reduced
 on a side stream, so that the next critic iteration's generator forward, which does not
 depend on the critic's weights, overlaps the exchange; afterwards the parameters' .grad are
-views of the buckets (no unpack). The generator's exchange (18.9 MB every 8th iteration) is
-blocking: a ring over one 153 GB/s xGMI link moves it in ~0.25 ms of a ~150 ms cycle, so
-bucket-by-bucket overlap with its own backward could win at most 0.2 %.
+views of the buckets (no unpack). With `overlap_backward()` armed (the critic: 41.7 MB every
+iteration) a bucket's all-reduce is launched from a post-accumulate-grad hook as soon as the
+backward pass has produced its last gradient, i.e. underneath the rest of that backward; what
+is still unlaunched when start() is called goes then. The generator's exchange (18.9 MB every
+8th iteration) is blocking: a ring over one 153 GB/s xGMI link moves it in ~0.25 ms of a
+~120 ms cycle, so overlapping it with its own backward could win at most 0.2 %.
 """
 import torch
 import torch.distributed as dist
@@ -52,6 +55,17 @@ class GradExchange:
         self._stream = None
         self._pending = None
         self._avg_in_collective = None
+        # backward-overlapped launch (overlap_backward): per bucket, how many gradients the backward pass
+        # delivers (learnt from the first exchange: dead branches never deliver) and how many have arrived
+        self._bucket_of = {}
+        self._expect = None
+        self._arrived = None
+        self._launched = None
+        self._next = 0
+        self._stream_marks = {}  # raw stream handle -> event re-recorded by the hooks
+        self._marked = set()
+        self._hooks = []
+        self.launched_in_backward = 0  # diagnostics: buckets whose all-reduce left before start()
 
     @property
     def active(self):
@@ -75,34 +89,94 @@ class GradExchange:
             self._flat[i], self._views[i] = flat, views
         return self._flat[i], self._views[i]
 
-    def start(self):
-        """Pack the gradients and launch the all-reduces asynchronously."""
-        if not self.active:
-            return
-        assert self._pending is None, "previous exchange not finished"
+    def _launch(self, i):
+        """Pack bucket i on the current stream and start its all-reduce on the communication stream."""
+        bucket = self.buckets[i]
         device = self.params[0].device
         stream = self._comm_stream(device)
         if self._avg_in_collective is None:
             # RCCL averages inside the collective; gloo (CPU tests, single-GPU dry runs) only sums
             self._avg_in_collective = device.type == "cuda" and dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
-        works, had = [], []
+        flat, views = self._bucket(i, device)
+        src = [p.grad for p in bucket if p.grad is not None]
+        dst = [v for p, v in zip(bucket, views) if p.grad is not None]
+        aliased = bool(src) and all(s.data_ptr() == d.data_ptr() for s, d in zip(src, dst))
+        if len(src) != len(bucket) and not aliased:
+            flat.zero_()  # slots of parameters without a gradient contribute zeros
+        if src and not aliased:
+            torch._foreach_copy_(dst, src)
+        had = [p.grad is not None for p in bucket]
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(stream):
+                work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        return work, had
+
+    def overlap_backward(self):
+        """Arm the backward-overlapped launch: from now on a bucket's all-reduce starts inside backward(),
+        from the hook of the last gradient it waits for. The first exchange runs as before and records which
+        parameters receive gradients at all; a bucket whose expected gradients do not all arrive is launched by
+        start() like the rest. Gradients must be complete when their hook fires, i.e. ONE backward pass per
+        exchange (the engines' critic iteration), and every rank must see the same set of live parameters."""
+        if self._hooks:
+            return self
         for i, bucket in enumerate(self.buckets):
-            flat, views = self._bucket(i, device)
-            src = [p.grad for p in bucket if p.grad is not None]
-            dst = [v for p, v in zip(bucket, views) if p.grad is not None]
-            aliased = bool(src) and all(s.data_ptr() == d.data_ptr() for s, d in zip(src, dst))
-            if len(src) != len(bucket) and not aliased:
-                flat.zero_()  # slots of parameters without a gradient contribute zeros
-            if src and not aliased:
-                torch._foreach_copy_(dst, src)
-            had.append([p.grad is not None for p in bucket])
-            if stream is not None:
-                stream.wait_stream(torch.cuda.current_stream(device))
-                with torch.cuda.stream(stream):
-                    works.append(dist.all_reduce(flat, op=op, group=self.group, async_op=True))
-            else:
-                works.append(dist.all_reduce(flat, op=op, group=self.group, async_op=True))
+            for p in bucket:
+                self._bucket_of[id(p)] = i
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        return self
+
+    def _on_grad(self, p):
+        if self._expect is None or self._pending is not None:
+            return
+        if p.is_cuda and torch.cuda.is_current_stream_capturing():
+            return  # captured backward passes: the exchange stays outside the graph
+        i = self._bucket_of[id(p)]
+        self._arrived[i] += 1
+        if p.is_cuda:
+            # a leaf's gradient is accumulated on the stream its accumulator node was created on (the critic's pose
+            # branch lives on a side stream): remember where each stream stands now; the launch below, which
+            # packs the whole bucket from ONE hook, first waits for all of them
+            st = torch.cuda.current_stream(p.device)
+            ev = self._stream_marks.get(st.cuda_stream)
+            if ev is None:
+                ev = self._stream_marks[st.cuda_stream] = torch.cuda.Event()
+            ev.record(st)
+            self._marked.add(st.cuda_stream)
+        # collectives must be issued in the same order on every rank: strictly by bucket index
+        while self._next < len(self.buckets) and self._expect[self._next] > 0 and \
+                self._arrived[self._next] >= self._expect[self._next]:
+            if p.is_cuda:
+                cur = torch.cuda.current_stream(p.device)
+                for key in self._marked:
+                    if key != cur.cuda_stream:
+                        cur.wait_event(self._stream_marks[key])
+            self._launched[self._next] = self._launch(self._next)
+            self.launched_in_backward += 1
+            self._next += 1
+
+    def start(self):
+        """Pack the gradients and launch the all-reduces asynchronously (those not already launched from
+        the backward hooks)."""
+        if not self.active:
+            return
+        assert self._pending is None, "previous exchange not finished"
+        works, had = [], []
+        for i in range(len(self.buckets)):
+            done = self._launched[i] if self._launched is not None else None
+            w, h = done if done is not None else self._launch(i)
+            works.append(w)
+            had.append(h)
+        if self._hooks:
+            # what the next backward is expected to deliver per bucket; arrival counters re-armed
+            self._expect = [sum(h) for h in had]
+            self._arrived = [0] * len(self.buckets)
+            self._launched = [None] * len(self.buckets)
+            self._next = 0
+            self._marked = set()
         self._pending = (works, had)
 
     def finish(self):

@@ -60,7 +60,8 @@ class WganGpEngine:
         self._critic_params = [p for p in critic.parameters() if p.dim() == 3] if self._keep_packs else None
         self._gen_params = [p for p in gen.parameters() if p.dim() == 3] if self._keep_packs else None
         self.total_iterations = 0
-        self.x_critic = GradExchange(critic.parameters()) if data_parallel else None
+        # the critic's exchange (every iteration) starts bucket by bucket underneath its own backward pass
+        self.x_critic = GradExchange(critic.parameters()).overlap_backward() if data_parallel else None
         self.x_gen = GradExchange(gen.parameters()) if data_parallel else None
         self._critic_step_pending = False
         self.last = {}

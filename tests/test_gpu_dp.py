@@ -105,6 +105,10 @@ def _rccl_worker(port, q):
         sigs.append(([float(v) for v in out.values()],
                      [float(p.detach().double().sum()) for p in list(critic.parameters())[:6] + list(gen.parameters())[:6]],
                      int(next(iter(eng.optim_critic.state.values()))["step"])))
+        # from the second iteration on the critic's buckets leave from the backward hooks (pose-branch gradients
+        # are accumulated on the side stream: the launch waits for every stream's mark)
+        ok = ok and (eng.x_critic.launched_in_backward >= 3 * len(eng.x_critic.buckets) if forced
+                     else eng.x_critic.launched_in_backward == 0)
     q.put((ok, sigs))
     dist.destroy_process_group()
 
