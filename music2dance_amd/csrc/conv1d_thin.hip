@@ -510,9 +510,11 @@ struct M2dWinView {
   int T, S, hop;
 };
 
-int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, hipStream_t stream);  // gemm_engine.hip
+int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, double* scratch, hipStream_t stream);  // gemm_engine.hip
 
-size_t m2d_thin_fwd_stats_ws(int B, int Lout) { return (size_t)B * m2d_ceil_div(Lout, 256) * 4 * 64 * sizeof(float); }
+// per-wave partials + the scratch of the two-stage row sum (256 groups x 32 rows x fp64 pair)
+static size_t thin_fwd_stats_part(int B, int Lout) { return (size_t)B * m2d_ceil_div(Lout, 256) * 4 * 64 * sizeof(float); }
+size_t m2d_thin_fwd_stats_ws(int B, int Lout) { return thin_fwd_stats_part(B, Lout) + (size_t)256 * 32 * 2 * sizeof(double); }
 
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
                  int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
@@ -534,7 +536,9 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
                     4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
   hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2>), dim3(m2d_ceil_div(Lout, 256), B), dim3(256), 0, stream, a);
   M2D_CHECK_LAUNCH("thin_fwd_mfma_kernel");
-  if (stats) return m2d_rowsums_reduce(a.stats, B * m2d_ceil_div(Lout, 256) * 4, 32, stats, stream);
+  if (stats)
+    return m2d_rowsums_reduce(a.stats, B * m2d_ceil_div(Lout, 256) * 4, 32, stats,
+                              (double*)((char*)a.stats + thin_fwd_stats_part(B, Lout)), stream);
   return M2D_OK;
 }
 

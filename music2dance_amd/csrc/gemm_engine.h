@@ -95,8 +95,18 @@ struct M2dOutMap {
   double* row_sums;  // [2 * M]: written by the launcher's reduction over row_part
 };
 // sums[2*row], sums[2*row + 1] (fp64) = fixed-order sums over the P partials part[p][row][0..1]
-int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, hipStream_t stream);
-static inline size_t m2d_rowstats_bytes(int M, int N) { return (size_t)((N + 127) / 128) * 4 * (size_t)M * 2 * sizeof(float); }
+// `scratch` (optional, M2D_ROWSUMS_GROUPS * M fp64 pairs): enables the two-stage sum when P * M is large
+#define M2D_ROWSUMS_GROUPS 256
+#define M2D_ROWSUMS_TWO_STAGE (64LL * 1024)
+int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, double* scratch, hipStream_t stream);
+static inline size_t m2d_rowstats_part_bytes(int M, int N) { return (size_t)((N + 127) / 128) * 4 * (size_t)M * 2 * sizeof(float); }
+// partials + the two-stage sum's scratch behind them (16-byte aligned)
+static inline size_t m2d_rowstats_bytes(int M, int N) {
+  return ((m2d_rowstats_part_bytes(M, N) + 15) & ~(size_t)15) + (size_t)M2D_ROWSUMS_GROUPS * M * 2 * sizeof(double);
+}
+static inline double* m2d_rowstats_scratch(float* row_part, int M, int N) {
+  return (double*)((char*)row_part + ((m2d_rowstats_part_bytes(M, N) + 15) & ~(size_t)15));
+}
 
 struct M2dGemmParams {
   M2dOperand A, B;
