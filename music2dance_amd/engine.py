@@ -37,8 +37,9 @@ class _Freeze:
 
 
 class WganGpEngine:
-    """Common machinery: optimisers, n_critic gating, data-parallel gradient exchange with
-    the critic's optimiser step deferred behind the next generator forward."""
+    """Common machinery: optimisers, n_critic gating, data-parallel gradient exchange (the critic's
+    optimiser step is taken at the start of the next iteration, once its all-reduce has landed),
+    the critic iterations' generator forward one iteration ahead on a second stream."""
 
     def __init__(self, gen, critic, lr_gen, lr_critic, n_critic_steps, data_parallel=True, fused_adam=None,
                  sync_bn=False):
@@ -117,7 +118,17 @@ class WganGpEngine:
         if self._gen_stream is None:
             self._gen_stream = torch.cuda.Stream(dev)  # default priority: a high-priority queue preempts (measured +25 %)
             self._gen_params_ready = main.record_event()  # weights as initialised / loaded on the main stream
+            # (float tensors only: the BatchNorm step counters are bumped by every forward itself)
+            self._gen_tensors = [t for t in list(self.gen.parameters()) + list(self.gen.buffers()) if t.is_floating_point()]
+            self._gen_versions = sum(t._version for t in self._gen_tensors)
         gs = self._gen_stream
+        # parameters / buffers changed by ordinary tensor operations since the last forward (load_state_dict, manual
+        # edits - they move the version counters; the engine's own fused optimizer step is covered in _gen_step):
+        # those ran on the main stream, so this forward has to queue behind it once
+        ver = sum(t._version for t in self._gen_tensors)
+        if ver != self._gen_versions:
+            self._gen_versions = ver
+            self._gen_params_ready = main.record_event()
         gs.wait_event(ready)
         gs.wait_event(self._gen_params_ready)
         if self._main_mark is not None:

@@ -313,3 +313,36 @@ def test_pipelined_generator_forward_is_bit_identical():
                 assert torch.equal(e[k], g[k]), (other, k, float(e[k]), float(g[k]))
         for pe, pg in zip(params[0], params[other]):
             assert torch.equal(pe, pg)
+
+
+def test_pipelined_forward_sees_weights_loaded_between_steps():
+    """A checkpoint loaded into the generator between two train steps (ordinary copy_ kernels on the main stream)
+    is visible to the next pipelined forward: the second stream queues behind the main stream once when the
+    parameters' version counters have moved. Same trace as the in-line order with the same load."""
+    import bench
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+    dev = torch.device(DEV)
+    b, t = 8, 120
+    batch = synthetic_phase3_batch(b, t, dev, seed=50)
+    torch.cuda.synchronize(dev)
+    ready = torch.cuda.current_stream(dev).record_event()
+    other, _ = bench.build_models(dev, t)
+    with torch.no_grad():
+        for p in other.parameters():
+            p.mul_(1.01)
+    state = {k: v.clone() for k, v in other.state_dict().items()}
+    traces = []
+    for pipelined in (False, True):
+        gen, critic = bench.build_models(dev, t)
+        eng = Phase3Engine(gen, critic, dict(bench.P3_DEFAULT, n_critic_steps=4))
+        torch.manual_seed(81)
+        outs = []
+        for i in range(6):
+            if i == 3:
+                gen.load_state_dict(state)
+            outs.append(eng.train_step(*batch, inputs_ready=ready if pipelined else None))
+        eng.flush()
+        traces.append([{k: v.clone() for k, v in o.items()} for o in outs])
+    for e, g in zip(*traces):
+        for k in e:
+            assert torch.equal(e[k], g[k]), (k, float(e[k]), float(g[k]))
