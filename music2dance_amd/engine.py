@@ -154,6 +154,15 @@ class WganGpEngine:
 
     def flush(self):
         self._finish_critic_step()
+        self._check_async()
+
+    @staticmethod
+    def _check_async():
+        # fail loudly if a persistent recurrent launch gave up waiting for its peers (it raises a word in pinned
+        # host memory; reading it costs nothing): the poses of that iteration would be garbage
+        chk = getattr(kernels.impl(), "check_async_errors", None)
+        if chk is not None:
+            chk()
 
     def train_step(self, *batch, inputs_ready=None):
         """One loop body of the reference: a critic iteration, plus a generator iteration every
@@ -162,6 +171,7 @@ class WganGpEngine:
         forward start before the previous iteration has drained (_generator_forward_nograd)."""
         self.total_iterations += 1
         self._inputs_ready = inputs_ready
+        self._check_async()
         # weights only change in the optimizer steps, which drop the packed conv-weight images
         with kernels.impl().weight_cache(keep=self._keep_packs):
             out = self.critic_iteration(*batch)
@@ -284,6 +294,7 @@ class Phase3Engine(WganGpEngine):
         if not getattr(self, "_use_graphs", False) or real.device.type != "cuda":
             return super().train_step(real, audio, audio_slices, inputs_ready=inputs_ready)
         self.total_iterations += 1
+        self._check_async()
         self._finish_critic_step()
         g = self._graph_for(real, audio, audio_slices)
         B, T = self._shapes(real)
