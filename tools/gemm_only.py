@@ -1,3 +1,4 @@
+"""Dev tool: the engine on plain 4096-cubed GEMMs only (NT / NN / TN), for rocprofv3 --pmc passes."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
