@@ -309,3 +309,56 @@ def test_sync_batchnorm_reproduces_the_global_batch(sync):
     else:
         # documents the deviation the default (per-rank statistics, torch-DDP semantics) has
         assert err_rows > 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# Backward-overlapped launch, single process (gloo, world size 1, force=True): a bucket whose expected
+# gradients do not all arrive during backward is launched by start() like before; one whose gradients do
+# arrive leaves from the hook.
+def _overlap_fallback_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from music2dance_amd.dp import GradExchange
+    torch.manual_seed(0)
+    a, b, c = (torch.nn.Parameter(torch.randn(40)) for _ in range(3))
+    ex = GradExchange([a, b, c], bucket_mb=1e-4, force=True).overlap_backward()
+    assert len(ex.buckets) == 3
+    x = torch.randn(40)
+
+    def run(use_b):
+        for p in (a, b, c):
+            p.grad = None
+        loss = (a * x).sum() + (c * x * 2).sum() + ((b * x * 3).sum() if use_b else 0.0)
+        n0 = ex.launched_in_backward
+        loss.backward()
+        ex.start()
+        ex.finish()
+        return ex.launched_in_backward - n0, [None if p.grad is None else p.grad.clone() for p in (a, b, c)]
+
+    first = run(True)    # learns: all three buckets deliver
+    second = run(True)   # all three leave from the hooks
+    third = run(False)   # b delivers nothing: its bucket (and, in bucket order, the ones behind it) wait for start()
+    fourth = run(True)   # expectations re-learnt from the third exchange: b's bucket expects nothing now
+    q.put((first[0], second[0], third[0], fourth[0],
+           [[None if g is None else g.numpy().copy() for g in r[1]] for r in (second, third, fourth)], x.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_falls_back_when_gradients_are_missing():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_overlap_fallback_worker, args=(_free_port(), q))
+    p.start()
+    n1, n2, n3, n4, grads, x = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert n1 == 0 and n2 == 3, (n1, n2)
+    assert n3 < 3, n3
+    x = torch.from_numpy(x)
+    for gs, use_b in zip(grads, (True, False, True)):
+        assert torch.allclose(torch.from_numpy(gs[0]), x) and torch.allclose(torch.from_numpy(gs[2]), 2 * x)
+        if use_b:
+            assert torch.allclose(torch.from_numpy(gs[1]), 3 * x)
+        else:
+            assert gs[1] is None
