@@ -147,8 +147,8 @@ class GradExchange:
             ev.record(st)
             self._marked.add(st.cuda_stream)
         # collectives must be issued in the same order on every rank: strictly by bucket index
-        while self._next < len(self.buckets) and self._expect[self._next] > 0 and \
-                self._arrived[self._next] >= self._expect[self._next]:
+        # (a bucket that expects no gradient at all - every parameter dead - goes as soon as its turn comes)
+        while self._next < len(self.buckets) and self._arrived[self._next] >= self._expect[self._next]:
             if p.is_cuda:
                 cur = torch.cuda.current_stream(p.device)
                 for key in self._marked:
