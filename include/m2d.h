@@ -81,7 +81,8 @@ int m2d_conv1d_bwd_weight_windows(const float* track, int B, int S, int T, int h
                                   float* dw, float* dbias, int Cout, int ks, int stride, int pad,
                                   const float* dy_mask, float dy_mask_slope, void* ws, size_t ws_bytes, void* stream);
 /* The GEMMs behind forward / backward-data contract over (tap, channel) and read the weights
- * through packed images: w_fwd (Cout, ks, Cin) and w_bwd (Cin, ks, Cout) of w (Cout, Cin, ks).
+ * through K-major packed images (the GEMM's row index contiguous, so that weight tiles are staged with
+ * lane-consecutive loads straight into the LDS): w_fwd (Cin, ks, Cout) and w_bwd (Cout, ks, Cin) of w (Cout, Cin, ks).
  * `w_packed` above is the matching image, or NULL: the call then packs into its workspace.
  * Callers that reuse weights across calls pack once per weight update (either output may be NULL). */
 int m2d_conv1d_pack_weights(const float* w, float* w_fwd, float* w_bwd, int Cout, int Cin, int ks, void* stream);

@@ -76,9 +76,10 @@ static void fill_fwd(M2dGemmParams& p, const float* x, const float* w, const flo
     p.kdiv = Cin;
     p.lo_outer = 1;
     p.small_tile_penalty = fwd_tile_penalty(stride);
-    // A(m = co, k = (kk,ci)) = wp[co*ks*Cin + kk*Cin + ci]
-    m2d_operand_plain(p.A, wp, Cout, Cin * ks, 1, (long long)Cout * Cin * ks);
-    p.A.k_hi_stride = Cin;
+    // K-major weight image (Cin, ks, Cout): A(m = co, k = (kk,ci)) = wp[ci*ks*Cout + kk*Cout + co] - rows contiguous,
+    // so both operands are row-fast and the launch can stage straight into the LDS (m2d_gemm_dl_kernel)
+    m2d_operand_plain(p.A, wp, Cout, 1, ks * Cout, (long long)Cout * Cin * ks);
+    p.A.k_hi_stride = Cout;
     // B(k = (kk,ci), col = (n,l)) = x[n*Cin*L + ci*L + l*s - p + kk]
     b.k_hi_stride = 1;
     b.k_lo_stride = L;
@@ -147,12 +148,13 @@ int m2d_conv1d_pack_weights(const float* w, float* w_fwd, float* w_bwd, int Cout
   if (Cout <= 0 || Cin <= 0 || ks <= 0 || !w) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_pack_weights: bad arguments");
   if (!fits_i32((long long)Cout * Cin * ks)) M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_pack_weights: too large");
   if (!w_fwd && !w_bwd) return M2D_OK;
-  return pack_weights(w, w_fwd, w_bwd, Cout, Cin, ks, (hipStream_t)stream);
+  // the forward reads the K-major image (Cin, ks, Cout), backward-data (Cout, ks, Cin): see fill_fwd / m2d_conv1d_bwd_data
+  return pack_weights(w, /*(Cout, ks, Cin) ->*/ w_bwd, /*(Cin, ks, Cout) ->*/ w_fwd, Cout, Cin, ks, (hipStream_t)stream);
 }
 
 // Replaces nn.Conv1d forward (+ fused bias / ReLU / LeakyReLU / residual add):
 // phase3/archis/default.py:78-82,137-143,207-210,312-319,342-346.
-// `w_packed` (optional): the (Cout, ks, Cin) image of w from m2d_conv1d_pack_weights.
+// `w_packed` (optional): the forward image (Cin, ks, Cout) of w from m2d_conv1d_pack_weights.
 // `out_mask` (optional, shape of y) multiplies the result by (mask>0 ? 1 : out_mask_slope):
 // it is the d/d(dy) branch of backward-data's derivative (double backward of the GP).
 static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
@@ -203,7 +205,7 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
   if (conv_uses_packed(Cin) && !w_packed) {
     const size_t pb = pack_bytes(Cout, Cin, ks);
     if (!ws || ws_bytes < pb) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd: workspace too small to pack the weights");
-    const int rc = pack_weights(w, (float*)ws, nullptr, Cout, Cin, ks, (hipStream_t)stream);
+    const int rc = pack_weights(w, nullptr, (float*)ws, Cout, Cin, ks, (hipStream_t)stream);
     if (rc) return rc;
     w_packed = (const float*)ws;
     ws = (char*)ws + pb;
@@ -223,8 +225,8 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
     p.O.row_part = (float*)ws;
     p.O.row_sums = stats;
   }
-  return m2d_gemm_launch(p, /*a_kfast=*/true, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
-                         (hipStream_t)stream, "m2d_conv1d_fwd");
+  return m2d_gemm_launch(p, /*a_kfast=*/!conv_uses_packed(Cin), /*b_kfast=*/false, /*allow_split=*/true,
+                         ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_fwd");
 }
 
 int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
@@ -254,7 +256,7 @@ int m2d_conv1d_fwd_windows(const float* track, int B, int S, int T, int hop, int
 
 // Replaces the input-gradient half of convolution_backward (autograd of nn.Conv1d), the
 // op the gradient penalty differentiates a second time (losses.py:40-44).
-// `w_packed` (optional): the (Cin, ks, Cout) image of w from m2d_conv1d_pack_weights.
+// `w_packed` (optional): the backward image (Cout, ks, Cin) of w from m2d_conv1d_pack_weights.
 // `dy_mask` (optional, shape of dy): dy is read as dy * (mask>0 ? 1 : dy_mask_slope).
 int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
                         int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
@@ -291,7 +293,7 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
     const size_t pb = pack_bytes(Cout, Cin, ks);
     if (!ws || ws_bytes < pb)
       M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_bwd_data: workspace too small to pack the weights");
-    const int rc = pack_weights(w, nullptr, (float*)ws, Cout, Cin, ks, (hipStream_t)stream);
+    const int rc = pack_weights(w, (float*)ws, nullptr, Cout, Cin, ks, (hipStream_t)stream);
     if (rc) return rc;
     w_packed = (const float*)ws;
     ws = (char*)ws + pb;
@@ -320,9 +322,11 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
   }
   p.N = B * nq_max;
   p.K = Cout * p.nhi;
-  // A(m = ci, k = (t,co)) = wb[ci*ks*Cout + (r + s*t)*Cout + co]  (r*Cout added per phase on device)
-  m2d_operand_plain(p.A, w_packed, Cin, ks * Cout, 1, (long long)Cout * Cin * ks);
-  p.A.k_hi_stride = stride * Cout;
+  // K-major weight image (Cout, ks, Cin): A(m = ci, k = (t,co)) = wk[co*ks*Cin + (r + s*t)*Cin + ci], rows contiguous
+  // (r*Cin added per phase on the device)
+  m2d_operand_plain(p.A, w_packed, Cin, 1, ks * Cin, (long long)Cout * Cin * ks);
+  p.A.k_hi_stride = stride * Cin;
+  p.ph_a_step = Cin;
   // B(k = (t,co), col = (n,q)) = dy[n*Cout*Lout + co*Lout + q - t], valid iff 0 <= q - t < Lout
   M2dOperand& b = p.B;
   b.base = dy;
@@ -367,10 +371,10 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
     p.O.cdiv_inv = b.rdiv_inv;
     p.O.c_off = 0;
     p.O.c_pos_off = 0;
-    return m2d_gemm_launch(p, /*a_kfast=*/true, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
+    return m2d_gemm_launch(p, /*a_kfast=*/false, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
                            (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }
-  return m2d_gemm_launch(p, /*a_kfast=*/true, /*b_kfast=*/false, /*allow_split=*/false, ws, ws_bytes,
+  return m2d_gemm_launch(p, /*a_kfast=*/false, /*b_kfast=*/false, /*allow_split=*/false, ws, ws_bytes,
                          (hipStream_t)stream, "m2d_conv1d_bwd_data");
 }
 

@@ -121,6 +121,7 @@ struct M2dGemmParams {
   int bwd_data;
   int phases;
   int ph_ks, ph_cout, ph_pad, ph_L, ph_batch;
+  int ph_a_step;        // element offset of one tap in the A operand (0: ph_cout, the (Cin, ks, Cout) image)
   int splits;           // > 1: split-K, partial tiles go to slab[split][M*N]
   float* slab;
 };

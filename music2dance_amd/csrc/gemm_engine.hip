@@ -28,6 +28,13 @@ __device__ __forceinline__ float m2d_bload(__amdgpu_buffer_rsrc_t r, unsigned vo
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }
 
+// the same load with the LDS as its destination: lane L of the wave writes dst[L] (M0 = dst, wave-uniform);
+// lanes whose offset fails the range check write 0.0f (measured on gfx950), so padding needs no separate store
+typedef __attribute__((address_space(3))) float m2d_lds_f;
+__device__ __forceinline__ void m2d_bload_lds(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (m2d_lds_f*)dst, 4, (int)voff, soff, 0, 0);
+}
+
 // element offset of row-side index hi (two-level for window views, see M2dOperand)
 __device__ __forceinline__ int m2d_hi_offset(const M2dOperand& op, int hi) {
   if (op.rdiv2 <= 0) return hi * op.r_hi_stride;
@@ -132,6 +139,33 @@ struct TileMap {
           const int pp = (lo0 + kb + i < kdiv) ? P + i * op.k_pos_lo : M2D_BAD;
           fetch(rs, rm, i, ((unsigned)(posr + pp) < lim_eff) ? full + (unsigned)(i * ls4) : M2D_OOB, 0);
         }
+      }
+    }
+  }
+
+  // row-fast map, unmasked, no all-ones row: stage chunk (hi, lo0) STRAIGHT into the LDS image [k][row] (leading
+  // dimension LD): a wave's 64 rows of one k-slot are lane-consecutive dwords. `img` = the operand's image of
+  // the stage being filled; no staging registers, no ds_write.
+  template <bool UNIFORM, int LD>
+  __device__ __forceinline__ void load_lds(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs, int hi, int lo0, int kdiv,
+                                           float* img, int tid) const {
+    static_assert(!KF && !MASKED && BR >= 64, "LDS-direct staging: row-fast, unmasked, whole waves per k-slot");
+    int hoff = hi * op.k_hi_stride;
+    const int S = (hoff + lo0 * op.k_lo_stride) << 2;
+    const int P = hi * op.k_pos_hi + lo0 * op.k_pos_lo;
+    const unsigned full = eoff[0] + (unsigned)S;
+    const int ls4 = op.k_lo_stride << 2;
+    // wave-uniform destination of this wave's rows for slot kb: img[(kb + i) * LD + first row of the wave]
+    float* dst = img + kb * LD + (__builtin_amdgcn_readfirstlane(tid) & (BR - 1) & ~63);
+    if constexpr (UNIFORM) {
+      const unsigned voff = ((unsigned)(posr + P) < lim_eff) ? full : M2D_OOB;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) m2d_bload_lds(rs, dst + i * LD, voff, i * ls4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int pp = (lo0 + kb + i < kdiv) ? P + i * op.k_pos_lo : M2D_BAD;
+        m2d_bload_lds(rs, dst + i * LD, ((unsigned)(posr + pp) < lim_eff) ? full + (unsigned)(i * ls4) : M2D_OOB, 0);
       }
     }
   }
@@ -245,6 +279,71 @@ __device__ __forceinline__ void m2d_chunk_mma(const TileMap<AKF, BM, MASKED>& ta
   }
 }
 
+// Tile epilogue shared by the staging variants. C/D layout of the 32x32 MFMA: col = lane & 31,
+//      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+template <int BM, int BN>
+__device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const M2dOutMap& O, int N, int split, int m0,
+                                                  int n0, int wm, int wn, int l31, int lh,
+                                                  f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  int caddr[TN], colj[TN];
+  bool cvj[TN], cokj[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+    const bool cv = col < N;
+    int chi, clo;
+    m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
+    caddr[j] = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
+    bool cok = cv;
+    if (O.c_lim > 0) cok = cok && ((unsigned)(clo * O.c_pos_mul + O.c_pos_off) < (unsigned)O.c_lim);
+    colj[j] = col;
+    cvj[j] = cv;
+    cokj[j] = cok;
+  }
+  const bool stats = O.row_part != nullptr && p.splits <= 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const bool rok = row < p.M;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (rok) {
+          if (p.splits > 1) {
+            if (cvj[j]) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + colj[j]] = acc[i][j][r];
+          } else if (colj[j] + 1 == O.redirect_col_p1) {
+            O.col_out[row] = acc[i][j][r];
+          } else if (cokj[j]) {
+            const int addr = row * O.m_stride + caddr[j];
+            const float v = m2d_epilogue(O, acc[i][j][r], row, colj[j], addr);
+            O.out[addr] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+      if (stats) {  // wave-uniform: sum over the 32 lanes (columns) that share this row, one atomic pair per row
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        if (l31 == 0 && rok) {
+          float* dst = O.row_part + ((size_t)(blockIdx.x * WN + wn) * p.M + row) * 2;
+          dst[0] = s1;
+          dst[1] = s2;
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN, bool AKF, bool BKF, bool MASKED>
 __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p) {
   constexpr int LDA = BM + M2D_LDPAD;
@@ -285,7 +384,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
     N = p.ph_batch * nq;
     if ((int)(blockIdx.x * BN) >= N) return;
     nhi = taps;
-    A.r_off += r * p.ph_cout;
+    A.r_off += r * (p.ph_a_step ? p.ph_a_step : p.ph_cout);
     B.nrows = N;
     B.rdiv = nq;
     B.rdiv_inv = 1.f / (float)nq;
@@ -362,61 +461,146 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
     }
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31,
-  //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  int caddr[TN], colj[TN];
-  bool cvj[TN], cokj[TN];
+  m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+}
+
+// ---- LDS-direct staging variant ------------------------------------------------------------------------------------
+// Both operands row-fast and unmasked (conv forward / backward-data over the K-major weight image, plain NN GEMMs):
+// the chunk's loads write the LDS image themselves (`buffer_load ... lds`), so the tile needs neither the 16 staging
+// registers nor the ds_write pass, and with rows lane-consecutive on both sides the image needs no padding: 32 KB of
+// LDS and <= 102 VGPRs per workgroup = FIVE workgroups per CU instead of four.
+template <int BM, int BN>
+__device__ __forceinline__ void m2d_chunk_mma_dl(const float* stage, int wm, int wn, int l31, int lh,
+                                                 f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  const float* as = stage + wm * (TM * 32) + l31;
+  const float* bs = stage + M2D_BK * BM + wn * (TN * 32) + l31;
+  float fa[M2D_BK / 2][TM], fb[M2D_BK / 2][TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (TN * 32) + j * 32 + l31;
-    const bool cv = col < N;
-    int chi, clo;
-    m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
-    caddr[j] = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
-    bool cok = cv;
-    if (O.c_lim > 0) cok = cok && ((unsigned)(clo * O.c_pos_mul + O.c_pos_off) < (unsigned)O.c_lim);
-    colj[j] = col;
-    cvj[j] = cv;
-    cokj[j] = cok;
+  for (int kk = 0; kk < M2D_BK / 2; ++kk) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[kk][i] = as[(2 * kk + lh) * BM + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[kk][j] = bs[(2 * kk + lh) * BN + j * 32];
   }
-  const bool stats = O.row_part != nullptr && p.splits <= 1;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int kk = 0; kk < M2D_BK / 2; ++kk)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const bool rok = row < p.M;
-      float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (rok) {
-          if (p.splits > 1) {
-            if (cvj[j]) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + colj[j]] = acc[i][j][r];
-          } else if (colj[j] + 1 == O.redirect_col_p1) {
-            O.col_out[row] = acc[i][j][r];
-          } else if (cokj[j]) {
-            const int addr = row * O.m_stride + caddr[j];
-            const float v = m2d_epilogue(O, acc[i][j][r], row, colj[j], addr);
-            O.out[addr] = v;
-            s1 += v;
-            s2 += v * v;
-          }
-        }
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+  for (int kk = 0; kk < M2D_BK / 2; ++kk) {
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+    if (kk < M2D_BK / 2 - 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  }
+}
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams p) {
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  constexpr int STAGE = M2D_BK * (BM + BN);
+  __shared__ float smem[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM;
+  const int wn = wave / WM;
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+
+  M2dOperand A = p.A;
+  M2dOperand B = p.B;
+  M2dOutMap O = p.O;
+  int N = p.N;
+  int nhi = p.nhi;
+  int split = blockIdx.z;
+  if (p.bwd_data) {  // as in m2d_gemm_kernel
+    const int r = blockIdx.z;
+    const int s = p.phases;
+    split = 0;
+    const int taps = r < p.ph_ks ? (p.ph_ks - r + s - 1) / s : 0;
+    const int qmin = r >= p.ph_pad ? 0 : (p.ph_pad - r + s - 1) / s;
+    const int top = p.ph_L - 1 + p.ph_pad - r;
+    const int nq = top >= 0 ? (top / s - qmin + 1) : 0;
+    if (nq <= 0) return;
+    N = p.ph_batch * nq;
+    if ((int)(blockIdx.x * BN) >= N) return;
+    nhi = taps;
+    A.r_off += r * (p.ph_a_step ? p.ph_a_step : p.ph_cout);
+    B.nrows = N;
+    B.rdiv = nq;
+    B.rdiv_inv = 1.f / (float)nq;
+    B.r_off = qmin;
+    B.r_pos_off = qmin;
+    O.cdiv = nq;
+    O.cdiv_inv = B.rdiv_inv;
+    O.c_off = s * qmin + r - p.ph_pad;
+    O.c_pos_off = O.c_off;
+  }
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  TileMap<false, BM, false> ta;
+  TileMap<false, BN, false> tb;
+  ta.prep(A, m0, tid);
+  tb.prep(B, n0, tid);
+  const __amdgpu_buffer_rsrc_t ra = m2d_rsrc(A.base, A.nbytes);
+  const __amdgpu_buffer_rsrc_t rb = m2d_rsrc(B.base, B.nbytes);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int cph = (p.kdiv + M2D_BK - 1) / M2D_BK;
+  const int nchunks = nhi * cph;
+  const int cps = (nchunks + p.splits - 1) / p.splits;
+  const int c0 = split * cps;
+  const int c1 = (c0 + cps < nchunks) ? (c0 + cps) : nchunks;
+
+  if (c0 < c1) {
+    ChunkCursor cc;
+    cc.kdiv = p.kdiv;
+    cc.nhi = nhi;
+    cc.lo_outer = p.lo_outer;
+    cc.seek(c0, cph);
+    cc.a_lo = A.k_safe_lo; cc.a_hi = A.k_safe_hi;
+    cc.b_lo = B.k_safe_lo; cc.b_hi = B.k_safe_hi;
+    ta.template load_lds<false, BM>(A, ra, cc.hi, cc.lo0, cc.extent(), smem, tid);
+    tb.template load_lds<false, BN>(B, rb, cc.hi, cc.lo0, cc.extent(), smem + M2D_BK * BM, tid);
+    cc.next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+      const int cur = (c - c0) & 1;
+      // chunk c + 1 streams into the other stage (every wave left it at the barrier that ended chunk c - 1) while
+      // chunk c is multiplied; the chunk after the last one loads zeros or the next split's data, harmlessly
+      float* nxt = smem + (cur ^ 1) * STAGE;
+      if (cc.uniform()) {
+        ta.template load_lds<true, BM>(A, ra, cc.hi, cc.lo0, cc.kdiv, nxt, tid);
+        tb.template load_lds<true, BN>(B, rb, cc.hi, cc.lo0, cc.kdiv, nxt + M2D_BK * BM, tid);
+      } else {
+        ta.template load_lds<false, BM>(A, ra, cc.hi, cc.lo0, cc.extent(), nxt, tid);
+        tb.template load_lds<false, BN>(B, rb, cc.hi, cc.lo0, cc.extent(), nxt + M2D_BK * BM, tid);
       }
-      if (stats) {  // wave-uniform: sum over the 32 lanes (columns) that share this row, one atomic pair per row
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          s1 += __shfl_xor(s1, off, 64);
-          s2 += __shfl_xor(s2, off, 64);
-        }
-        if (l31 == 0 && rok) {
-          float* dst = O.row_part + ((size_t)(blockIdx.x * WN + wn) * p.M + row) * 2;
-          dst[0] = s1;
-          dst[1] = s2;
-        }
-      }
+      m2d_chunk_mma_dl<BM, BN>(smem + cur * STAGE, wm, wn, l31, lh, acc);
+      cc.next();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
   }
+  m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 }
 
 // Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue. Eight
@@ -686,8 +870,21 @@ static void launch_tile(const M2dGemmParams& p, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, false>), grid, dim3(256), 0, stream, p);
 }
 
+// M2D_DL=0: keep row-fast / row-fast launches on the register-staging kernel (A/B lever)
+static bool dl_enabled() {
+  static const bool on = [] { const char* e = getenv("M2D_DL"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <int BM>
 static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hipStream_t stream) {
+  if constexpr (BM >= 64) {
+    if (!akf && !bkf && dl_enabled() && !p.A.mask && !p.B.mask && !p.A.ones_row_p1 && !p.B.ones_row_p1 &&
+        p.A.rdiv2 <= 0 && p.B.rdiv2 <= 0 && p.A.kdiv2 <= 0 && p.B.kdiv2 <= 0) {
+      hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128>), grid, dim3(256), 0, stream, p);
+      return 0;
+    }
+  }
   if (akf && !bkf) launch_tile<BM, true, false>(p, grid, stream);
   else if (!akf && !bkf) launch_tile<BM, false, false>(p, grid, stream);
   else if (akf && bkf) launch_tile<BM, true, true>(p, grid, stream);

@@ -140,7 +140,8 @@ class HipKernels:
                 self._packed.pop(id(w), None)
 
     def packed_weights(self, w):
-        """(w_fwd (Cout, ks, Cin), w_bwd (Cin, ks, Cout)) of a conv weight (written on the current stream)."""
+        """(w_fwd (Cin, ks, Cout), w_bwd (Cout, ks, Cin)): the K-major images of a conv weight the forward / backward-data
+        GEMMs read (written on the current stream)."""
         stream = _stream(w.device)
         key = id(w)
         if self._cache_depth > 0:
@@ -148,8 +149,8 @@ class HipKernels:
             if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == stream:
                 return ent[3], ent[4]
         Cout, Cin, ks = w.shape
-        wf = torch.empty((Cout, ks, Cin), dtype=torch.float32, device=w.device)
-        wb = torch.empty((Cin, ks, Cout), dtype=torch.float32, device=w.device)
+        wf = torch.empty((Cin, ks, Cout), dtype=torch.float32, device=w.device)
+        wb = torch.empty((Cout, ks, Cin), dtype=torch.float32, device=w.device)
         with _on(w.device):
             rc = _lib.lib().m2d_conv1d_pack_weights(_ptr(w), _ptr(wf), _ptr(wb), Cout, Cin, ks, stream)
         _lib.check(rc, "m2d_conv1d_pack_weights")
