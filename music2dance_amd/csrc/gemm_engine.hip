@@ -98,6 +98,28 @@ struct TileMap {
     }
   }
 
+  // LDS-direct staging (row-fast): a wave must fill lane-consecutive dwords of the [k][row] image. BR >= 64: as prep().
+  // BR == 32: the two half-waves take ADJACENT k-slots (slot = 4 * wave + (lane >> 5) + 2 i), so that lanes 0..63 of
+  // one load cover two whole 32-row lines of the image.
+  static constexpr int DL_KSTEP = BR >= 64 ? 1 : 64 / BR;
+  __device__ __forceinline__ void prep_dl(const M2dOperand& op, int row0, int tid) {
+    static_assert(!KF && !MASKED && (BR == 32 || BR >= 64), "LDS-direct staging: row-fast, unmasked");
+    if constexpr (BR >= 64) {
+      prep(op, row0, tid);
+    } else {
+      lim_eff = op.lim > 0 ? (unsigned)op.lim : (unsigned)(M2D_BAD - 1);
+      force_one = false;
+      kb = 4 * (tid >> 6) + ((tid >> 5) & 1);
+      const int g = row0 + (tid & (BR - 1));
+      const bool rv = g < op.nrows;
+      int hi, lo;
+      m2d_divmod(rv ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
+      const int off = m2d_hi_offset(op, hi) + lo * op.r_lo_stride + op.r_off + kb * op.k_lo_stride;
+      eoff[0] = (unsigned)off << 2;
+      posr = rv ? (op.lim > 0 ? lo * op.r_pos_mul + op.r_pos_off + kb * op.k_pos_lo : 0) : M2D_BAD;
+    }
+  }
+
   __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rm, int i, unsigned voff,
                                         int soff) {
     v[i] = m2d_bload(rs, voff, soff);
@@ -149,23 +171,26 @@ struct TileMap {
   template <bool UNIFORM, int LD>
   __device__ __forceinline__ void load_lds(const M2dOperand& op, __amdgpu_buffer_rsrc_t rs, int hi, int lo0, int kdiv,
                                            float* img, int tid) const {
-    static_assert(!KF && !MASKED && BR >= 64, "LDS-direct staging: row-fast, unmasked, whole waves per k-slot");
+    static_assert(!KF && !MASKED, "LDS-direct staging: row-fast, unmasked");
+    constexpr int KS = DL_KSTEP;
     int hoff = hi * op.k_hi_stride;
     const int S = (hoff + lo0 * op.k_lo_stride) << 2;
     const int P = hi * op.k_pos_hi + lo0 * op.k_pos_lo;
     const unsigned full = eoff[0] + (unsigned)S;
-    const int ls4 = op.k_lo_stride << 2;
-    // wave-uniform destination of this wave's rows for slot kb: img[(kb + i) * LD + first row of the wave]
-    float* dst = img + kb * LD + (__builtin_amdgcn_readfirstlane(tid) & (BR - 1) & ~63);
+    const int ls4 = (op.k_lo_stride * KS) << 2;
+    // wave-uniform destination: the image line of lane 0's slot, at the wave's first row
+    const int kb0 = BR >= 64 ? kb : 4 * (__builtin_amdgcn_readfirstlane(tid) >> 6);
+    const int row0 = BR >= 64 ? (__builtin_amdgcn_readfirstlane(tid) & (BR - 1) & ~63) : 0;
+    float* dst = img + kb0 * LD + row0;
     if constexpr (UNIFORM) {
       const unsigned voff = ((unsigned)(posr + P) < lim_eff) ? full : M2D_OOB;
 #pragma unroll
-      for (int i = 0; i < NE; ++i) m2d_bload_lds(rs, dst + i * LD, voff, i * ls4);
+      for (int i = 0; i < NE; ++i) m2d_bload_lds(rs, dst + (KS * i) * LD, voff, i * ls4);
     } else {
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        const int pp = (lo0 + kb + i < kdiv) ? P + i * op.k_pos_lo : M2D_BAD;
-        m2d_bload_lds(rs, dst + i * LD, ((unsigned)(posr + pp) < lim_eff) ? full + (unsigned)(i * ls4) : M2D_OOB, 0);
+        const int pp = (lo0 + kb + KS * i < kdiv) ? P + (KS * i) * op.k_pos_lo : M2D_BAD;
+        m2d_bload_lds(rs, dst + (KS * i) * LD, ((unsigned)(posr + pp) < lim_eff) ? full + (unsigned)(i * ls4) : M2D_OOB, 0);
       }
     }
   }
@@ -550,8 +575,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   const int n0 = blockIdx.x * BN;
   TileMap<false, BM, false> ta;
   TileMap<false, BN, false> tb;
-  ta.prep(A, m0, tid);
-  tb.prep(B, n0, tid);
+  ta.prep_dl(A, m0, tid);
+  tb.prep_dl(B, n0, tid);
   const __amdgpu_buffer_rsrc_t ra = m2d_rsrc(A.base, A.nbytes);
   const __amdgpu_buffer_rsrc_t rb = m2d_rsrc(B.base, B.nbytes);
 
@@ -878,7 +903,7 @@ static bool dl_enabled() {
 
 template <int BM>
 static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hipStream_t stream) {
-  if constexpr (BM >= 64) {
+  {
     if (!akf && !bkf && dl_enabled() && !p.A.mask && !p.B.mask && !p.A.ones_row_p1 && !p.B.ones_row_p1 &&
         p.A.rdiv2 <= 0 && p.B.rdiv2 <= 0 && p.A.kdiv2 <= 0 && p.B.kdiv2 <= 0) {
       hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128>), grid, dim3(256), 0, stream, p);
