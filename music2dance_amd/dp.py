@@ -16,6 +16,8 @@ is still unlaunched when start() is called goes then. The generator's exchange (
 8th iteration) is blocking: a ring over one 153 GB/s xGMI link moves it in ~0.25 ms of a
 ~120 ms cycle, so overlapping it with its own backward could win at most 0.2 %.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -65,6 +67,7 @@ class GradExchange:
         self._stream_marks = {}  # raw stream handle -> event re-recorded by the hooks
         self._marked = set()
         self._hooks = []
+        self._suspended = 0
         self.launched_in_backward = 0  # diagnostics: buckets whose all-reduce left before start()
 
     @property
@@ -129,8 +132,20 @@ class GradExchange:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         return self
 
+    @contextlib.contextmanager
+    def suspended(self):
+        """Inside: backward passes do not feed the exchange (no arrival counting, no hook-launched all-reduce).
+        For a backward that is NOT followed by start() - a captured-graph warm-up pass, a diagnostic backward:
+        its hooks would otherwise pack and reduce THOSE gradients, and the next start() would adopt the stale
+        works instead of launching the real ones."""
+        self._suspended += 1
+        try:
+            yield self
+        finally:
+            self._suspended -= 1
+
     def _on_grad(self, p):
-        if self._expect is None or self._pending is not None:
+        if self._expect is None or self._pending is not None or self._suspended:
             return
         if p.is_cuda and torch.cuda.is_current_stream_capturing():
             return  # captured backward passes: the exchange stays outside the graph

@@ -355,7 +355,11 @@ class Phase3Engine(WganGpEngine):
         saved = [[b.clone() for b in m.buffers()] for m in mods]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        # (the warm-up backward must not feed the data-parallel exchange either: no start() follows it)
+        quiet = [x.suspended() for x in (self.x_critic, self.x_gen) if x is not None]
+        with torch.cuda.stream(side), contextlib.ExitStack() as es:
+            for q in quiet:
+                es.enter_context(q)
             critic_body()
             gen_body()
         torch.cuda.current_stream(dev).wait_stream(side)

@@ -362,3 +362,47 @@ def test_overlapped_exchange_falls_back_when_gradients_are_missing():
             assert torch.allclose(torch.from_numpy(gs[1]), 3 * x)
         else:
             assert gs[1] is None
+
+
+# ---------------------------------------------------------------------------------------------
+# A backward pass that is not followed by start() (the captured-graph warm-up of a second batch shape) must not
+# feed the armed exchange: without suspended() its hooks pack and reduce the warm-up gradients and the next
+# start() adopts those works - the optimizer would step on stale averages.
+def _suspend_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from music2dance_amd.dp import GradExchange
+    torch.manual_seed(0)
+    a, b = (torch.nn.Parameter(torch.randn(40)) for _ in range(2))
+    ex = GradExchange([a, b], bucket_mb=1e-4, force=True).overlap_backward()
+    x = torch.randn(40)
+
+    def backward(scale):
+        for p in (a, b):
+            p.grad = None
+        ((a * x).sum() * scale + (b * x).sum() * 2 * scale).backward()
+
+    backward(1.0)
+    ex.start(), ex.finish()            # first exchange: learns the live set
+    n0 = ex.launched_in_backward
+    with ex.suspended():
+        backward(100.0)                # warm-up pass: no start() follows
+    quiet = ex.launched_in_backward - n0
+    backward(1.0)                      # the real pass
+    ex.start(), ex.finish()
+    q.put((quiet, ex.launched_in_backward - n0, a.grad.numpy().copy(), b.grad.numpy().copy(), x.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_suspended_backward_does_not_feed_the_exchange():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_suspend_worker, args=(_free_port(), q))
+    p.start()
+    quiet, launched, ga, gb, x = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert quiet == 0 and launched == 2, (quiet, launched)
+    x = torch.from_numpy(x)
+    assert torch.allclose(torch.from_numpy(ga), x) and torch.allclose(torch.from_numpy(gb), 2 * x)

@@ -125,3 +125,55 @@ def test_rccl_backend_exchange_world_size_one():
     assert n0 == n1 == 4  # every critic step taken, deferred or not
     for a, b in zip(l0 + s0, l1 + s1):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (sigs)
+
+
+def _rccl_graphs_worker(port, q):
+    """RCCL (world size 1, exchange forced on) with everything that meets on a real 8-GPU run in ONE step: the
+    persistent GRU launch, the generator forward pipelined on its own stream (inputs_ready), the critic's buckets
+    leaving from backward hooks - and, in graph mode, a SECOND batch shape captured after eager exchanges have armed
+    the hooks (the warm-up backward of that capture must not feed the exchange: GradExchange.suspended)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert os.environ.get("M2D_PERSISTENT_GRU", "1") != "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import bench
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+    dev = torch.device("cuda:0")
+    batches = {b: synthetic_phase3_batch(b, 120, dev, seed=70 + b, with_event=True) for b in (4, 2)}
+    order = (4, 4, 2, 4, 2, 2, 4, 4)
+    sigs = []
+    for graphs in (False, True):
+        gen, critic = bench.build_models(dev, 120)
+        eng = Phase3Engine(gen, critic, dict(bench.P3_DEFAULT, n_critic_steps=2))
+        eng.x_critic.force = eng.x_gen.force = True
+        if graphs:
+            eng.enable_graphs()
+        torch.manual_seed(11)
+        for b in order:
+            real, audio, slices, ready = batches[b]
+            out = eng.train_step(real, audio, slices, inputs_ready=ready)
+        eng.flush()
+        torch.cuda.synchronize()
+        eng._check_async()
+        sigs.append(([float(v) for v in out.values()],
+                     [float(p.detach().double().sum()) for p in list(critic.parameters()) + list(gen.parameters())],
+                     int(next(iter(eng.optim_critic.state.values()))["step"]), eng.x_critic.launched_in_backward))
+    q.put(sigs)
+    dist.destroy_process_group()
+
+
+def test_rccl_two_shapes_graphs_equal_eager_with_persistent_gru_and_hook_overlap():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_graphs_worker, args=(_free_port(), q))
+    p.start()
+    sigs = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    (l0, s0, n0, h0), (l1, s1, n1, h1) = sigs
+    assert n0 == n1 == 8
+    assert h0 > 0  # eager: buckets left from the backward hooks (captured backward passes keep the exchange outside)
+    for a, b in zip(l0 + s0, l1 + s1):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), sigs
