@@ -33,7 +33,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-REF_GFLOP_PER_SEQ_CYCLE = 31.10  # reference formulation, per sequence per cycle
+# GFLOP the reference's own formulation executes per sequence consumed per 8+1 cycle, by workload
+# (encoder, frames, ablated critic); shapes outside the table report no equivalent-work rate
+REF_GFLOP_PER_SEQ_CYCLE = {("default", 120, False): 31.10, ("wavegan", 120, False): 35.91,
+                           ("unet", 120, False): 52.12, ("unet", 300, True): 65.3}
 
 P3_DEFAULT = {"lr_gen": 2e-4, "lr_critic": 2e-4, "n_critic_steps": 8, "gamma": 10, "beta": 1, "eta": 0,
               "output_size": 69}
@@ -127,13 +130,41 @@ def self_launch(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # rank 0's stdout is drained by a thread (its pipe must not fill up while we poll); every child is polled: the
+    # first failing rank ends the others (they would otherwise sit in a rendezvous / all-reduce forever), and the
+    # whole run is bounded (M2D_BENCH_TIMEOUT seconds, default 3600)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("M2D_BENCH_TIMEOUT", "3600"))
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "ranks failed (rank, exit code): %s" % bad
+        elif time.monotonic() > deadline:
+            failed = "timed out; unfinished ranks: %s" % [r for r, c in enumerate(codes) if c is None]
+        else:
+            time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.exit("bench.py: ranks failed (rank, exit code): %s" % bad)
+    bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+    if failed is not None or bad:
+        sys.exit("bench.py: %s" % (failed or "ranks failed (rank, exit code): %s" % bad))
 
 
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -243,29 +274,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # A generator iteration runs on every 8th loop body. Whatever --steps / --warmup are, the timed window starts at
+    # a phase of that cycle where it holds ceil(steps / 8) generator iterations (never fewer than the nominal
+    # steps / 8: the number cannot flatter), and the roofline pass below restarts at the same phase, so both passes
+    # execute the same work. `whole_cycles` in the output is the phase-independent figure: the mean GPU time of
+    # every window of 8 consecutive timed steps (each holds exactly one generator iteration).
+    ncs = engine.n_critic_steps
+    want_gen = -(-args.steps // ncs)
+    phase = next(o for o in range(ncs) if sum(1 for i in range(o + 1, o + args.steps + 1) if i % ncs == 0) == want_gen)
     torch.manual_seed(1234 + rank)
+    engine.total_iterations = (phase - args.warmup) % ncs  # the warm-up ends exactly at `phase`
     for _ in range(args.warmup):
         engine.train_step(real, audio, slices, inputs_ready=ready)
     engine.flush()
+    assert engine.total_iterations % ncs == phase
     # host hygiene, as the train scripts do after building their engine: a generation-2 garbage collection over
     # the module graph stalls the launch thread for 60-80 ms (tools/spike_probe.py)
     runner.settle_garbage_collector()
     K = kernels.impl()
     barrier()
-    step_events = [] if os.environ.get("M2D_STEP_TIMES") else None  # dev aid: per-step GPU time to stderr
+    # one event per step on the main stream (asynchronous: no host sync) for the per-cycle figure
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_events[0].record()
+    for i in range(args.steps):
         engine.train_step(real, audio, slices, inputs_ready=ready)
-        if step_events is not None:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            step_events.append(ev)
+        step_events[i + 1].record()
     engine.flush()
     barrier()
     elapsed = time.perf_counter() - t0
-    if step_events:
-        print("step ms:", " ".join("%.2f" % a.elapsed_time(b) for a, b in zip(step_events, step_events[1:])),
-              file=sys.stderr)
+    step_ms = [a.elapsed_time(b) for a, b in zip(step_events, step_events[1:])]
+    if os.environ.get("M2D_STEP_TIMES"):  # dev aid: per-step GPU time to stderr
+        print("step ms:", " ".join("%.2f" % v for v in step_ms), file=sys.stderr)
+    whole_cycles = None
+    if args.steps >= ncs:
+        wins = [sum(step_ms[i:i + ncs]) for i in range(args.steps - ncs + 1)]
+        ms_cycle = sum(wins) / len(wins)
+        whole_cycles = {"ms_per_cycle": round(ms_cycle, 3), "ms_per_step": round(ms_cycle / ncs, 3),
+                        "value": round(ncs * args.batch * world / (ms_cycle * 1e-3), 2),
+                        "windows": len(wins), "generator_iterations_in_timed_steps": want_gen,
+                        "note": "mean GPU time (rank 0's stream events) of every window of %d consecutive timed steps "
+                                "= exactly one generator iteration each; `value` above is the contract's K steps / "
+                                "wall time, whose window holds ceil(K/%d) generator iterations" % (ncs, ncs)}
     # Per-launch HIP events for the roofline: a SECOND pass over the same K steps. Two event
     # records around each of the ~680 launches of a step cost ~8 % of wall time (measured:
     # 20.3 vs 18.7 ms per step), so they stay out of the region `value` is timed on; the kernels,
@@ -279,6 +329,7 @@ def main():
         # pass runs the two branches one after the other: each duration is the launch's own
         type(critic).overlap_branches = False
         engine.pipeline_generator = False  # likewise the generator forward: in line for the per-launch pass
+        engine.total_iterations = phase  # same place in the 8+1 cycle as the timed window: same work
         K.prof_begin()
         for _ in range(args.steps):
             engine.train_step(real, audio, slices)
@@ -310,6 +361,8 @@ def main():
                        "parallelism": "dp%d" % world, "backend": args.backend if world > 1 else None},
             "losses_last_step": last,
         }
+        if whole_cycles is not None:
+            out["whole_cycles"] = whole_cycles
         if prof is not None:
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
@@ -337,11 +390,15 @@ def main():
                 # memory-bound kernel families: algorithmic bytes / event time against 8.0 TB/s, over the
                 # launches that move >= 64 MB (smaller ones are launch-bound, listed under "small")
                 "hbm": hbm,
-                # the reference's own formulation executes 31.10 GFLOP per sequence consumed
-                # (SURVEY.md 8(d)); the engine skips work the reference discards, so this is
-                # an equivalent-work rate, not a kernel rate
-                "step_tflops_reference_formulation": round(REF_GFLOP_PER_SEQ_CYCLE * 1e9 * seqs / elapsed / 1e12, 2),
             }
+            # the reference's own formulation executes REF_GFLOP_PER_SEQ_CYCLE per sequence consumed (SURVEY.md
+            # 8(d), per workload); the engine skips work the reference discards, so this is an equivalent-work
+            # rate over whole cycles, not a kernel rate
+            ref_gf = REF_GFLOP_PER_SEQ_CYCLE.get((args.enc_type, args.frames, args.ablated))
+            if ref_gf is not None and whole_cycles is not None:
+                out["roofline"]["reference_formulation"] = {
+                    "gflop_per_seq_cycle": ref_gf,
+                    "step_tflops": round(ref_gf * 1e9 * whole_cycles["value"] / 1e12, 2)}
         default_cfg = (args.enc_type, args.frames, args.ablated) == ("default", 120, False)
         if not args.no_cpu_baseline and world == 1 and default_cfg:
             try:
