@@ -174,6 +174,17 @@ int m2d_tv_mean_fwd(const float* x, float* out, int B, int C, int T, long sb, lo
 int m2d_tv_mean_bwd(const float* x, const float* gout, float* dx, int B, int C, int T, long sb, long sc, long st,
                     void* stream);
 
+/* ---- evaluation metric + dataset scaling ------------------------------
+ * m2d_jerk_mean_fwd: losses.py:85-89 `jerkiness` (phase3/test.py:78-104) on a (B, C, T) tensor given by element
+ *   strides: sum over channels of the squared third time difference, mean over (B, T-3).
+ * m2d_affine_cols: y[r, c] = x[r, c] * scale[c] + shift[c]: sklearn MinMaxScaler.transform (scale_, min_) /
+ *   inverse_transform (1/scale_, -min_/scale_) as the reference's datasets apply it (utils.py:26-31,79-85;
+ *   phase2/train.py:192-193). y may alias x. */
+int m2d_jerk_mean_fwd(const float* x, float* out, int B, int C, int T, long sb, long sc, long st, void* ws,
+                      size_t ws_bytes, void* stream);
+int m2d_affine_cols(const float* x, const float* scale, const float* shift, float* y, size_t rows, int cols,
+                    void* stream);
+
 /* ---- U-Net encoder resampling (phase3/archis/default.py:235-245) --------------------------- */
 int m2d_maxpool2_fwd(const float* x, float* y, size_t rows, int L, void* stream);
 int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, int L, void* stream);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "m2d_l1_mean_bwd": (_I, [_F, _F, _F, _F, _S, _F]),
     "m2d_tv_mean_fwd": (_I, [_F, _F, _I, _I, _I, _L, _L, _L, _F, _S, _F]),
     "m2d_tv_mean_bwd": (_I, [_F, _F, _F, _I, _I, _I, _L, _L, _L, _F]),
+    "m2d_jerk_mean_fwd": (_I, [_F, _F, _I, _I, _I, _L, _L, _L, _F, _S, _F]),
+    "m2d_affine_cols": (_I, [_F, _F, _F, _F, _S, _I, _F]),
     "m2d_maxpool2_fwd": (_I, [_F, _F, _S, _I, _F]),
     "m2d_maxpool2_bwd": (_I, [_F, _F, _F, _S, _I, _F]),
     "m2d_upsample2_fwd": (_I, [_F, _F, _S, _I, _F]),

@@ -184,6 +184,39 @@ __global__ void __launch_bounds__(256) m2d_tv_bwd_kernel(const float* x, const f
   }
 }
 
+// jerkiness (losses.py:85-89): third finite difference along time of a (B, C, T) tensor given by element
+// strides, squared, summed over channels, mean over (B, T-3): sum_{b,c,t} d^2 / (B * (T - 3)).
+__global__ void __launch_bounds__(256) m2d_jerk_partial_kernel(const float* x, int B, int C, int T, long sb,
+                                                               long sc, long st, double* partial) {
+  __shared__ double sh[256];
+  const size_t total = (size_t)B * C * (T - 3);
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i % (size_t)(T - 3));
+    const size_t bc = i / (size_t)(T - 3);
+    const int c = (int)(bc % (size_t)C);
+    const int b = (int)(bc / (size_t)C);
+    const float* p = x + b * sb + c * sc + t * st;
+    // the reference's expression, left to right in fp32: x[t+3] - 3 x[t+2] + 3 x[t+1] - x[t]
+    // (separately rounded products and sums, as torch evaluates it: no contraction into FMAs)
+    const float d = __fsub_rn(__fadd_rn(__fsub_rn(p[3 * st], __fmul_rn(3.f, p[2 * st])), __fmul_rn(3.f, p[st])), p[0]);
+    s += (double)__fmul_rn(d, d);
+  }
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// y[r, c] = x[r, c] * scale[c] + shift[c] (MinMaxScaler.transform / inverse_transform of the reference's datasets,
+// utils.py:26-31,79-85: two separately rounded fp32 operations, like numpy's X *= scale; X += min)
+__global__ void __launch_bounds__(256) m2d_affine_cols_kernel(const float* x, const float* scale, const float* shift,
+                                                              float* y, size_t rows, int cols) {
+  const size_t total = rows * (size_t)cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % (size_t)cols);
+    y[i] = __fadd_rn(__fmul_rn(x[i], scale[c]), shift[c]);
+  }
+}
+
 // ---------------------------------------------------------------- pool / upsample
 // MaxPool1d(2,2): y[r, j] = max(x[r, 2j], x[r, 2j+1]), rows = B*C, Lout = L/2
 __global__ void __launch_bounds__(256) m2d_maxpool2_fwd_kernel(const float* x, float* y, size_t rows, int L,
@@ -355,6 +388,37 @@ int m2d_tv_mean_bwd(const float* x, const float* gout, float* dx, int B, int C, 
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 8.0 * (double)total, "tv_mean_bwd");
   hipLaunchKernelGGL(m2d_tv_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, gout, dx, B, C, T, sb, sc, st);
   M2D_CHECK_LAUNCH("m2d_tv_mean_bwd");
+  return M2D_OK;
+}
+
+// losses.py:85-89 jerkiness on a (B, C, T) tensor given by element strides (an evaluation metric of the
+// reference, phase3/test.py:78-104): out = sum over channels of the squared third difference, mean over (B, T-3).
+int m2d_jerk_mean_fwd(const float* x, float* out, int B, int C, int T, long sb, long sc, long st, void* ws,
+                      size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || T < 4) M2D_FAIL(M2D_ERR_ARG, "m2d_jerk_mean_fwd: bad shape (needs T >= 4)");
+  if (!ws || ws_bytes < m2d_reduce_workspace_bytes()) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_jerk_mean_fwd: workspace");
+  const size_t total = (size_t)B * C * (T - 3);
+  M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, 4.0 * (double)B * C * T, "jerk_mean_fwd");
+  const unsigned gx = grid_for(total);
+  hipLaunchKernelGGL(m2d_jerk_partial_kernel, dim3(gx), dim3(256), 0, stream, x, B, C, T, sb, sc, st, (double*)ws);
+  hipLaunchKernelGGL(m2d_finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, (int)gx,
+                     1.0 / ((double)B * (double)(T - 3)), out);
+  M2D_CHECK_LAUNCH("m2d_jerk_mean_fwd");
+  return M2D_OK;
+}
+
+// MinMaxScaler.transform (scale_, min_) / inverse_transform (1/scale_, -min_/scale_) over (rows, cols) features
+// (utils.py:26-31,79-85; phase3/test.py:92-101): y = x * scale[col] + shift[col]. In place when y == x.
+int m2d_affine_cols(const float* x, const float* scale, const float* shift, float* y, size_t rows, int cols,
+                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (cols <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_affine_cols: bad shape");
+  if (rows == 0) return M2D_OK;
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 8.0 * (double)rows * cols, "affine_cols");
+  hipLaunchKernelGGL(m2d_affine_cols_kernel, dim3(grid_for(rows * (size_t)cols)), dim3(256), 0, stream, x, scale,
+                     shift, y, rows, cols);
+  M2D_CHECK_LAUNCH("m2d_affine_cols");
   return M2D_OK;
 }
 

@@ -555,6 +555,30 @@ class HipKernels:
         _lib.check(rc, "m2d_tv_mean_bwd")
         return dx
 
+    # ---------------------------------------------------------------- evaluation metric, dataset scaling
+    def jerk_mean_fwd(self, x, B, C, T, sb, sc, st):
+        """jerkiness of the (B, C, T) view (element strides sb, sc, st) of storage `x` -> 0-dim."""
+        dev = _chk(x)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        h = _lib.lib()
+        ws = _ws(_ws_bytes('m2d_reduce_workspace_bytes', ), dev)
+        with _on(dev):
+            rc = h.m2d_jerk_mean_fwd(_ptr(x), _ptr(out), B, C, T, sb, sc, st, _ptr(ws), ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_jerk_mean_fwd")
+        return out
+
+    def affine_cols(self, x, scale, shift, out=None):
+        """x (..., cols) * scale[cols] + shift[cols] (MinMaxScaler transform / inverse); out may be x."""
+        dev = _chk(x, scale, shift, out)
+        cols = x.shape[-1]
+        assert scale.numel() == cols and shift.numel() == cols
+        y = torch.empty_like(x) if out is None else out
+        with _on(dev):
+            rc = _lib.lib().m2d_affine_cols(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), x.numel() // max(cols, 1), cols,
+                                            _stream(dev))
+        _lib.check(rc, "m2d_affine_cols")
+        return y
+
     # ---------------------------------------------------------------- U-Net resampling
     def maxpool2_fwd(self, x):
         dev = _chk(x)

@@ -56,3 +56,9 @@ def gradient_penalty(critic, bsize, real, fake, audio=None, is_seq=False, is_con
 def tv_loss(sequence):
     """Total-variation regulariser: mean |x[:, :, 1:] - x[:, :, :-1]| of a (B, C, T) tensor."""
     return ops.tv_mean(sequence)
+
+
+def jerkiness(sequence):
+    """Evaluation metric of the reference (losses.py:85-89, phase3/test.py:78-104): the squared third finite
+    difference along time of a (B, C, T) sequence, summed over channels, averaged over (B, T - 3)."""
+    return ops.jerk_mean(sequence)

@@ -648,6 +648,20 @@ def tv_mean(seq):
     return tv_mean(seq.contiguous())
 
 
+def jerk_mean(seq):
+    """losses.jerkiness of a (B, C, T) tensor (or permuted view of a dense (B, T, C) one): a metric, no gradient."""
+    B, C, T = seq.shape
+    seq = seq.detach()
+    if seq.dtype != torch.float32:
+        seq = seq.float()
+    if seq.is_contiguous():
+        return K().jerk_mean_fwd(seq, B, C, T, C * T, T, 1)
+    base = seq.permute(0, 2, 1)
+    if base.is_contiguous():
+        return K().jerk_mean_fwd(base, B, C, T, T * C, 1, C)
+    return jerk_mean(seq.contiguous())
+
+
 # --------------------------------------------------------------------------------------- U-Net resampling
 class _MaxPool2(Function):
     @staticmethod

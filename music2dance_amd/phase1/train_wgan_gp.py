@@ -23,6 +23,7 @@ def main(argv=None):
     ap.add_argument("-d", "--device", type=int, help="choose gpu id")
     ap.add_argument("-n", "--name", type=str, help="choose name of experiment")
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--folder", type=str, default=None, help="dataset folder (overrides the YAML's `folder:`)")
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--no-run-dir", action="store_true")
@@ -32,8 +33,15 @@ def main(argv=None):
     rank, world, local = dp.init_from_env()
     device = runner.pick_device(local if world > 1 else opts.device)
     cfg = runner.load_config(opts.config)
+    loader = None
     if not opts.synthetic:
-        raise SystemExit("the Music-to-Dance dataset pipeline is outside this engine (SURVEY.md 8(f)); use --synthetic")
+        # phase1/train_wgan-gp.py:24-26,71-72: MinMax-scaled still poses, a random subset sampler
+        from torch.utils.data import DataLoader, SubsetRandomSampler
+        from .. import data as D
+        print("Loading sticks and sequences datasets...")
+        dataset = D.StickDataset(runner.dataset_folder(cfg, opts.folder), normalize="minmax")
+        loader = DataLoader(dataset, batch_size=cfg["batch_size"], drop_last=True,
+                            sampler=SubsetRandomSampler(range(min(cfg["num_train"], len(dataset)))))
     logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
     np.random.seed(37)
     gen = Generator(cfg["latent_vector_size"], cfg["size"], cfg["output_size"], cfg["nblocks_gen"]).to(device)
@@ -53,9 +61,13 @@ def main(argv=None):
     done = False
     for epoch in range(cfg["num_epochs"]):
         gen.train()
-        for b in range(batches_per_epoch):
-            g = torch.Generator().manual_seed(1 + (epoch * batches_per_epoch + b) * world + rank)
-            real = torch.rand(B, 23, 3, generator=g).to(device)
+        def synthetic():
+            for b in range(batches_per_epoch):
+                g = torch.Generator().manual_seed(1 + (epoch * batches_per_epoch + b) * world + rank)
+                yield torch.rand(B, 23, 3, generator=g).to(device)
+
+        source = synthetic() if loader is None else (runner.staged((b,), device)[0][0] for b in loader)
+        for real in source:
             out = engine.train_step(real)
             it = engine.total_iterations
             if "loss_gen" in out:

@@ -22,6 +22,7 @@ def main(argv=None):
     ap.add_argument("-n", "--name", type=str, help="name experiment")
     ap.add_argument("-f", "--framework", type=str, default="wgangp", help="choose between `wgangp` and `gan`")
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--folder", type=str, default=None, help="dataset folder (overrides the YAML's `folder:`)")
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--log-every", type=int, default=1)
@@ -35,11 +36,22 @@ def main(argv=None):
     device = runner.pick_device(local if world > 1 else opts.device)
     cfg = runner.load_config(opts.config)
     torch.manual_seed(0)
-    if not opts.synthetic:
-        raise SystemExit("the Music-to-Dance dataset pipeline is outside this engine (SURVEY.md 8(f)); use --synthetic")
     ds = cfg["dataset"]
     stick_length = int(ds["seq_length"] * ds["video_rate"])
     batch_size = opts.batch_size or cfg["batch_size"]
+    loader = None
+    if not opts.synthetic:
+        # phase2/train.py:66-70,115-116: MinMax-scaled pose sequences, random crops, a random subset sampler
+        from torch.utils.data import DataLoader, SubsetRandomSampler
+        from .. import data as D
+        folder = runner.dataset_folder(cfg, opts.folder)
+        print("Loading sticks and sequences datasets...")
+        sticks = D.StickDataset(folder, normalize="minmax")
+        dataset = D.SequenceDataset(folder, ds, dance_types=cfg["dance_types"], scaler=sticks.scaler, withaudio=False)
+        stick_length = dataset.stick_length
+        loader = DataLoader(dataset, batch_size=batch_size, drop_last=True,
+                            collate_fn=lambda b: D.collate_fn(b, withaudio=False),
+                            sampler=SubsetRandomSampler(range(min(cfg["num_train"], len(dataset)))))
     logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
     gen = SequenceGenerator(cfg["input_vector_size"], cfg["latent_vector_size"], cfg["size"], cfg["output_size"],
                             cfg["nblocks_gen"], cfg["n_cells"], device)
@@ -56,9 +68,14 @@ def main(argv=None):
     done = False
     for epoch in range(cfg["num_epochs"]):
         gen.train()
-        for b in range(batches_per_epoch):
-            g = torch.Generator().manual_seed(1 + (epoch * batches_per_epoch + b) * world + rank)
-            real = torch.rand(batch_size, stick_length, cfg["output_size"], generator=g).to(device)
+        def synthetic():
+            for b in range(batches_per_epoch):
+                g = torch.Generator().manual_seed(1 + (epoch * batches_per_epoch + b) * world + rank)
+                yield torch.rand(batch_size, stick_length, cfg["output_size"], generator=g).to(device)
+
+        source = synthetic() if loader is None else (
+            runner.staged((b[0].float().reshape(b[0].size(0), stick_length, -1),), device)[0][0] for b in loader)
+        for real in source:
             out = engine.train_step(real)
             it = engine.total_iterations
             if "loss_gen" in out:

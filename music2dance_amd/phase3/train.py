@@ -36,6 +36,7 @@ def main(argv=None):
     ap.add_argument("-d", "--device", type=int, help="choose gpu id")
     ap.add_argument("-n", "--name", type=str, help="name experiment")
     ap.add_argument("--synthetic", action="store_true", help="random poses / audio of the dataset's shapes")
+    ap.add_argument("--folder", type=str, default=None, help="dataset folder (overrides the YAML's `folder:`)")
     ap.add_argument("--iterations", type=int, default=None, help="stop after this many loop bodies")
     ap.add_argument("--batch-size", type=int, default=None, help="override batch_size (per GPU)")
     ap.add_argument("--log-every", type=int, default=1)
@@ -48,13 +49,24 @@ def main(argv=None):
     device = runner.pick_device(local if world > 1 else opts.device)
     cfg = runner.load_config(opts.config)
     torch.manual_seed(0)
-    if not opts.synthetic:
-        raise SystemExit("the Music-to-Dance dataset pipeline is outside this engine (SURVEY.md 8(f)); use --synthetic")
-
     ds = cfg["dataset"]
     stick_length = int(ds["seq_length"] * ds["video_rate"])
     batch_size = opts.batch_size or cfg["batch_size"]
     logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
+    train_loader = val_loader = None
+    if not opts.synthetic:
+        # phase3/train.py:72-76,112-162: scaler fitted on all still poses, sequences + audio, seeded split,
+        # class-balanced samplers
+        from .. import data as D
+        from ..utils import slice_audio_batch
+        folder = runner.dataset_folder(cfg, opts.folder)
+        print("Loading sticks and sequences datasets...")
+        sticks = D.StickDataset(folder, normalize="minmax")
+        dataset = D.SequenceDataset(folder, ds, dance_types=cfg["dance_types"], scaler=sticks.scaler, withaudio=True)
+        dataset.truncate()
+        stick_length = dataset.stick_length
+        train_loader, val_loader, _ = D.make_loaders(dataset, batch_size, withaudio=True, logdir=logdir)
+        window, hop = int(cfg["window_size"] * dataset.aud_rate), dataset.ratio
     gen, critic = build(cfg, device, stick_length)
     engine = Phase3Engine(gen, critic, cfg, ablated=cfg["ablated"], sync_bn=opts.sync_bn)
     # seed 0 built identical weights on every rank; the in-loop host draws (generator noise,
@@ -68,9 +80,18 @@ def main(argv=None):
     np.random.seed(14)
     n_valid_steps = 1  # phase3/train.py:168
 
+    def loader_batches(loader):
+        for real_h, _, audio_h, _, _ in loader:
+            (real, audio), ready = runner.staged((real_h.float(), audio_h), device)
+            yield real, audio, slice_audio_batch(audio, window, hop, window - hop, lazy=True), ready
+
     def val_batches():
         # the reference's validation loader serves the held-out 20 % split as one batch
-        # (phase3/train.py:161); here: fixed held-out synthetic batches, disjoint seeds from training
+        # (phase3/train.py:161); synthetic runs: fixed held-out synthetic batches, disjoint seeds from training
+        if val_loader is not None:
+            for real, _, slices, _ in loader_batches(val_loader):
+                yield real, slices
+            return
         for v in range(opts.val_batches):
             real, _, slices = synthetic_phase3_batch(batch_size, stick_length, device, seed=-(1 + v * world + rank),
                                                      audio_rate=ds["audio_rate"], video_rate=ds["video_rate"],
@@ -83,12 +104,13 @@ def main(argv=None):
     e_val_loss = float("nan")
     for epoch in range(cfg["num_epochs"]):
         gen.train()
-        for b in range(batches_per_epoch):
-            # staged on the copy stream: the engine may start this batch's generator forward while the
-            # previous iteration's critic kernels are still running
-            real, audio, slices, ready = synthetic_phase3_batch(
-                batch_size, stick_length, device, seed=1 + (epoch * batches_per_epoch + b) * world + rank,
-                audio_rate=ds["audio_rate"], video_rate=ds["video_rate"], window_s=cfg["window_size"], with_event=True)
+        # staged on the copy stream: the engine may start this batch's generator forward while the
+        # previous iteration's critic kernels are still running
+        source = loader_batches(train_loader) if train_loader is not None else (
+            synthetic_phase3_batch(batch_size, stick_length, device, seed=1 + (epoch * batches_per_epoch + b) * world + rank,
+                                   audio_rate=ds["audio_rate"], video_rate=ds["video_rate"],
+                                   window_s=cfg["window_size"], with_event=True) for b in range(batches_per_epoch))
+        for real, audio, slices, ready in source:
             out = engine.train_step(real, audio, slices, inputs_ready=ready)
             it = engine.total_iterations
             if "loss_gen" in out:

@@ -1,9 +1,9 @@
 """Shared scaffolding of the three train scripts: YAML config, run folders, optional
 TensorBoard, checkpoints with the reference's file names, synthetic batches.
 
-The reference's dataset pipeline (JSON skeletons, wav loading, samplers: utils.py:15-194,
-phase3/train.py:114-162) is outside this engine's scope: the scripts
-run on `--synthetic` batches of the dataset's shapes, or on tensors a caller provides.
+The scripts run on `--synthetic` batches of the dataset's shapes, or - through music2dance_amd.data, the
+reference's dataset pipeline (utils.py:15-194, phase3/train.py:114-162) - on a Music-to-Dance-Motion-Synthesis
+folder (`folder:` of the YAML, or `--folder`).
 """
 import datetime
 import os
@@ -79,3 +79,30 @@ def dump_architectures(logdir, gen, critic):
 
 def save_state(module, path):
     torch.save(module.state_dict(), path)
+
+
+def dataset_folder(cfg, override=None):
+    """The dataset folder of a non-synthetic run (`--folder` or the YAML's `folder:` key); exits with the
+    reference's own situation spelled out when it is absent (the data is not distributed with either repo)."""
+    folder = override or cfg.get("folder")
+    if not folder or not os.path.isdir(folder):
+        raise SystemExit("dataset folder %r not found: pass --folder <Music-to-Dance-Motion-Synthesis-master> "
+                         "(or --synthetic for random batches of the dataset's shapes)" % (folder,))
+    return folder
+
+
+def staged(tensors, device):
+    """Host tensors of one loader batch -> device, on the copy stream; (device tensors, event after which they
+    are complete): what `train_step(..., inputs_ready=)` takes."""
+    from .layers import copy_stream
+    if torch.device(device).type != "cuda":
+        return [t.to(device) for t in tensors], None
+    cur = torch.cuda.current_stream(device)
+    cs = copy_stream(device)
+    with torch.cuda.stream(cs):
+        out = [t.to(device, non_blocking=True) for t in tensors]
+        ready = cs.record_event()
+    cur.wait_event(ready)
+    for t in out:
+        t.record_stream(cur)
+    return out, ready

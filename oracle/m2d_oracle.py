@@ -525,3 +525,11 @@ def p1_train_iterations(gen_sd, critic_sd, real, n_iters, rng_seed, nblocks=1, l
     gen_out = {k: v.detach() for k, v in g_params.items()}
     gen_out.update(g_buf)
     return trace, gen_out, {k: v.detach() for k, v in d_params.items()}
+
+
+# ------------------------------------------------------------------------------------------- evaluation metric
+def jerkiness(sequence):
+    """losses.py:85-89: squared third finite difference along time of (B, C, T), summed over channels,
+    mean over (B, T - 3)."""
+    d = sequence[:, :, 3:] - 3 * sequence[:, :, 2:-1] + 3 * sequence[:, :, 1:-2] - sequence[:, :, :-3]
+    return (d ** 2).sum(dim=1).mean()

@@ -270,6 +270,18 @@ class FakeKernels:
         dv[:, :, :-1] -= s
         return dx
 
+    def jerk_mean_fwd(self, x, B, C, T, sb, sc, st):
+        v = torch.as_strided(x, (B, C, T), (sb, sc, st))
+        d = v[:, :, 3:] - 3 * v[:, :, 2:-1] + 3 * v[:, :, 1:-2] - v[:, :, :-3]
+        return (d ** 2).sum(dim=1).mean()
+
+    def affine_cols(self, x, scale, shift, out=None):
+        y = x * scale + shift
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
     def maxpool2_fwd(self, x):
         return F.max_pool1d(x, 2, 2)
 

@@ -327,10 +327,114 @@ def case_init(R):
     save("init", **out)
 
 
+# ------------------------------------------------------------------------------ dataset side
+def _wav_stub(path, sr=None):
+    """stands in for librosa.load(path, sr=None) (librosa is absent): PCM16 -> float32 in [-1, 1), mono"""
+    from scipy.io import wavfile
+    rate, data = wavfile.read(path)
+    data = data.astype(np.float32) / 32768.0
+    if data.ndim > 1:
+        data = data.mean(axis=1)
+    return data, rate
+
+
+def case_data(R):
+    """Outputs of the reference's dataset code (utils.py:15-201,245-248,320-326; losses.py:85-89; the split block of
+    phase3/train.py:112-143 re-enacted) on a synthetic dataset folder written by music2dance_amd.data
+    .write_synthetic_dataset (same seed -> same files on the test box) and on small stored inputs."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from music2dance_amd.data import write_synthetic_dataset
+    U, Lz = R["utils"], R["losses"]
+    sys.modules["librosa"].load = _wav_stub
+    out = {}
+    rng = np.random.RandomState(5)
+    # jerkiness (losses.py:85-89), fp32 and fp64 inputs
+    seq = rng.rand(3, 69, 40).astype(np.float32)
+    out["jerk_in"] = seq
+    out["jerk_f32"] = Lz.jerkiness(torch.from_numpy(seq)).item()
+    out["jerk_f64"] = Lz.jerkiness(torch.from_numpy(seq).double()).item()
+    perm = torch.from_numpy(seq).permute(0, 2, 1).contiguous().permute(0, 2, 1)  # (B, T, C) storage viewed (B, C, T)
+    out["jerk_perm"] = Lz.jerkiness(perm).item()
+    # MinMaxScaler (sklearn) as StickDataset(normalize='minmax') applies it; one constant feature
+    X = rng.randn(50, 23, 3) * 3 + 1
+    X[:, 4, 1] = 2.5
+    path = os.path.join(tempfile.mkdtemp(), "sk.npy")
+    np.save(path, X)
+    sd = U.StickDataset(path, resume=True, normalize="minmax")
+    out["mm_in"] = X
+    out["mm_scaled"] = sd.skeletons
+    out["mm_scale"], out["mm_min"] = sd.scaler.scale_, sd.scaler.min_
+    out["mm_data_min"], out["mm_data_max"] = sd.scaler.data_min_, sd.scaler.data_max_
+    Y = rng.rand(7, 69)
+    out["mm_inv_in"] = Y
+    out["mm_inv"] = sd.scaler.inverse_transform(Y)
+    out["mm_item3"] = sd[3].numpy()
+    # the folder loaders + datasets on the synthetic folder
+    folder = write_synthetic_dataset(os.path.join(tempfile.mkdtemp(), "ds"), n_takes=6, seconds=6, seed=3)
+    sticks = U.StickDataset(folder, normalize="minmax")
+    cfg = {"audio_rate": 16000, "video_rate": 25, "seq_length": 4.8, "feat_size": 0.2}
+    ds = U.SequenceDataset(folder, cfg, dance_types=["W", "C", "R", "T"], scaler=sticks.scaler, withaudio=True)
+    ds.truncate()
+    order = np.argsort([os.path.basename(d) for d in ds.dirs])
+    out["ds_names"] = np.array([os.path.basename(ds.dirs[i]) for i in order])
+    out["ds_labels"] = np.array([int(ds.labels[i]) for i in order])
+    out["ds_frames"] = np.array([len(ds.sequences[i]) for i in order])
+    out["ds_samples"] = np.array([len(ds.musics[i]) for i in order])
+    out["ds_seq_sum"] = np.array([float(np.sum(ds.sequences[i])) for i in order])
+    out["ds_seq_abs"] = np.array([float(np.abs(ds.sequences[i]).sum()) for i in order])
+    out["ds_music_abs"] = np.array([float(np.abs(ds.musics[i].astype(np.float64)).sum()) for i in order])
+    out["ds_scaler_min"], out["ds_scaler_max"] = sticks.scaler.data_min_, sticks.scaler.data_max_
+    out["ds_n_sticks"] = len(sticks)
+    out["ds_stick_sum"] = float(np.sum(sticks.skeletons))
+    out["ds_lengths"] = np.array([ds.stick_length, ds.audio_length, ds.ratio])
+    # seeded crops (__getitem__ draws from numpy's global generator) of the takes in name order
+    crops_p, crops_a, starts = [], [], []
+    for j, i in enumerate(order):
+        np.random.seed(100 + j)
+        pose, music, label, d = ds[int(i)]
+        crops_p.append(float(pose.double().sum())); crops_a.append(float(music.double().abs().sum()))
+        np.random.seed(100 + j)
+        starts.append(U.get_positions(ds.sequences[int(i)], length=ds.stick_length)[0])
+    out["ds_crop_pose_sum"], out["ds_crop_audio_abs"], out["ds_crop_start"] = map(np.array, (crops_p, crops_a, starts))
+    # collate_fn on ragged samples (stored inputs), with and without audio
+    lens = [9, 14, 14, 5]
+    seqs = [rng.rand(n, 23, 3) for n in lens]
+    mus = [rng.randn(32).astype(np.float32) for _ in lens]
+    labs = [2, 0, 3, 1]
+    out["col_lens"], out["col_labels"] = np.array(lens), np.array(labs)
+    for j, sq in enumerate(seqs):
+        out["col_seq%d" % j] = sq
+        out["col_mus%d" % j] = mus[j]
+    batch = [(torch.from_numpy(sq), torch.from_numpy(m), torch.from_numpy(np.asarray(l)), "d%d" % j)
+             for j, (sq, m, l) in enumerate(zip(seqs, mus, labs))]
+    padded, lengths, musics, labels, dirs = U.collate_fn(list(batch))
+    out["col_padded"], out["col_lengths"], out["col_musics"] = npf(padded), np.array(lengths), npf(musics)
+    out["col_out_labels"], out["col_dirs"] = npf(labels), np.array(dirs)
+    padded2, lengths2, labels2, dirs2 = U.collate_fn([(b[0], b[2], b[3]) for b in batch], withaudio=False)
+    out["col2_padded_sum"], out["col2_dirs"] = float(padded2.double().sum()), np.array(dirs2)
+    # one_hot_encode
+    out["onehot"] = U.one_hot_encode(list("WCRTTRCW"))
+    # split + class-balanced weights: phase3/train.py:112-143 re-enacted (module-level code, not importable)
+    for n in (61, 8):
+        indices = list(range(n))
+        vsplit = int(np.floor(.2 * n)); tsplit = int(np.floor(.5 * vsplit))
+        np.random.seed(14)
+        np.random.shuffle(indices)
+        out["split%d_train" % n] = np.array(indices[vsplit:]); out["split%d_val" % n] = np.array(indices[tsplit:vsplit])
+        out["split%d_test" % n] = np.array(indices[:tsplit])
+    labels61 = np.array([i % 4 for i in range(61)]); labels61[::7] = 0
+    tr = out["split61_train"]
+    cnt = np.unique(labels61[tr], return_counts=True)[1]
+    out["w61_labels"], out["w61_train_weights"] = labels61, (1. / cnt)[labels61[tr]]
+    save("data", **out)
+
+
 def main():
     torch.set_num_threads(8)
     R = import_reference()
     case_init(R)
+    case_data(R)
     case_p1(R)
     case_p2(R)
     case_p3(R, "default", "id", False, trace=True)

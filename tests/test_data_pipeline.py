@@ -1,0 +1,116 @@
+"""Dataset side of the train scripts: music2dance_amd.data / losses.jerkiness against
+OUTPUTS of the reference's own code (tests/golden/data.npz, written by make_golden.py::case_data from
+utils.py:15-201,245-248,320-326, losses.py:85-89 and the split block of phase3/train.py:112-143).
+Host logic runs here; the two HIP kernels behind it (m2d_jerk_mean_fwd, m2d_affine_cols) are checked on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "data.npz"), allow_pickle=False)
+
+
+@pytest.fixture(params=["cpu-fake", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    from music2dance_amd import kernels
+    if request.param == "hip":
+        yield torch.device("cuda:0")
+        return
+    from tests.fake_backend import FakeKernels
+    prev = kernels.set_impl(FakeKernels())
+    yield torch.device("cpu")
+    kernels.set_impl(prev)
+
+
+def test_jerkiness_matches_reference(backend):
+    from music2dance_amd.losses import jerkiness
+    from oracle import m2d_oracle as O
+    seq = torch.from_numpy(G["jerk_in"]).to(backend)
+    want = float(G["jerk_f32"])
+    assert abs(float(jerkiness(seq)) - want) <= 2e-6 * abs(want)
+    # the generator's native (B, T, C) storage viewed as (B, C, T), as phase3/test.py:96 builds it
+    perm = seq.permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    assert abs(float(jerkiness(perm)) - float(G["jerk_perm"])) <= 2e-6 * abs(want)
+    # float64 input (scaler.inverse_transform output): computed in fp32 here, fp64 in the reference
+    assert abs(float(jerkiness(seq.double())) - float(G["jerk_f64"])) <= 2e-6 * abs(want)
+    assert abs(float(O.jerkiness(torch.from_numpy(G["jerk_in"]))) - want) <= 1e-6 * abs(want)
+
+
+def test_minmax_scaler_matches_sklearn_as_the_reference_uses_it(backend, tmp_path):
+    from music2dance_amd.data import StickDataset
+    path = str(tmp_path / "sk.npy")
+    np.save(path, G["mm_in"])
+    sd = StickDataset(path, resume=True, normalize="minmax")
+    for key, got in (("mm_scale", sd.scaler.scale_), ("mm_min", sd.scaler.min_), ("mm_data_min", sd.scaler.data_min_),
+                     ("mm_data_max", sd.scaler.data_max_), ("mm_scaled", sd.skeletons)):
+        assert np.array_equal(G[key], got), key  # same fp64 operations in the same order: bit-equal
+    assert np.array_equal(sd.scaler.inverse_transform(G["mm_inv_in"]), G["mm_inv"])
+    assert np.array_equal(sd[3].numpy(), G["mm_item3"])
+    # device forms (one kernel each): fp32 against the fp64 host result
+    x = torch.from_numpy(G["mm_in"].reshape(50, 69)).float().to(backend)
+    y = sd.scaler.transform_device(x)
+    assert np.abs(y.cpu().numpy() - G["mm_scaled"].reshape(50, 69)).max() <= 1e-5
+    back = sd.scaler.inverse_transform_device(y)
+    assert np.abs(back.cpu().numpy() - G["mm_in"].reshape(50, 69)).max() <= 1e-4
+    inv = sd.scaler.inverse_transform_device(torch.from_numpy(G["mm_inv_in"]).float().to(backend))
+    assert np.abs(inv.cpu().numpy() - G["mm_inv"]).max() <= 1e-4
+    z = x.clone()
+    assert sd.scaler.transform_device(z, out=z) is z and torch.equal(z, y)  # in place
+
+
+def test_folder_loaders_and_datasets_match_reference(tmp_path):
+    from music2dance_amd import data as D
+    folder = D.write_synthetic_dataset(str(tmp_path / "ds"), n_takes=6, seconds=6, seed=3)
+    sticks = D.StickDataset(folder, normalize="minmax")
+    cfg = {"audio_rate": 16000, "video_rate": 25, "seq_length": 4.8, "feat_size": 0.2}
+    ds = D.SequenceDataset(folder, cfg, dance_types=["W", "C", "R", "T"], scaler=sticks.scaler, withaudio=True)
+    ds.truncate()
+    order = np.argsort([os.path.basename(d) for d in ds.dirs])
+    assert [os.path.basename(ds.dirs[i]) for i in order] == list(G["ds_names"])
+    assert [int(ds.labels[i]) for i in order] == list(G["ds_labels"])
+    assert [len(ds.sequences[i]) for i in order] == list(G["ds_frames"])
+    assert [len(ds.musics[i]) for i in order] == list(G["ds_samples"])
+    assert np.allclose([np.sum(ds.sequences[i]) for i in order], G["ds_seq_sum"], rtol=1e-12, atol=0)
+    assert np.allclose([np.abs(ds.sequences[i]).sum() for i in order], G["ds_seq_abs"], rtol=1e-12, atol=0)
+    assert np.allclose([np.abs(ds.musics[i].astype(np.float64)).sum() for i in order], G["ds_music_abs"], rtol=1e-12)
+    assert np.array_equal(sticks.scaler.data_min_, G["ds_scaler_min"]) and np.array_equal(sticks.scaler.data_max_, G["ds_scaler_max"])
+    assert len(sticks) == int(G["ds_n_sticks"]) and abs(np.sum(sticks.skeletons) - float(G["ds_stick_sum"])) <= 1e-8
+    assert [ds.stick_length, ds.audio_length, ds.ratio] == list(G["ds_lengths"])
+    for j, i in enumerate(order):
+        np.random.seed(100 + j)
+        pose, music, label, d = ds[int(i)]
+        assert pose.shape == (120, 23, 3) and music.shape == (76800,) and music.dtype == torch.float32
+        assert abs(float(pose.double().sum()) - G["ds_crop_pose_sum"][j]) <= 1e-9
+        assert abs(float(music.double().abs().sum()) - G["ds_crop_audio_abs"][j]) <= 1e-9
+        np.random.seed(100 + j)
+        assert D.get_positions(ds.sequences[int(i)], length=120)[0] == int(G["ds_crop_start"][j])
+    # and the loaders built from it hand the engine batches of the shapes phase3/train.py:186-194 expects
+    train_loader, val_loader, (tr, va, te) = D.make_loaders(ds, batch_size=3, logdir=None)
+    assert len(tr) + len(va) + len(te) == 6
+    real, lengths, audio, label, dirs = next(iter(train_loader))
+    assert real.shape == (3, 120, 23, 3) and audio.shape == (3, 76800) and lengths == [120] * 3
+
+
+def test_collate_fn_matches_reference():
+    from music2dance_amd.data import collate_fn
+    lens, labs = list(G["col_lens"]), list(G["col_labels"])
+    batch = [(torch.from_numpy(G["col_seq%d" % j]), torch.from_numpy(G["col_mus%d" % j]),
+              torch.from_numpy(np.asarray(labs[j])), "d%d" % j) for j in range(len(lens))]
+    padded, lengths, musics, labels, dirs = collate_fn(list(batch))
+    assert padded.dtype == torch.float32 and np.array_equal(padded.numpy(), G["col_padded"])
+    assert lengths == list(G["col_lengths"]) and list(dirs) == list(G["col_dirs"])
+    assert np.array_equal(musics.numpy(), G["col_musics"]) and np.array_equal(labels.numpy(), G["col_out_labels"])
+    p2, l2, lab2, d2 = collate_fn([(b[0], b[2], b[3]) for b in batch], withaudio=False)
+    assert abs(float(p2.double().sum()) - float(G["col2_padded_sum"])) <= 1e-9 and list(d2) == list(G["col2_dirs"])
+
+
+def test_label_encoding_split_and_sampler_weights_match_reference():
+    from music2dance_amd import data as D
+    assert np.array_equal(D.one_hot_encode(list("WCRTTRCW")), G["onehot"])
+    for n in (61, 8):
+        tr, va, te = D.split_indices(n)
+        assert tr == list(G["split%d_train" % n]) and va == list(G["split%d_val" % n]) and te == list(G["split%d_test" % n])
+    tr = D.split_indices(61)[0]
+    assert np.array_equal(D.class_balanced_weights(G["w61_labels"], tr), G["w61_train_weights"])

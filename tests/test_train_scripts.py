@@ -122,6 +122,35 @@ def test_phase1_train_script_runs(dev, tmp_path, monkeypatch):
     assert eng.total_iterations == 5 and "loss_gen" in eng.last
 
 
+# ------------------------------------------------------------------------------ dataset path
+def test_train_scripts_run_on_a_dataset_folder(dev, tmp_path, monkeypatch):
+    """Without --synthetic the scripts go through music2dance_amd.data (the reference's StickDataset /
+    SequenceDataset / collate_fn / seeded split + class-balanced samplers) on a folder in the dataset's on-disk
+    format; a missing folder exits with a message instead of a traceback."""
+    from music2dance_amd.data import write_synthetic_dataset
+    from music2dance_amd.phase1 import train_wgan_gp as T1
+    from music2dance_amd.phase2 import train as T2
+    from music2dance_amd.phase3 import train as T3
+    monkeypatch.chdir(tmp_path)
+    folder = write_synthetic_dataset(str(tmp_path / "ds"), n_takes=10, seconds=6, seed=1)
+    c3 = _cfg(tmp_path, "phase3/configs/ablated.yaml", batch_size=2, num_epochs=1, n_critic_steps=2, folder=folder)
+    eng = T3.main(["-c", c3, "-d", "0", "-n", "d3"])
+    assert eng.total_iterations == 4 and "loss_gen" in eng.last_full  # 8 training takes / batch 2
+    assert torch.isfinite(T3.LAST_LOG.last["l1_loss_val"])
+    run = glob.glob(str(tmp_path / "runs" / "*_d3"))[0]
+    split = yaml.safe_load(open(run + "/trainvaltest_samples.json"))
+    assert sorted(len(v) for v in split.values()) == [1, 1, 8]
+    c2 = _cfg(tmp_path, "phase2/configs/default.yaml", batch_size=2, num_train=6, num_epochs=1, n_critic_steps=2)
+    eng = T2.main(["-c", c2, "-d", "0", "-n", "d2", "--no-run-dir", "--folder", folder])
+    assert eng.total_iterations == 3
+    c1 = _cfg(tmp_path, "phase1/configs/b2l50s32.yaml", batch_size=8, num_train=40, num_epochs=1)
+    eng = T1.main(["-c", c1, "-d", "0", "-n", "d1", "--no-run-dir", "--folder", folder])
+    assert eng.total_iterations == 5
+    c3 = _cfg(tmp_path, "phase3/configs/ablated.yaml", batch_size=2, num_epochs=1, n_critic_steps=2)  # (same file name)
+    with pytest.raises(SystemExit, match="dataset folder"):
+        T3.main(["-c", c3, "-d", "0", "-n", "d3", "--folder", str(tmp_path / "nope")])
+
+
 # ------------------------------------------------------------------------------ MultiStepLR
 def _lr_closed_form(lr0, gen_iters, milestones=(10000, 35000, 50000), gamma=0.8):
     return lr0 * gamma ** sum(1 for m in milestones if gen_iters >= m)
