@@ -134,13 +134,14 @@ def test_p2_trace():
     fx = load("p2")
     gsd, dsd = filled(fx, "gen", 3000), filled(fx, "critic", 4000)
     real = P.poses(2, 120, seed=32)
-    tr, g_out, d_out = O.p2_train_iterations(gsd, dsd, real, 8, 8)
+    lr = float(fx["trace_lr"])  # 5e-5: see make_golden.py::case_p2 (at the config's 5e-4 the trace diverges)
+    tr, g_out, d_out = O.p2_train_iterations(gsd, dsd, real, 8, 8, lr=lr)
     for k in ("loss_critic", "gp", "w_dist", "loss_gen"):
-        close(np.array(tr[k]), fx["trace_" + k], 1e-3, 2e-2)
+        close(np.array(tr[k]), fx["trace_" + k], 1e-3, 2e-3)
     close(np.array(tr["loss_critic"][:1]), fx["trace_loss_critic"][:1], 2e-5)
     assert tr["g_step"] == [0] * 7 + [1]
-    sums_close({k: g_out[k] for k in gsd}, fx["gen_final_sum"], adam_lr=5e-4, adam_steps=1)
-    sums_close({k: d_out[k] for k in dsd}, fx["critic_final_sum"], adam_lr=5e-4, adam_steps=8)
+    sums_close({k: g_out[k] for k in gsd}, fx["gen_final_sum"], adam_lr=lr, adam_steps=1)
+    sums_close({k: d_out[k] for k in dsd}, fx["critic_final_sum"], adam_lr=lr, adam_steps=8)
 
 
 # ------------------------------------------------------------------------------ phase 3

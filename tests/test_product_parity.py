@@ -30,9 +30,11 @@ from tests.golden import patterns as P
 # oracle run in fp64 tracks its own fp32 run to 1e-6 over these 8 steps, so nothing here is
 # "amplification": round 1's 2e-2 was simply loose.
 TRACE_RTOL = 2e-3
-# Phase 2 (WGAN-LP): product and oracle agree with each other but BOTH sit 1.1e-2 from the reference at
-# one of the 8 iterations - the LP term max(0, |g| - 1)^2 has a kink that a 1e-7 difference can cross.
-TRACE_RTOL_P2 = 2e-2
+# Phase 2 (round 3): the fixture's trace runs at lr 5e-5 instead of the config's 5e-4. At 5e-4 the closed-form critic
+# blows up inside the 8 steps (penalty 0.03 -> 235) and loss_critic at step 6 is the difference of two numbers
+# near 2 000: every fp32 implementation, the oracle included, then sits 4e-3 / 1.1e-2 from the reference (round 2
+# bounded that trace at 2e-2 and blamed the LP kink; it was cancellation on a diverging run). Same loop, same bound
+# as phases 1 and 3 now.
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -225,7 +227,8 @@ def test_p2_trace(dev):
     gen = fill(p2.SequenceGenerator(50, 50, 256, 69, 2, 3, "cpu"), fx, "gen", 3000).to(dev)
     critic = fill(p2.SequenceDiscriminator(69, 128, 120, 25, 3, "cpu"), fx, "critic", 4000).to(dev)
     real = P.poses(2, 120, seed=32).to(dev)
-    cfg = {"lr_gen": 5e-4, "lr_critic": 5e-4, "n_critic_steps": 8, "gamma": 10, "eta": 50, "input_vector_size": 50}
+    lr = float(fx["trace_lr"])  # 5e-5: see make_golden.py::case_p2 (at the config's 5e-4 the trace diverges)
+    cfg = {"lr_gen": lr, "lr_critic": lr, "n_critic_steps": 8, "gamma": 10, "eta": 50, "input_vector_size": 50}
     eng = Phase2Engine(gen, critic, cfg)
     torch.manual_seed(8)
     tr = {"loss_critic": [], "gp": [], "w_dist": [], "loss_gen": []}
@@ -236,11 +239,11 @@ def test_p2_trace(dev):
                 tr[k].append(out[k].item())
     eng.flush()
     for k in tr:
-        close(np.array(tr[k]), fx["trace_" + k], 1e-3, TRACE_RTOL_P2)
+        close(np.array(tr[k]), fx["trace_" + k], 1e-3, TRACE_RTOL)
     close(np.array(tr["loss_critic"][:1]), fx["trace_loss_critic"][:1], 1e-4)
     assert len(tr["loss_gen"]) == 1
-    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=5e-4, adam_steps=1, bn_biases=True)
-    sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=5e-4, adam_steps=8)
+    sums_close(gen.state_dict(), fx["gen_final_sum"], adam_lr=lr, adam_steps=1, bn_biases=True)
+    sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=lr, adam_steps=8)
 
 
 # ------------------------------------------------------------------------------ phase 3
