@@ -69,6 +69,44 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
 int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
                           int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
                           void* ws, size_t ws_bytes, void* stream);
+/* ---- the critic iteration as ONE hand-scheduled pass (round 3; music2dance_amd/critic_step.py) ---------------
+ * The reference runs three critic forwards and three autograd passes per iteration (phase3/train.py:204-216,
+ * losses.py:28-44). Scheduled by hand, the pose branch sees ONE batch of 3B rows [interpolated | real | fake], the
+ * first backward of the penalty and the loss backward travel together, and every weight gradient of a layer comes
+ * from one launch. The entry points below are what that schedule needs on top of the three conv ops:
+ *  - m2d_conv1d_fwd_sum: two outputs, y = out_mask * act(conv + bias) and sum_out = y + residual (a TemporalBlock's
+ *    second conv, phase3/archis/default.py:207-210: relu(conv) is the backward mask, x + relu(conv) the next input).
+ *    m2d_conv1d_fwd itself applies out_mask BEFORE its residual (out = act'(y) * conv(g) + skip: the forward-mode
+ *    tangent of a skip block).
+ *  - m2d_conv1d_bwd_data_res: dx = out_mask * (conv^T(dy) + residual) - the skip connection's gradient is added in
+ *    the epilogue instead of by an accumulation pass.
+ *  - m2d_conv1d_bwd_weight_from: the bias gradient sums over samples [bias_from_sample, B) only, so rows that pair
+ *    second-order operands (no bias term) can share the launch with ordinary (x, dy) rows.
+ *  - m2d_gemm_ld: m2d_gemm on sub-matrices of wider buffers (row pitches lda / ldb / ldc in elements, 0 = dense;
+ *    a_mask shares lda, out_mask shares ldc): the (B, 200) concatenated code of phase3/archis/default.py:266-269
+ *    is written / read in place.
+ *  - m2d_pose_pack3: (3B, C, T) = [alpha*real + (1-alpha)*fake | real^T | fake^T] from real (B, T, C) and the
+ *    generator's rows (B*T, C): phase3/train.py:196-199 + losses.py:13-25 in one LDS-staged transpose.
+ *  - m2d_wgan_critic_loss: out[0..2] = (E[D(fake)] - E[D(real)] + gamma*gp, gp, E[D(fake)] - E[D(real)]) from the
+ *    (3B,) scores and the penalty term(s) (phase3/train.py:210-212). */
+int m2d_conv1d_fwd_sum(const float* x, const float* w, const float* w_packed, const float* bias, float* y,
+                       float* sum_out, int B, int Cin, int L, int Cout, int ks, int stride, int pad, int act,
+                       float slope, const float* residual, const float* out_mask, float out_mask_slope, void* ws,
+                       size_t ws_bytes, void* stream);
+int m2d_conv1d_bwd_data_res(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
+                            int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                            const float* residual, const float* out_mask, float out_mask_slope, void* ws,
+                            size_t ws_bytes, void* stream);
+int m2d_conv1d_bwd_weight_from(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
+                               int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                               int bias_from_sample, void* ws, size_t ws_bytes, void* stream);
+int m2d_gemm_ld(int mode, const float* a, int lda, const float* b, int ldb, const float* bias, float* c, int ldc,
+                int M, int N, int K, int act, float slope, const float* a_mask, float a_mask_slope,
+                const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream);
+int m2d_pose_pack3(const float* real, const float* fake, const float* alpha, float* out, int B, int T, int C,
+                   void* stream);
+int m2d_wgan_critic_loss(const float* scores, int B, const float* pen0, const float* pen1, float gamma, float* out,
+                         void* stream);
 /* Audio slicing fused into the first encoder conv (reference: utils.slice_audio_batch, utils.py:329-353,
  * then Conv1d(1, Cout, ...) on the (B*T, 1, window) slices, phase3/archis/default.py:27-28,64,90,117):
  * the windows are read in place from the padded track (B, S) - window t of track b is

@@ -1,0 +1,316 @@
+"""The critic iteration as ONE hand-scheduled pass over the HIP kernels (no autograd tape).
+
+The reference's critic iteration (phase3/train.py:204-216, phase2/train.py:146-155) is three critic
+forwards (interpolated / real / fake poses) and three autograd passes (the penalty's first backward with
+create_graph, its double backward, the loss backward), losses.py:28-44. The critics are piecewise linear
+(conv / linear + ReLU, 'id' or 'relu' heads), so every one of those passes is the same linear operator chain
+with fixed activation masks, and the whole iteration can be scheduled by hand:
+
+  forward        pose branch ONCE over 3B rows [interpolated | real | fake] (m2d_pose_pack3 writes them
+                 channels-first from the loader's (B, T, 69) poses and the generator's rows); audio branch
+                 once over B rows (the audio is never interpolated: SURVEY.md A.6); head over 3B rows.
+  backward-data  ONE chain for the pose branch: row cotangents 1 (interpolated rows: this IS the penalty's first
+                 backward, d score / d input), -1/B (real), +1/B (fake: the loss backward). The skip
+                 connections' gradients are added in the conv epilogues (m2d_conv1d_bwd_data_res).
+  penalty        per-sample norms of the interpolated rows' input gradient (+ the audio term), loss scalars.
+  tangent        the penalty's double backward is the forward-mode tangent G = d pen / d v pushed through the
+                 linearised net: conv_fwd(G) with the forward's masks, written IN PLACE over the interpolated
+                 rows of the saved activations (nothing reads those rows afterwards).
+  weight grads   dW_n = correlate(x~_{n-1}, h_n) over all 3B rows in ONE launch per layer: rows [0, B) pair
+                 (tangent, first-backward gradient) - the second-order term -, rows [B, 3B) pair (activation,
+                 loss gradient) - the ordinary term. Bias gradients sum over the ordinary rows only
+                 (m2d_conv1d_bwd_weight_from). No gradient-accumulation adds, no concatenations, no transposes.
+
+Same arithmetic as the autograd path of losses.gradient_penalty + critic.score_pair (tests compare the two
+gradient for gradient); ~100 launches per iteration instead of ~380. Heads with `activ: tanh` are not piecewise
+linear: `supports()` is False for them and the engines keep the autograd path.
+"""
+import torch
+
+from . import kernels, ops
+
+ACT_NONE, ACT_RELU = ops.ACT_NONE, ops.ACT_RELU
+
+
+def K():
+    return kernels.impl()
+
+
+def _conv_params(conv):
+    return conv.weight, conv.bias, conv.stride[0], conv.padding[0]
+
+
+class CriticStep:
+    """critic: phase3 SequenceDiscriminator / AblatedSequenceDiscriminator or phase2 SequenceDiscriminator."""
+
+    @staticmethod
+    def supports(critic):
+        stick = getattr(critic, "stick_d", critic)
+        if not hasattr(stick, "conv1") or not hasattr(stick, "blocks"):
+            return False
+        for branch in (stick, getattr(critic, "audio_d", None)):
+            if branch is not None and getattr(branch, "_head_tanh", False):
+                return False
+        return True
+
+    def __init__(self, critic, gamma, lp=False):
+        assert self.supports(critic)
+        self.critic = critic
+        self.gamma = float(gamma)
+        self.lp = bool(lp)
+        self.stick = getattr(critic, "stick_d", critic)
+        self.audio = getattr(critic, "audio_d", None)
+        self.has_head = hasattr(critic, "fc1")
+        self.fconv = self.stick.fconv if hasattr(self.stick, "fconv") else self.stick.lastconv
+        self.head_act = int(getattr(self.stick, "_head_act", ACT_NONE))
+        self._const = {}
+        # the pose branch's launches are small (they leave most CUs idle between dependent kernels): they run on a
+        # side stream underneath the audio branch's large convolutions, section by section
+        self.overlap = self.audio is not None and getattr(type(critic), "overlap_branches", True)
+        self._side = None
+
+    # ------------------------------------------------------------------ helpers
+    def _constants(self, B, dev):
+        key = (B, str(dev))
+        c = self._const.get(key)
+        if c is None:
+            cs = torch.cat((torch.ones(B), torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B))).view(3 * B, 1)
+            c = self._const[key] = (cs.to(dev), torch.tensor(self.gamma, dtype=torch.float32).to(dev))
+        return c
+
+    def _fork(self, dev):
+        """-> (side stream or None, main stream); the side stream starts behind everything queued on main"""
+        if not self.overlap or dev.type != "cuda":
+            return None, None
+        if self._side is None:
+            # the critic's own pose-branch stream (its autograd path forks the same way): packed weight images are
+            # cached per (weight, stream)
+            if getattr(self.critic, "_stick_stream", None) is None:
+                self.critic._stick_stream = torch.cuda.Stream(device=dev)
+                self.critic._joins = {}
+            self._side = self.critic._stick_stream
+        cur = torch.cuda.current_stream(dev)
+        self._side.wait_stream(cur)
+        return self._side, cur
+
+    @staticmethod
+    def _join(side, cur, *tensors):
+        if side is None:
+            return
+        cur.wait_stream(side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cur)
+
+    class _On:
+        def __init__(self, stream):
+            self.ctx = torch.cuda.stream(stream) if stream is not None else None
+
+        def __enter__(self):
+            if self.ctx is not None:
+                self.ctx.__enter__()
+
+        def __exit__(self, *exc):
+            if self.ctx is not None:
+                return self.ctx.__exit__(*exc)
+            return False
+
+    # ------------------------------------------------------------------ the pass
+    @torch.no_grad()
+    def run(self, real, fake_rows, audio=None, alpha=None, on_grads=None):
+        """real: (B, T, C) poses [any view of B*T*C], fake_rows: (B*T, C) generator rows (no graph), audio:
+        (B, 1, S) for the two-branch critic, alpha: (B, 1) or (B,) interpolation weights on the device.
+        Sets p.grad of every critic parameter (they must be None on entry: the engines zero with set_to_none);
+        on_grads: called whenever further gradients are in place (GradExchange.poll).
+        -> {"loss_critic", "gp", "w_dist"} (0-dim device tensors)."""
+        k = K()
+        st, au = self.stick, self.audio
+        dev = fake_rows.device
+        C = st.conv1.weight.shape[1]
+        B = real.size(0)
+        T = real.numel() // (B * C)
+        R = 3 * B
+        cs, gamma_t = self._constants(B, dev)
+        nb = len(st.blocks)
+        w1, b1, _, pad1 = _conv_params(st.conv1)
+        CH = w1.shape[0]
+        Cc = self.fconv.weight.shape[0]
+        fw2d = self.fconv.weight.view(Cc, CH * T)
+
+        # ---------------------------------------------------------------- forward
+        side, cur = self._fork(dev)
+        with self._On(side):
+            X3 = k.pose_pack3(real.reshape(B, T, C), fake_rows, alpha.reshape(B))
+            a = [k.conv1d_fwd(X3, w1, b1, 1, pad1, ACT_RELU)]
+            p, q = [], []
+            for blk in st.blocks:
+                wa, ba, _, pa = _conv_params(blk.conv1)
+                wb, bb, _, pb = _conv_params(blk.conv2)
+                p.append(k.conv1d_fwd(a[-1], wa, ba, 1, pa, ACT_RELU))
+                qk, ak = k.conv1d_fwd(p[-1], wb, bb, 1, pb, ACT_RELU, residual=a[-1],
+                                      sum_out=torch.empty_like(a[-1]))
+                q.append(qk)
+                a.append(ak)
+        E = Cc + (au.l6.weight.shape[0] if au is not None else 0)
+        e = torch.empty((R, E), dtype=torch.float32, device=dev)
+        if au is not None:
+            layers = [au.l1, au.l2, au.l3, au.l4, au.l5]
+            Y, x = [], audio
+            for conv in layers:
+                w, b, s_, pd = _conv_params(conv)
+                Lo = kernels.conv_out_len(x.shape[2], w.shape[2], s_, pd)
+                buf = torch.empty((2 * B, w.shape[0], Lo), dtype=torch.float32, device=dev)
+                x = k.conv1d_fwd(x, w, b, s_, pd, ACT_RELU, out=buf[B:])
+                Y.append(buf)
+            Ca = au.l6.weight.shape[0]
+            l6w2d = au.l6.weight.view(Ca, -1)
+            k.gemm_ld(0, Y[-1][B:].view(B, -1), l6w2d, au.l6.bias, self.head_act, out=e[0:B, Cc:])
+            e.view(3, B, E)[1:, :, Cc:] = e[0:B, Cc:]
+        with self._On(side):
+            k.gemm_ld(0, a[-1].view(R, CH * T), fw2d, self.fconv.bias, self.head_act, out=e[:, :Cc])
+        self._join(side, cur, e)
+
+        # ---------------------------------------------------------------- head forward + first backward
+        if self.has_head:
+            fc1, fc2 = self.critic.fc1, self.critic.fc2
+            z = k.gemm(0, e, fc1.weight, fc1.bias, ACT_RELU)
+            s = k.gemm(0, z, fc2.weight, fc2.bias)
+            dzp = k.gemm(1, cs, fc2.weight, out_mask=z)            # (R, 128), multiplied by relu'(z)
+            de_s = k.gemm_ld(1, dzp, fc1.weight[:, :Cc])           # (R, Cc)
+            de_a = k.gemm_ld(1, dzp, fc1.weight[:, Cc:]) if au is not None else None
+        else:
+            s, dzp, de_s, de_a = e, None, cs, None
+        if self.head_act == ACT_RELU:
+            de_s = de_s * (e[:, :Cc] > 0)
+            if de_a is not None:
+                de_a = de_a * (e[:, Cc:] > 0)
+
+        # ---------------------------------------------------------------- backward-data chains
+        side, cur = self._fork(dev)
+        with self._On(side):
+            da = [None] * (nb + 1)
+            dp = [None] * nb
+            da[nb] = k.gemm(1, de_s, fw2d).view(R, CH, T)
+            for i in range(nb - 1, -1, -1):
+                blk = st.blocks[i]
+                wa, _, _, pa = _conv_params(blk.conv1)
+                wb, _, _, pb = _conv_params(blk.conv2)
+                dp[i] = k.conv1d_bwd_data(da[i + 1], wb, T, 1, pb, dy_mask=q[i], out_mask=p[i])
+                da[i] = k.conv1d_bwd_data(dp[i], wa, T, 1, pa, residual=da[i + 1],
+                                          out_mask=a[0] if i == 0 else None)
+            if nb == 0:
+                da[0] = da[0] * (a[0] > 0)
+            v_pose = k.conv1d_bwd_data(da[0][0:B], w1, T, 1, pad1)
+            pen_p, norms_p = k.gp_penalty_fwd(v_pose.view(B, -1), self.lp)
+        v_audio = pen_a = None
+        if au is not None:
+            ca2 = torch.empty((2 * B, Ca), dtype=torch.float32, device=dev)
+            ca2[0:B] = de_a[0:B]
+            torch.add(de_a[B:2 * B], de_a[2 * B:], out=ca2[B:])
+            HD = [None] * 5
+            HD[4] = torch.empty_like(Y[4])
+            y5 = Y[4][B:].view(B, -1)
+            k.gemm(1, ca2[0:B], l6w2d, out_mask=y5, out=HD[4][0:B].view(B, -1))
+            k.gemm(1, ca2[B:], l6w2d, out_mask=y5, out=HD[4][B:].view(B, -1))
+            for n in range(4, 0, -1):
+                w, _, s_, pd = _conv_params(layers[n])
+                HD[n - 1] = torch.empty_like(Y[n - 1])
+                Lin = Y[n - 1].shape[2]
+                for half in (slice(0, B), slice(B, 2 * B)):
+                    k.conv1d_bwd_data(HD[n][half], w, Lin, s_, pd, out_mask=Y[n - 1][B:], out=HD[n - 1][half])
+            w, _, s_, pd = _conv_params(layers[0])
+            v_audio = k.conv1d_bwd_data(HD[0][0:B], w, audio.shape[2], s_, pd)
+            pen_a, norms_a = k.gp_penalty_fwd(v_audio.view(B, -1), False)
+        self._join(side, cur, pen_p, v_pose)
+
+        # ---------------------------------------------------------------- loss scalars, tangent seeds
+        losses = k.wgan_critic_loss(s.view(-1), B, pen_p, pen_a, self.gamma)
+        side, cur = self._fork(dev)
+        with self._On(side):
+            # G = gamma * d pen / d v over the interpolated rows of X3 (in place: those poses are not read again)
+            k.gp_penalty_bwd(v_pose.view(B, -1), norms_p, gamma_t, self.lp, out=X3[0:B].view(B, -1))
+            # ------------------------------------------------------------ tangent through the pose branch
+            k.conv1d_fwd(X3[0:B], w1, None, 1, pad1, ACT_NONE, out_mask=a[0][0:B], out=a[0][0:B])
+            for i, blk in enumerate(st.blocks):
+                wa, _, _, pa = _conv_params(blk.conv1)
+                wb, _, _, pb = _conv_params(blk.conv2)
+                k.conv1d_fwd(a[i][0:B], wa, None, 1, pa, ACT_NONE, out_mask=p[i][0:B], out=p[i][0:B])
+                k.conv1d_fwd(p[i][0:B], wb, None, 1, pb, ACT_NONE, residual=a[i][0:B], out_mask=q[i][0:B],
+                             out=a[i + 1][0:B])
+            if self.has_head:
+                hm = e[0:B, :Cc] if self.head_act == ACT_RELU else None
+                k.gemm_ld(0, a[nb][0:B].view(B, CH * T), fw2d, out_mask=hm, out=e[0:B, :Cc])
+        if au is not None:
+            ga = k.gp_penalty_bwd(v_audio.view(B, -1), norms_a, gamma_t, False).view(audio.shape)
+            x = ga
+            for n, conv in enumerate(layers):
+                w, _, s_, pd = _conv_params(conv)
+                x = k.conv1d_fwd(x, w, None, s_, pd, ACT_NONE, out_mask=Y[n][B:], out=Y[n][0:B])
+            hm = e[0:B, Cc:] if self.head_act == ACT_RELU else None
+            k.gemm_ld(0, Y[4][0:B].view(B, -1), l6w2d, out_mask=hm, out=e[0:B, Cc:])
+        self._join(side, cur, e)
+        if self.has_head:
+            # tangent of the head: gz = relu'(z) * (W1 ge), in place over z's interpolated rows
+            k.gemm(0, e[0:B], fc1.weight, out_mask=z[0:B], out=z[0:B])
+
+        # ---------------------------------------------------------------- weight gradients: one launch per layer
+        # in REVERSE parameter order (head, audio branch from its last layer down, pose branch likewise), each p.grad
+        # bound as soon as its launch is queued: a data-parallel exchange (`on_grads` = GradExchange.poll) can send a
+        # bucket - buckets follow reverse parameter order too - underneath the remaining launches
+        late = []  # pose-branch gradients produced on the side stream: bound after the join (a bucket must not be
+        #            packed on the main stream before the side stream's launches are ordered in front of it)
+
+        def put(conv, gw, gb, defer=False):
+            if defer:
+                late.append((conv, gw, gb))
+            else:
+                conv.weight.grad, conv.bias.grad = gw, gb
+
+        def ready():
+            if on_grads is not None:
+                on_grads()
+
+        side, cur = self._fork(dev)
+        with self._On(side):
+            if self.has_head:
+                put(self.fconv, k.gemm(2, de_s, a[nb].view(R, CH * T)).view(self.fconv.weight.shape),
+                    k.channel_sums(de_s[B:].contiguous()), defer=side is not None)
+            else:
+                # phase 2: the full-length conv IS the score; its rows pair (tangent, 1) / (activation, +-1/B)
+                put(self.fconv, k.gemm(2, cs, a[nb].view(R, CH * T)).view(self.fconv.weight.shape),
+                    k.channel_sums(cs[B:].contiguous()), defer=side is not None)
+            if side is None:
+                ready()
+            for i in range(nb - 1, -1, -1):
+                blk = st.blocks[i]
+                wa, _, _, pa = _conv_params(blk.conv1)
+                wb, _, _, pb = _conv_params(blk.conv2)
+                put(blk.conv2, *k.conv1d_bwd_weight(p[i], da[i + 1], wb.shape[2], 1, pb, dy_mask=q[i], with_bias=True,
+                                                    bias_from_sample=B), defer=side is not None)
+                put(blk.conv1, *k.conv1d_bwd_weight(a[i], dp[i], wa.shape[2], 1, pa, with_bias=True,
+                                                    bias_from_sample=B), defer=side is not None)
+                if side is None:
+                    ready()
+            put(st.conv1, *k.conv1d_bwd_weight(X3, da[0], w1.shape[2], 1, pad1, with_bias=True, bias_from_sample=B),
+                defer=side is not None)
+        if self.has_head:
+            put(fc2, k.gemm(2, cs, z), k.channel_sums(cs[B:].contiguous()))
+            put(fc1, k.gemm(2, dzp, e), k.channel_sums(dzp[B:].contiguous()))
+        if au is not None:
+            put(au.l6, k.gemm(2, ca2, Y[4].view(2 * B, -1)).view(au.l6.weight.shape),
+                k.channel_sums(ca2[B:].contiguous()))
+            ready()
+            for n in range(4, 0, -1):
+                w, _, s_, pd = _conv_params(layers[n])
+                put(layers[n], *k.conv1d_bwd_weight(Y[n - 1], HD[n], w.shape[2], s_, pd, with_bias=True,
+                                                    bias_from_sample=B))
+                ready()
+            w, _, s_, pd = _conv_params(layers[0])
+            g2 = k.conv1d_bwd_weight(ga, HD[0][0:B], w.shape[2], s_, pd)
+            g1, gb = k.conv1d_bwd_weight(audio, HD[0][B:], w.shape[2], s_, pd, with_bias=True)
+            put(layers[0], g1.add_(g2), gb)
+        self._join(side, cur, *[g for _, gw, gb in late for g in (gw, gb)])
+        for conv, gw, gb in late:
+            conv.weight.grad, conv.bias.grad = gw, gb
+        ready()
+        return {"loss_critic": losses[0], "gp": losses[1], "w_dist": losses[2]}

@@ -160,7 +160,9 @@ int m2d_conv1d_pack_weights(const float* w, float* w_fwd, float* w_bwd, int Cout
 static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed, const float* bias, float* y, int B,
                            int Cin, int L, int Cout, int ks, int stride, int pad, int act, float slope,
                            const float* residual, const float* out_mask, float out_mask_slope, void* ws,
-                           size_t ws_bytes, void* stream, const M2dWinView* wv, double* stats) {
+                           size_t ws_bytes, void* stream, const M2dWinView* wv, double* stats,
+                           float* sum_out = nullptr) {
+  if (sum_out && !residual) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd: sum_out needs a residual");
 
   if (B <= 0 || Cin <= 0 || Cout <= 0 || ks <= 0 || stride <= 0 || pad < 0 || L <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd: bad shape B=%d Cin=%d L=%d Cout=%d k=%d s=%d p=%d", B, Cin, L,
@@ -169,7 +171,7 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
   if (Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd: empty output (L=%d k=%d s=%d p=%d)", L, ks, stride, pad);
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd: tensor exceeds 2^31 elements");
-  if (!residual && m2d_thin_applicable(Cin, Cout, ks, stride))
+  if (!residual && !sum_out && m2d_thin_applicable(Cin, Cout, ks, stride))
     return m2d_thin_fwd(x, w, bias, y, B, L, Cout, ks, stride, pad, Lout, act, slope, out_mask, out_mask_slope,
                         wv, stats, ws, ws_bytes, (hipStream_t)stream);
   if (wv && (Cin != 1 || (Lout == 1 && pad == 0 && L == ks)))
@@ -193,6 +195,7 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
     p.O.act = act;
     p.O.slope = slope;
     p.O.residual = residual;
+    p.O.sum_out = sum_out;
     p.O.mask = out_mask;
     p.O.mask_slope = out_mask_slope;
     if (stats) {
@@ -218,6 +221,7 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
   p.O.act = act;
   p.O.slope = slope;
   p.O.residual = residual;
+  p.O.sum_out = sum_out;
   p.O.mask = out_mask;
   p.O.mask_slope = out_mask_slope;
   if (stats) {  // no split-K with statistics, so the slab room holds the partials
@@ -235,6 +239,18 @@ int m2d_conv1d_fwd(const float* x, const float* w, const float* w_packed, const 
                    size_t ws_bytes, void* stream) {
   return conv1d_fwd_impl(x, w, w_packed, bias, y, B, Cin, L, Cout, ks, stride, pad, act, slope, residual, out_mask,
                          out_mask_slope, ws, ws_bytes, stream, nullptr, stats);
+}
+
+// The same launch with TWO outputs (a TemporalBlock's second conv, phase3/archis/default.py:207-210: x + relu(conv)):
+//   y = mask * act(conv(x) + bias)            (what the backward pass needs as its activation mask)
+//   sum_out = y + residual                    (what the next layer reads)
+int m2d_conv1d_fwd_sum(const float* x, const float* w, const float* w_packed, const float* bias, float* y,
+                       float* sum_out, int B, int Cin, int L, int Cout, int ks, int stride, int pad, int act,
+                       float slope, const float* residual, const float* out_mask, float out_mask_slope, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (!sum_out || !residual) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd_sum: needs sum_out and residual");
+  return conv1d_fwd_impl(x, w, w_packed, bias, y, B, Cin, L, Cout, ks, stride, pad, act, slope, residual, out_mask,
+                         out_mask_slope, ws, ws_bytes, stream, nullptr, nullptr, sum_out);
 }
 
 // The first conv of an audio encoder applied to the windows of a padded track WITHOUT writing the
@@ -258,16 +274,17 @@ int m2d_conv1d_fwd_windows(const float* track, int B, int S, int T, int hop, int
 // op the gradient penalty differentiates a second time (losses.py:40-44).
 // `w_packed` (optional): the backward image (Cout, ks, Cin) of w from m2d_conv1d_pack_weights.
 // `dy_mask` (optional, shape of dy): dy is read as dy * (mask>0 ? 1 : dy_mask_slope).
-int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
-                        int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
-                        const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream) {
+static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
+                                int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                                const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream,
+                                const float* residual) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_data: bad shape");
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout) ||
       !fits_i32((long long)Cout * Cin * ks))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_bwd_data: tensor exceeds 2^31 elements");
-  if (m2d_thin_applicable(Cin, Cout, ks, stride) && !out_mask)
+  if (m2d_thin_applicable(Cin, Cout, ks, stride) && !out_mask && !residual)
     return m2d_thin_bwd_data(dy, w, dx, B, L, Cout, ks, stride, pad, Lout, dy_mask, dy_mask_slope,
                              (hipStream_t)stream);
   M2dGemmParams p;
@@ -287,6 +304,8 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
     m2d_outmap_plain(p.O, dx, Cin * ks, 1);
     p.O.mask = out_mask;
     p.O.mask_slope = out_mask_slope;
+    p.O.residual = residual;
+    p.O.mask_last = 1;
     return m2d_gemm_launch(p, true, false, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }
   if (!w_packed) {
@@ -354,6 +373,8 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
   p.O.c_lim = L;
   p.O.mask = out_mask;
   p.O.mask_slope = out_mask_slope;
+  p.O.residual = residual;
+  p.O.mask_last = 1;
   if (stride == 1) {
     // single phase: resolve the phase parameters here (r = 0, taps = ks, q in [pad, L-1+pad]) so the
     // launch is an ordinary GEMM and may be split along K (the TCN critic's small grids need it)
@@ -378,14 +399,36 @@ int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, 
                          (hipStream_t)stream, "m2d_conv1d_bwd_data");
 }
 
+int m2d_conv1d_bwd_data(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
+                        int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                        const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream) {
+  return conv1d_bwd_data_impl(dy, w, w_packed, dx, B, Cin, L, Cout, ks, stride, pad, dy_mask, dy_mask_slope, out_mask,
+                              out_mask_slope, ws, ws_bytes, stream, nullptr);
+}
+
+// dx = out_mask * (conv^T(dy * dy_mask, W) + residual): the input gradient of a layer whose input also feeds a
+// skip connection (TemporalBlock: d x = d out + conv1^T(...), phase3/archis/default.py:207-210) - the skip
+// gradient is added in the epilogue instead of by a separate accumulation pass. residual: shape of dx.
+int m2d_conv1d_bwd_data_res(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
+                            int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                            const float* residual, const float* out_mask, float out_mask_slope, void* ws,
+                            size_t ws_bytes, void* stream) {
+  return conv1d_bwd_data_impl(dy, w, w_packed, dx, B, Cin, L, Cout, ks, stride, pad, dy_mask, dy_mask_slope, out_mask,
+                              out_mask_slope, ws, ws_bytes, stream, residual);
+}
+
 // Replaces the weight-gradient half of convolution_backward. K = (sample, position) is the long
 // dimension (hi = n, lo = l), so the launch is split-K with a deterministic slab reduction.
 // `dbias` (optional, Cout floats): the bias gradient sum_{n,l} dy[n,co,l] (masked like dy) from the
 // same launch - one all-ones column appended to the x operand - instead of a second pass over dy.
 static int conv1d_bwd_weight_impl(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
                                   int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
-                                  void* ws, size_t ws_bytes, void* stream, const M2dWinView* wv) {
+                                  void* ws, size_t ws_bytes, void* stream, const M2dWinView* wv,
+                                  int bias_from_sample = 0) {
   const int Lout = conv_out_len(L, ks, stride, pad);
+  if (bias_from_sample < 0 || bias_from_sample > B) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight: bad bias_from_sample");
+  if (bias_from_sample > 0 && dbias && (Lout < M2D_BK || m2d_thin_applicable(Cin, Cout, ks, stride)))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight: bias_from_sample needs >= %d output positions and Cin > 1", M2D_BK);
   if (B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight: bad shape");
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout))
@@ -458,6 +501,7 @@ static int conv1d_bwd_weight_impl(const float* x, const float* dy, float* dw, fl
     // column Cin*ks of the x operand reads as ones: dbias[co] = sum_k dy[co, k]
     p.N = Cin * ks + 1;
     b.ones_row_p1 = Cin * ks + 1;
+    b.ones_from_hi = bias_from_sample;
     p.O.col_out = dbias;
     p.O.redirect_col_p1 = Cin * ks + 1;
   }
@@ -470,6 +514,17 @@ int m2d_conv1d_bwd_weight(const float* x, const float* dy, float* dw, float* dbi
                           void* ws, size_t ws_bytes, void* stream) {
   return conv1d_bwd_weight_impl(x, dy, dw, dbias, B, Cin, L, Cout, ks, stride, pad, dy_mask, dy_mask_slope, ws,
                                 ws_bytes, stream, nullptr);
+}
+
+// The same with the bias gradient summed over the samples [bias_from_sample, B) only. One launch then serves a
+// batch whose first rows pair SECOND-order operands (x := the penalty's forward-mode tangent, dy := the first
+// backward's input gradient; they feed dW but no bias) with ordinary (x, dy) rows behind them - the critic
+// iteration's two weight-gradient launches per layer (losses.py:40-44 double backward + loss backward) as one.
+int m2d_conv1d_bwd_weight_from(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
+                               int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
+                               int bias_from_sample, void* ws, size_t ws_bytes, void* stream) {
+  return conv1d_bwd_weight_impl(x, dy, dw, dbias, B, Cin, L, Cout, ks, stride, pad, dy_mask, dy_mask_slope, ws,
+                                ws_bytes, stream, nullptr, bias_from_sample);
 }
 
 // Weight (and bias) gradient of m2d_conv1d_fwd_windows; dy: (B*T, Cout, Lout). Workspace as for the
@@ -523,10 +578,16 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
 //   mode 1 (NN): C[M,N] = A[M,K] * B[K,N]                              dx = dy W
 //   mode 2 (TN): C[M,N] = A[K,M]^T * B[K,N]                            dW = dy^T x
 // a_mask (shape of A) / out_mask (shape of C) fuse the activation derivative as in conv1d.
-int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float* c, int M, int N, int K,
-             int act, float slope, const float* a_mask, float a_mask_slope, const float* out_mask,
-             float out_mask_slope, void* ws, size_t ws_bytes, void* stream) {
+static int gemm_impl(int mode, const float* a, int lda, const float* b, int ldb, const float* bias, float* c, int ldc,
+                     int M, int N, int K, int act, float slope, const float* a_mask, float a_mask_slope,
+                     const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream) {
   if (M < 0 || N < 0 || K < 0 || mode < 0 || mode > 2) M2D_FAIL(M2D_ERR_ARG, "m2d_gemm: bad arguments");
+  // leading dimensions (row pitch in elements) of the stored matrices; 0 = dense
+  const int a_cols = mode == 2 ? M : K, b_cols = mode == 0 ? K : N;
+  if (lda == 0) lda = a_cols;
+  if (ldb == 0) ldb = b_cols;
+  if (ldc == 0) ldc = N;
+  if (lda < a_cols || ldb < b_cols || ldc < N) M2D_FAIL(M2D_ERR_ARG, "m2d_gemm: leading dimension smaller than the row");
   if (!fits_i32((long long)M * K) || !fits_i32((long long)N * K) || !fits_i32((long long)M * N))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_gemm: matrix exceeds 2^31 elements");
   M2dGemmParams p;
@@ -540,26 +601,28 @@ int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float*
   bool akf = true, bkf = true;
   // an empty contraction still runs the epilogue (bias / activation of zero): give the
   // descriptors a non-empty extent, nothing is read through them
-  const long long ea = K > 0 ? (long long)M * K : 1, eb = K > 0 ? (long long)N * K : 1;
+  const long long a_rows = mode == 2 ? K : M, b_rows = mode == 0 ? N : K;
+  const long long ea = K > 0 ? (a_rows - 1) * lda + a_cols : 1, eb = K > 0 ? (b_rows - 1) * ldb + b_cols : 1;
+  if (!fits_i32((long long)(M - 1) * ldc + N)) M2D_FAIL(M2D_ERR_RANGE, "m2d_gemm: output exceeds 2^31 elements");
   if (mode == 0) {
-    m2d_operand_plain(p.A, a, M, K, 1, ea);
-    m2d_operand_plain(p.B, b, N, K, 1, eb);
+    m2d_operand_plain(p.A, a, M, lda, 1, ea);
+    m2d_operand_plain(p.B, b, N, ldb, 1, eb);
     akf = true;
     bkf = true;
   } else if (mode == 1) {
-    m2d_operand_plain(p.A, a, M, K, 1, ea);
-    m2d_operand_plain(p.B, b, N, 1, N, eb);
+    m2d_operand_plain(p.A, a, M, lda, 1, ea);
+    m2d_operand_plain(p.B, b, N, 1, ldb, eb);
     akf = true;
     bkf = false;
   } else {
-    m2d_operand_plain(p.A, a, M, 1, M, ea);
-    m2d_operand_plain(p.B, b, N, 1, N, eb);
+    m2d_operand_plain(p.A, a, M, 1, lda, ea);
+    m2d_operand_plain(p.B, b, N, 1, ldb, eb);
     akf = false;
     bkf = false;
   }
   p.A.mask = a_mask;
   p.A.mask_slope = a_mask_slope;
-  m2d_outmap_plain(p.O, c, N, 1);
+  m2d_outmap_plain(p.O, c, ldc, 1);
   p.O.bias = bias;
   p.O.bias_mode = bias ? 2 : 0;
   p.O.act = act;
@@ -567,6 +630,23 @@ int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float*
   p.O.mask = out_mask;
   p.O.mask_slope = out_mask_slope;
   return m2d_gemm_launch(p, akf, bkf, true, ws, ws_bytes, (hipStream_t)stream, "m2d_gemm");
+}
+
+int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float* c, int M, int N, int K,
+             int act, float slope, const float* a_mask, float a_mask_slope, const float* out_mask,
+             float out_mask_slope, void* ws, size_t ws_bytes, void* stream) {
+  return gemm_impl(mode, a, 0, b, 0, bias, c, 0, M, N, K, act, slope, a_mask, a_mask_slope, out_mask, out_mask_slope,
+                   ws, ws_bytes, stream);
+}
+
+// m2d_gemm on sub-matrices: lda / ldb / ldc are the row pitches (elements) of the STORED a / b / c (0 = dense);
+// a_mask shares lda, out_mask shares ldc. Lets the critic head read / write column blocks of wider buffers in
+// place (the concatenated (B, 200) code of phase3/archis/default.py:266-269 is never assembled by a copy).
+int m2d_gemm_ld(int mode, const float* a, int lda, const float* b, int ldb, const float* bias, float* c, int ldc,
+                int M, int N, int K, int act, float slope, const float* a_mask, float a_mask_slope,
+                const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream) {
+  return gemm_impl(mode, a, lda, b, ldb, bias, c, ldc, M, N, K, act, slope, a_mask, a_mask_slope, out_mask,
+                   out_mask_slope, ws, ws_bytes, stream);
 }
 
 size_t m2d_gemm_workspace_bytes(int mode, int M, int N, int K) {

@@ -55,7 +55,10 @@ struct M2dOperand {
   // row-fast operands only: row (ones_row_p1 - 1) reads as 1.0 for every k instead of being gathered
   // (0 = none). Backward-weight appends such a column to its B operand: C[:, that column] = sum_k A[:, k],
   // i.e. the bias gradient comes out of the same launch (A is zero wherever k is padding).
+  // ones_from_hi: the row reads as 1.0 only in chunks whose hi index (backward-weight: the sample) is >= this,
+  // 0.0 before: the bias gradient then sums over the samples [ones_from_hi, B) only.
   int ones_row_p1;
+  int ones_from_hi;
   // Window views (audio slicing fused into the first encoder conv, utils.py:329-353 of the reference):
   // the operand is (B*T, 1, window) windows of a padded track (B, S), window t of track b starting at
   // b*S + t*hop, never materialised. The sample index n = b*T + t is then split once more:
@@ -70,8 +73,16 @@ struct M2dOperand {
 struct M2dOutMap {
   float* out;
   const float* bias;      // bias_mode 1: bias[m], 2: bias[col]
-  const float* mask;      // optional: value *= (mask[addr] > 0 ? 1 : mask_slope), applied last
-  const float* residual;  // optional: value += residual[addr] (after activation)
+  // Epilogue order: bias, activation, then the mask (value *= mask[addr] > 0 ? 1 : mask_slope) and the residual
+  // (value += residual[addr]) - mask first by default (forward-type launches: out = act'(y) * conv(g) + skip),
+  // residual first with `mask_last` (backward-data: dx = act'(x) * (conv^T(h) + skip gradient)).
+  // With `sum_out` the launch has two outputs: out[addr] = the masked value WITHOUT the residual,
+  // sum_out[addr] = value + residual[addr] (a TemporalBlock's second conv: relu(conv) for the backward mask and
+  // x + relu(conv) for the next layer, phase3/archis/default.py:207-210).
+  const float* mask;
+  const float* residual;
+  float* sum_out;
+  int mask_last;
   float mask_slope;
   float slope;            // LeakyReLU slope for act == 2
   int bias_mode;

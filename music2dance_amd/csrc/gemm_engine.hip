@@ -66,12 +66,14 @@ struct TileMap {
   int kb;    // k-fast: the thread's slot; row-fast: its first slot
   unsigned lim_eff;
   bool force_one;  // row-fast: this thread's row is the operand's all-ones row
+  float one_val;   // what that row reads as in the staged chunk (1, or 0 for chunks below ones_from_hi)
   float v[NE];   // staged values
   float mv[NM];  // staged mask values (MASKED only)
 
   __device__ __forceinline__ void prep(const M2dOperand& op, int row0, int tid) {
     lim_eff = op.lim > 0 ? (unsigned)op.lim : (unsigned)(M2D_BAD - 1);
     force_one = false;
+    one_val = 1.f;
     if constexpr (KF) {
       kb = tid % M2D_BK;
       posr = 0;
@@ -136,6 +138,7 @@ struct TileMap {
       hoff = q * op.k_hi2_stride + (hi - q * op.kdiv2) * op.k_hi_stride;
     }
     const int S = (hoff + lo0 * op.k_lo_stride) << 2;  // wave-uniform
+    if constexpr (!KF) one_val = hi >= op.ones_from_hi ? 1.f : 0.f;
     if constexpr (KF) {
       if constexpr (UNIFORM) {
 #pragma unroll
@@ -205,7 +208,7 @@ struct TileMap {
       const int rl = KF ? (tid / M2D_BK + i * (256 / M2D_BK)) : (tid % BR);
       float x = v[i];
       if constexpr (MASKED) x *= (mv[i] > 0.f ? 1.f : op.mask_slope);
-      if constexpr (!KF) x = force_one ? 1.f : x;
+      if constexpr (!KF) x = force_one ? one_val : x;
       s[kl * LD + rl] = x;
     }
   }
@@ -251,13 +254,23 @@ struct ChunkCursor {
   }
 };
 
+// -> the value stored at out[addr]; with O.sum_out the second output is written here too
 __device__ __forceinline__ float m2d_epilogue(const M2dOutMap& o, float v, int row, int col, int addr) {
   if (o.bias_mode == 1) v += o.bias[row];
   else if (o.bias_mode == 2) v += o.bias[col];
   if (o.act == 1) v = v > 0.f ? v : 0.f;
   else if (o.act == 2) v = v > 0.f ? v : v * o.slope;
-  if (o.residual) v += o.residual[addr];
+  if (o.mask_last) {
+    if (o.residual) v += o.residual[addr];
+    if (o.mask) v *= (o.mask[addr] > 0.f ? 1.f : o.mask_slope);
+    return v;
+  }
   if (o.mask) v *= (o.mask[addr] > 0.f ? 1.f : o.mask_slope);
+  if (o.sum_out) {
+    o.sum_out[addr] = v + o.residual[addr];
+    return v;
+  }
+  if (o.residual) v += o.residual[addr];
   return v;
 }
 

@@ -217,6 +217,70 @@ __global__ void __launch_bounds__(256) m2d_affine_cols_kernel(const float* x, co
   }
 }
 
+// ---------------------------------------------------------------- critic-iteration input pack
+// The critic iteration's three pose batches in ONE channels-first buffer (3B, C, T) - [interpolated | real | fake] -
+// from the loader's real poses (B, T, C) and the generator's rows (B*T, C) (phase3/train.py:196-199 permute +
+// contiguous, losses.py:13-25 interpolate): a (32 frames x C joints) tile is read as one contiguous run, staged in
+// LDS, and leaves as 128-byte runs along time per joint row. The interpolation is the reference's expression,
+// three separately rounded fp32 operations.
+#define M2D_PACK_TT 32
+__global__ void __launch_bounds__(256) m2d_pose_pack3_kernel(const float* __restrict__ real,
+                                                             const float* __restrict__ fake,
+                                                             const float* __restrict__ alpha, float* __restrict__ out,
+                                                             int B, int T, int C) {
+  extern __shared__ float sh[];  // [2][TT][C + 1]
+  const int b = blockIdx.y, t0 = blockIdx.x * M2D_PACK_TT;
+  const int nt = min(M2D_PACK_TT, T - t0);
+  const int ld = C + 1;
+  float* sr = sh;
+  float* sf = sh + M2D_PACK_TT * ld;
+  const size_t base = ((size_t)b * T + t0) * C;
+  for (int i = threadIdx.x; i < nt * C; i += 256) {
+    const int t = i / C, c = i - t * C;
+    sr[t * ld + c] = real[base + i];
+    sf[t * ld + c] = fake[base + i];
+  }
+  __syncthreads();
+  const float a = alpha[b];
+  const float na = __fsub_rn(1.f, a);
+  const size_t plane = (size_t)C * T;
+  float* oi = out + (size_t)b * plane + t0;
+  float* orl = out + ((size_t)B + b) * plane + t0;
+  float* of = out + ((size_t)2 * B + b) * plane + t0;
+  for (int i = threadIdx.x; i < C * M2D_PACK_TT; i += 256) {
+    const int c = i / M2D_PACK_TT, t = i - c * M2D_PACK_TT;
+    if (t < nt) {
+      const float r = sr[t * ld + c], f = sf[t * ld + c];
+      oi[(size_t)c * T + t] = __fadd_rn(__fmul_rn(a, r), __fmul_rn(na, f));
+      orl[(size_t)c * T + t] = r;
+      of[(size_t)c * T + t] = f;
+    }
+  }
+}
+
+// loss scalars of a critic iteration from the (3B,) scores [interpolated | real | fake] and the penalty term(s):
+// out[0] = E[D(fake)] - E[D(real)] + gamma * gp, out[1] = gp, out[2] = E[D(fake)] - E[D(real)]
+// (phase3/train.py:204-212, phase2/train.py:146-153). One block; fp64 accumulation.
+__global__ void __launch_bounds__(256) m2d_wgan_critic_loss_kernel(const float* scores, int B, const float* pen0,
+                                                                   const float* pen1, float gamma, float* out) {
+  __shared__ double sh[256];
+  double sr = 0.0, sf = 0.0;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    sr += (double)scores[B + i];
+    sf += (double)scores[2 * B + i];
+  }
+  sr = block_sum_256(sr, sh);
+  sf = block_sum_256(sf, sh);
+  if (threadIdx.x == 0) {
+    const float er = (float)(sr / B), ef = (float)(sf / B);
+    const float gp = pen1 ? __fadd_rn(pen0[0], pen1[0]) : pen0[0];
+    const float w = __fsub_rn(ef, er);
+    out[0] = __fadd_rn(w, __fmul_rn(gamma, gp));
+    out[1] = gp;
+    out[2] = w;
+  }
+}
+
 // ---------------------------------------------------------------- pool / upsample
 // MaxPool1d(2,2): y[r, j] = max(x[r, 2j], x[r, 2j+1]), rows = B*C, Lout = L/2
 __global__ void __launch_bounds__(256) m2d_maxpool2_fwd_kernel(const float* x, float* y, size_t rows, int L,
@@ -419,6 +483,32 @@ int m2d_affine_cols(const float* x, const float* scale, const float* shift, floa
   hipLaunchKernelGGL(m2d_affine_cols_kernel, dim3(grid_for(rows * (size_t)cols)), dim3(256), 0, stream, x, scale,
                      shift, y, rows, cols);
   M2D_CHECK_LAUNCH("m2d_affine_cols");
+  return M2D_OK;
+}
+
+// [interpolated | real | fake] poses channels-first (3B, C, T) from real (B, T, C), fake rows (B*T, C), alpha (B,):
+// replaces permute(0,2,1).contiguous() x2 (phase3/train.py:196-199), the interpolation (losses.py:13-25) and the
+// concatenation of the batches the critic scores in one pass.
+int m2d_pose_pack3(const float* real, const float* fake, const float* alpha, float* out, int B, int T, int C,
+                   void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || T <= 0 || C <= 0 || C > 1024) M2D_FAIL(M2D_ERR_ARG, "m2d_pose_pack3: bad shape");
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 20.0 * (double)B * T * C, "pose_pack3");
+  const size_t lds = 2 * (size_t)M2D_PACK_TT * (C + 1) * sizeof(float);
+  hipLaunchKernelGGL(m2d_pose_pack3_kernel, dim3(m2d_ceil_div(T, M2D_PACK_TT), B), dim3(256), lds, stream, real, fake,
+                     alpha, out, B, T, C);
+  M2D_CHECK_LAUNCH("m2d_pose_pack3");
+  return M2D_OK;
+}
+
+// out[0..2] = (loss_critic, gp, w_dist) from scores (3B,) = [interpolated | real | fake] and the penalty term(s)
+// pen0 (+ pen1, optional: the audio term, losses.py:56-60).
+int m2d_wgan_critic_loss(const float* scores, int B, const float* pen0, const float* pen1, float gamma, float* out,
+                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || !pen0) M2D_FAIL(M2D_ERR_ARG, "m2d_wgan_critic_loss: bad arguments");
+  hipLaunchKernelGGL(m2d_wgan_critic_loss_kernel, dim3(1), dim3(256), 0, stream, scores, B, pen0, pen1, gamma, out);
+  M2D_CHECK_LAUNCH("m2d_wgan_critic_loss");
   return M2D_OK;
 }
 

@@ -173,6 +173,20 @@ class GradExchange:
             self.launched_in_backward += 1
             self._next += 1
 
+    def poll(self):
+        """For schedules that bind p.grad themselves (critic_step.CriticStep: no autograd hooks fire): launch, strictly
+        in bucket order, every bucket whose expected gradients are all in place. Same contract as the hooks - armed
+        by overlap_backward(), expectations learnt from the first exchange, what is left goes at start()."""
+        if not self.active or not self._hooks or self._expect is None or self._pending is not None or self._suspended:
+            return
+        while self._next < len(self.buckets):
+            i = self._next
+            if sum(1 for p in self.buckets[i] if p.grad is not None) < self._expect[i]:
+                break
+            self._launched[i] = self._launch(i)
+            self.launched_in_backward += 1
+            self._next += 1
+
     def start(self):
         """Pack the gradients and launch the all-reduces asynchronously (those not already launched from
         the backward hooks)."""

@@ -16,6 +16,7 @@ import torch
 import torch.optim as optim
 
 from . import kernels, ops
+from .critic_step import CriticStep
 from .dp import GradExchange
 from .layers import copy_stream, to_device_async
 from .losses import gradient_penalty, tv_loss
@@ -65,6 +66,9 @@ class WganGpEngine:
         self.x_critic = GradExchange(critic.parameters()).overlap_backward() if data_parallel else None
         self.x_gen = GradExchange(gen.parameters()) if data_parallel else None
         self._critic_step_pending = False
+        # the critic iteration as one hand-scheduled pass (critic_step.py) instead of three autograd passes; engines
+        # whose critic qualifies (piecewise-linear heads) build it in their constructor. M2D_MANUAL_CRITIC=0: autograd
+        self.manual_critic = None
         self.last = {}
         self.last_full = {}  # most recent value of every scalar (generator scalars persist between G steps)
         # generator-forward pipelining (see _generator_forward_nograd)
@@ -91,6 +95,12 @@ class WganGpEngine:
         else:
             self.optim_critic.step()
             kernels.impl().invalidate_packed(self._critic_params)
+
+    def _poll_exchange(self):
+        x = self.x_critic
+        if x is None or not x.active or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            return None
+        return x.poll
 
     def _gen_step(self):
         if self.x_gen is not None:
@@ -192,6 +202,8 @@ class Phase3Engine(WganGpEngine):
         self.output_size = int(cfg.get("output_size", 69))
         self.ablated = bool(ablated)
         self.early_pair_pass = os.environ.get("M2D_EARLY_PAIR", "1") != "0"
+        if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
+            self.manual_critic = CriticStep(critic, self.gamma, lp=False)
 
     def _shapes(self, real):
         B = real.size(0)
@@ -214,8 +226,14 @@ class Phase3Engine(WganGpEngine):
             self._finish_critic_step()
         # only after the deferred step has consumed the previous iteration's gradients
         self.optim_critic.zero_grad(set_to_none=True)
-        real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         audio_c = audio.unsqueeze(1)
+        if self.manual_critic is not None:
+            self._join_generator_forward(fake_rows)
+            if alpha is None:  # drawn on the host generator where the reference draws it (losses.py:15)
+                alpha = to_device_async(torch.rand(B, 1), real.device)
+            return self.manual_critic.run(real, fake_rows, None if self.ablated else audio_c, alpha,
+                                          on_grads=self._poll_exchange())
+        real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         with self.critic.shared_audio() if not self.ablated else contextlib.nullcontext():
             self._join_generator_forward(fake_rows)
             return self._critic_passes(B, T, real, real_c, fake_rows, audio_c, alpha)
@@ -414,6 +432,8 @@ class Phase2Engine(WganGpEngine):
         self.scheduler_critic = optim.lr_scheduler.MultiStepLR(self.optim_critic, milestones=ms, gamma=0.8)
         self.scheduler_gen = optim.lr_scheduler.MultiStepLR(self.optim_gen, milestones=ms, gamma=0.8)
         self.host_noise = True  # draw noise on the host generator (matches the CPU reference)
+        if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
+            self.manual_critic = CriticStep(critic, self.gamma, lp=True)
 
     def _noise(self, B, T, device):
         if self.host_noise:
@@ -428,6 +448,11 @@ class Phase2Engine(WganGpEngine):
             fake_rows = self.gen(noise, [T] * B)
         self._finish_critic_step()
         self.optim_critic.zero_grad(set_to_none=True)  # after the deferred step used the old gradients
+        if self.manual_critic is not None:
+            alpha = to_device_async(torch.rand(B, 1), real.device)  # host draw, as losses.py:15
+            out = self.manual_critic.run(real, fake_rows, None, alpha, on_grads=self._poll_exchange())
+            self._begin_critic_step()
+            return out
         fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=True, device=real.device)

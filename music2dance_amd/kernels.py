@@ -169,49 +169,73 @@ class HipKernels:
         return Cin == 1 and ks == 25 and stride == 4
 
     def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
-                   out_mask_slope=0.0, with_stats=False):
-        """-> y, or (y, sums) with `with_stats`: sums (2*Cout,) float64 = per-channel sum / sum of squares of y
-        from the conv's own epilogue (what a following BatchNorm needs: bn_fwd_sums)."""
-        dev = _chk(x, w, bias, residual, out_mask)
+                   out_mask_slope=0.0, with_stats=False, out=None, sum_out=None):
+        """y = out_mask * act(conv(x) + bias) + residual  (mask BEFORE the residual)
+        -> y, or (y, sums) with `with_stats`: sums (2*Cout,) float64 = per-channel sum / sum of squares of y
+        from the conv's own epilogue (what a following BatchNorm needs: bn_fwd_sums).
+        out: write y there (may alias out_mask: in-place masking). sum_out (needs residual): second output
+        sum_out = y + residual while y itself stays without the residual; -> (y, sum_out)."""
+        dev = _chk(x, w, bias, residual, out_mask, out, sum_out)
         B, Cin, L = x.shape
         Cout, Cin2, ks = w.shape
         assert Cin == Cin2, "conv1d: channel mismatch"
         Lout = conv_out_len(L, ks, stride, pad)
-        y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=dev)
+        y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=dev) if out is None else out
+        assert tuple(y.shape) == (B, Cout, Lout)
         h = _lib.lib()
         full_length = Lout == 1 and pad == 0 and L == ks
         wp = self.packed_weights(w)[0] if (Cin >= 16 and not full_length) else None
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 0, B, Cin, L, Cout, ks, stride, pad), dev)
+        nws = 0 if ws is None else ws.numel() * 4
+        if sum_out is not None:
+            assert not with_stats and residual is not None and tuple(sum_out.shape) == tuple(y.shape)
+            with _on(dev):
+                rc = h.m2d_conv1d_fwd_sum(_ptr(x), _ptr(w), _ptr(wp), _ptr(bias), _ptr(y), _ptr(sum_out), B, Cin, L,
+                                          Cout, ks, stride, pad, act, slope, _ptr(residual), _ptr(out_mask),
+                                          out_mask_slope, _ptr(ws), nws, _stream(dev))
+            _lib.check(rc, "m2d_conv1d_fwd_sum")
+            return y, sum_out
         sums = torch.empty((2 * Cout,), dtype=torch.float64, device=dev) if with_stats else None
         with _on(dev):
             rc = h.m2d_conv1d_fwd(_ptr(x), _ptr(w), _ptr(wp), _ptr(bias), _ptr(y), B, Cin, L, Cout, ks, stride, pad,
                                   act, slope, _ptr(residual), _ptr(out_mask), out_mask_slope, _ptr(sums), _ptr(ws),
-                                  0 if ws is None else ws.numel() * 4, _stream(dev))
+                                  nws, _stream(dev))
         _lib.check(rc, "m2d_conv1d_fwd")
         return (y, sums) if with_stats else y
 
     def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0, out_mask=None,
-                        out_mask_slope=0.0):
-        dev = _chk(dy, w, dy_mask, out_mask)
+                        out_mask_slope=0.0, residual=None, out=None):
+        """dx = out_mask * (conv^T(dy * dy_mask, w) + residual); out: write dx there."""
+        dev = _chk(dy, w, dy_mask, out_mask, residual, out)
         B, Cout, Lout = dy.shape
         Cout2, Cin, ks = w.shape
         assert Cout == Cout2 and Lout == conv_out_len(L, ks, stride, pad)
-        dx = torch.empty((B, Cin, L), dtype=torch.float32, device=dev)
+        dx = torch.empty((B, Cin, L), dtype=torch.float32, device=dev) if out is None else out
+        assert tuple(dx.shape) == (B, Cin, L)
         h = _lib.lib()
         full_length = Lout == 1 and pad == 0 and L == ks
-        if out_mask is not None and self._thin(Cin, ks, stride):
-            raise _lib.M2dError("conv1d_bwd_data: out_mask is not supported on the thin (Cin = 1, k25 s4) path")
+        if (out_mask is not None or residual is not None) and self._thin(Cin, ks, stride):
+            raise _lib.M2dError("conv1d_bwd_data: out_mask / residual are not supported on the thin (Cin = 1, k25 s4) path")
         wp = None if (full_length or self._thin(Cin, ks, stride)) else self.packed_weights(w)[1]
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 1, B, Cin, L, Cout, ks, stride, pad), dev)
+        nws = 0 if ws is None else ws.numel() * 4
         with _on(dev):
-            rc = h.m2d_conv1d_bwd_data(_ptr(dy), _ptr(w), _ptr(wp), _ptr(dx), B, Cin, L, Cout, ks, stride, pad,
-                                       _ptr(dy_mask), dy_mask_slope, _ptr(out_mask), out_mask_slope, _ptr(ws),
-                                       0 if ws is None else ws.numel() * 4, _stream(dev))
+            if residual is not None:
+                assert tuple(residual.shape) == tuple(dx.shape)
+                rc = h.m2d_conv1d_bwd_data_res(_ptr(dy), _ptr(w), _ptr(wp), _ptr(dx), B, Cin, L, Cout, ks, stride, pad,
+                                               _ptr(dy_mask), dy_mask_slope, _ptr(residual), _ptr(out_mask),
+                                               out_mask_slope, _ptr(ws), nws, _stream(dev))
+            else:
+                rc = h.m2d_conv1d_bwd_data(_ptr(dy), _ptr(w), _ptr(wp), _ptr(dx), B, Cin, L, Cout, ks, stride, pad,
+                                           _ptr(dy_mask), dy_mask_slope, _ptr(out_mask), out_mask_slope, _ptr(ws),
+                                           nws, _stream(dev))
         _lib.check(rc, "m2d_conv1d_bwd_data")
         return dx
 
-    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0, with_bias=False):
-        """-> dw, or (dw, dbias) with `with_bias`: dbias = sum over (batch, length) of the masked dy."""
+    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0, with_bias=False,
+                          bias_from_sample=0):
+        """-> dw, or (dw, dbias) with `with_bias`: dbias = sum over (batch, length) of the masked dy, over the
+        samples [bias_from_sample, B) only (rows in front of them pair second-order operands: no bias term)."""
         dev = _chk(x, dy, dy_mask)
         B, Cin, L = x.shape
         B2, Cout, Lout = dy.shape
@@ -220,10 +244,15 @@ class HipKernels:
         db = torch.empty((Cout,), dtype=torch.float32, device=dev) if with_bias else None
         h = _lib.lib()
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 2, B, Cin, L, Cout, ks, stride, pad), dev)
+        nws = 0 if ws is None else ws.numel() * 4
         with _on(dev):
-            rc = h.m2d_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, L, Cout, ks, stride, pad,
-                                         _ptr(dy_mask), dy_mask_slope, _ptr(ws),
-                                         0 if ws is None else ws.numel() * 4, _stream(dev))
+            if bias_from_sample:
+                rc = h.m2d_conv1d_bwd_weight_from(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, L, Cout, ks, stride,
+                                                  pad, _ptr(dy_mask), dy_mask_slope, int(bias_from_sample), _ptr(ws),
+                                                  nws, _stream(dev))
+            else:
+                rc = h.m2d_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, L, Cout, ks, stride, pad,
+                                             _ptr(dy_mask), dy_mask_slope, _ptr(ws), nws, _stream(dev))
         _lib.check(rc, "m2d_conv1d_bwd_weight")
         return (dw, db) if with_bias else dw
 
@@ -266,9 +295,10 @@ class HipKernels:
 
     # ---------------------------------------------------------------- gemm
     def gemm(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,
-             out_mask_slope=0.0):
-        """mode 0: a(M,K) b(N,K)^T (+bias[N]); 1: a(M,K) b(K,N); 2: a(K,M)^T b(K,N)."""
-        dev = _chk(a, b, bias, a_mask, out_mask)
+             out_mask_slope=0.0, out=None):
+        """mode 0: a(M,K) b(N,K)^T (+bias[N]); 1: a(M,K) b(K,N); 2: a(K,M)^T b(K,N). out: write there (may alias
+        out_mask: in-place masking)."""
+        dev = _chk(a, b, bias, a_mask, out_mask, out)
         if mode == 0:
             M, K = a.shape
             N, K2 = b.shape
@@ -279,7 +309,8 @@ class HipKernels:
             K, M = a.shape
             K2, N = b.shape
         assert K == K2, "gemm: inner dimension mismatch"
-        c = torch.empty((M, N), dtype=torch.float32, device=dev)
+        c = torch.empty((M, N), dtype=torch.float32, device=dev) if out is None else out
+        assert tuple(c.shape) == (M, N)
         h = _lib.lib()
         ws = _ws(_ws_bytes('m2d_gemm_workspace_bytes', mode, M, N, K), dev)
         with _on(dev):
@@ -288,6 +319,81 @@ class HipKernels:
                             0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_gemm")
         return c
+
+    @staticmethod
+    def _chk_rows(*tensors):
+        """2-D fp32 device tensors whose rows are dense (stride(1) == 1) but may be a column block of a wider
+        buffer (any stride(0) >= the row length) -> device."""
+        dev = None
+        for t in tensors:
+            if t is None:
+                continue
+            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2:
+                raise _lib.M2dError("gemm_ld: 2-D fp32 HIP tensors only")
+            if t.size(1) > 1 and t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1)):
+                raise _lib.M2dError("gemm_ld: rows must be dense")
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise _lib.M2dError("tensors on different devices")
+        return dev
+
+    @staticmethod
+    def _ld(t):
+        return t.stride(0) if t.size(0) > 1 else t.size(1)
+
+    def gemm_ld(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,
+                out_mask_slope=0.0, out=None):
+        """gemm() on row-strided 2-D views (column blocks of wider buffers): a_mask must share a's layout,
+        out_mask the output's (it may BE the output: in-place masking). out: a view to write into."""
+        dev = self._chk_rows(a, b, a_mask, out_mask, out)
+        _chk(bias)
+        if mode == 0:
+            M, K = a.shape
+            N, K2 = b.shape
+        elif mode == 1:
+            M, K = a.shape
+            K2, N = b.shape
+        else:
+            K, M = a.shape
+            K2, N = b.shape
+        assert K == K2, "gemm: inner dimension mismatch"
+        c = torch.empty((M, N), dtype=torch.float32, device=dev) if out is None else out
+        assert tuple(c.shape) == (M, N)
+        if a_mask is not None:
+            assert a_mask.shape == a.shape and self._ld(a_mask) == self._ld(a)
+        if out_mask is not None:
+            assert out_mask.shape == c.shape and self._ld(out_mask) == self._ld(c)
+        ws = _ws(_ws_bytes('m2d_gemm_workspace_bytes', mode, M, N, K), dev)
+        with _on(dev):
+            rc = _lib.lib().m2d_gemm_ld(mode, _ptr(a), self._ld(a), _ptr(b), self._ld(b), _ptr(bias), _ptr(c),
+                                        self._ld(c), M, N, K, act, slope, _ptr(a_mask), a_mask_slope, _ptr(out_mask),
+                                        out_mask_slope, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream(dev))
+        _lib.check(rc, "m2d_gemm_ld")
+        return c
+
+    # ---------------------------------------------------------------- critic iteration: pack + loss
+    def pose_pack3(self, real, fake_rows, alpha, out=None):
+        """real (B, T, C), fake_rows (B*T, C), alpha (B,) -> (3B, C, T) = [interpolated | real | fake] channels-first."""
+        dev = _chk(real, fake_rows, alpha, out)
+        B, T, C = real.shape
+        assert fake_rows.numel() == real.numel() and alpha.numel() == B
+        o = torch.empty((3 * B, C, T), dtype=torch.float32, device=dev) if out is None else out
+        with _on(dev):
+            rc = _lib.lib().m2d_pose_pack3(_ptr(real), _ptr(fake_rows), _ptr(alpha), _ptr(o), B, T, C, _stream(dev))
+        _lib.check(rc, "m2d_pose_pack3")
+        return o
+
+    def wgan_critic_loss(self, scores, B, pen0, pen1, gamma):
+        """scores (3B,) = [interpolated | real | fake] -> (3,) = (loss_critic, gp, w_dist)."""
+        dev = _chk(scores, pen0, pen1)
+        assert scores.numel() == 3 * B
+        out = torch.empty((3,), dtype=torch.float32, device=dev)
+        with _on(dev):
+            rc = _lib.lib().m2d_wgan_critic_loss(_ptr(scores), B, _ptr(pen0), _ptr(pen1), float(gamma), _ptr(out),
+                                                 _stream(dev))
+        _lib.check(rc, "m2d_wgan_critic_loss")
+        return out
 
     # ---------------------------------------------------------------- batch norm
     def channel_sums(self, x, mask=None, slope=0.0):
@@ -507,10 +613,11 @@ class HipKernels:
         _lib.check(rc, "m2d_gp_penalty_fwd")
         return pen, norms
 
-    def gp_penalty_bwd(self, g, norms, gout, lp):
-        dev = _chk(g, norms, gout)
+    def gp_penalty_bwd(self, g, norms, gout, lp, out=None):
+        dev = _chk(g, norms, gout, out)
         B, n = g.shape
-        dg = torch.empty_like(g)
+        dg = torch.empty_like(g) if out is None else out
+        assert dg.numel() == g.numel()
         with _on(dev):
             rc = _lib.lib().m2d_gp_penalty_bwd(_ptr(g), _ptr(norms), _ptr(gout), _ptr(dg), B, n, 1 if lp else 0,
                                                _stream(dev))

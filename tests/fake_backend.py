@@ -35,29 +35,42 @@ class FakeKernels:
     def invalidate_packed(self, tensors=None):
         pass
 
+    @staticmethod
+    def _into(out, val):
+        if out is None:
+            return val
+        out.copy_(val)
+        return out
+
     def conv1d_fwd(self, x, w, bias, stride, pad, act=0, slope=0.0, residual=None, out_mask=None,
-                   out_mask_slope=0.0, with_stats=False):
+                   out_mask_slope=0.0, with_stats=False, out=None, sum_out=None):
         y = _act(F.conv1d(x, w, bias, stride=stride, padding=pad), act, slope)
+        if out_mask is not None:  # mask BEFORE the residual (include/m2d.h)
+            y = y * _mf(out_mask, out_mask_slope)
+        if sum_out is not None:
+            return self._into(out, y), self._into(sum_out, y + residual)
         if residual is not None:
             y = y + residual
-        if out_mask is not None:
-            y = y * _mf(out_mask, out_mask_slope)
+        y = self._into(out, y)
         return (y, self.bn_stats(y)) if with_stats else y
 
     def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0, out_mask=None,
-                        out_mask_slope=0.0):
+                        out_mask_slope=0.0, residual=None, out=None):
         if dy_mask is not None:
             dy = dy * _mf(dy_mask, dy_mask_slope)
         dx = torch.nn.grad.conv1d_input((dy.shape[0], w.shape[1], L), w, dy, stride=stride, padding=pad)
+        if residual is not None:  # residual BEFORE the mask
+            dx = dx + residual
         if out_mask is not None:
             dx = dx * _mf(out_mask, out_mask_slope)
-        return dx
+        return self._into(out, dx)
 
-    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0, with_bias=False):
+    def conv1d_bwd_weight(self, x, dy, ks, stride, pad, dy_mask=None, dy_mask_slope=0.0, with_bias=False,
+                          bias_from_sample=0):
         if dy_mask is not None:
             dy = dy * _mf(dy_mask, dy_mask_slope)
         dw = torch.nn.grad.conv1d_weight(x, (dy.shape[1], x.shape[1], ks), dy, stride=stride, padding=pad)
-        return (dw, dy.sum((0, 2))) if with_bias else dw
+        return (dw, dy[bias_from_sample:].sum((0, 2))) if with_bias else dw
 
     def conv1d_fwd_windows(self, track, T, hop, window, w, bias, stride, pad, act=0, slope=0.0, with_stats=False):
         x = track.unfold(-1, window, hop)[:, :T].reshape(-1, 1, window)
@@ -69,7 +82,7 @@ class FakeKernels:
         return self.conv1d_bwd_weight(x, dy, ks, stride, pad, dy_mask, dy_mask_slope, with_bias)
 
     def gemm(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,
-             out_mask_slope=0.0):
+             out_mask_slope=0.0, out=None):
         if a_mask is not None:
             a = a * _mf(a_mask, a_mask_slope)
         if mode == 0:
@@ -83,7 +96,24 @@ class FakeKernels:
         c = _act(c, act, slope)
         if out_mask is not None:
             c = c * _mf(out_mask, out_mask_slope)
-        return c
+        return self._into(out, c)
+
+    def gemm_ld(self, mode, a, b, bias=None, act=0, slope=0.0, a_mask=None, a_mask_slope=0.0, out_mask=None,
+                out_mask_slope=0.0, out=None):
+        return self.gemm(mode, a, b, bias, act, slope, a_mask, a_mask_slope, out_mask, out_mask_slope, out)
+
+    def pose_pack3(self, real, fake_rows, alpha, out=None):
+        B, T, C = real.shape
+        fake = fake_rows.view(B, T, C)
+        a = alpha.view(B, 1, 1)
+        o = torch.cat((a * real + (1 - a) * fake, real, fake), 0).permute(0, 2, 1).contiguous()
+        return self._into(out, o)
+
+    def wgan_critic_loss(self, scores, B, pen0, pen1, gamma):
+        s = scores.view(-1)
+        gp = pen0 if pen1 is None else pen0 + pen1
+        w = s[2 * B:].mean() - s[B:2 * B].mean()
+        return torch.stack((w + gamma * gp, gp, w))
 
     def channel_sums(self, x, mask=None, slope=0.0):
         if mask is not None:
@@ -244,12 +274,12 @@ class FakeKernels:
             d = norms - 1
         return (d * d).mean(), norms
 
-    def gp_penalty_bwd(self, g, norms, gout, lp):
+    def gp_penalty_bwd(self, g, norms, gout, lp, out=None):
         d = norms - 1
         if lp:
             d = d.clamp_min(0)
         coef = torch.where(d == 0, torch.zeros_like(d), gout * 2 * d / (norms * g.shape[0]))
-        return coef.view(-1, 1) * g
+        return self._into(out, coef.view(-1, 1) * g)
 
     def l1_mean_fwd(self, a, b):
         return (a - b).abs().mean()

@@ -1,0 +1,118 @@
+"""The hand-scheduled critic iteration (music2dance_amd/critic_step.py) against the autograd path it replaces
+(losses.gradient_penalty + critic.score_pair + backward: the path the reference fixtures pin, test_product_parity.py):
+same losses, and every parameter gradient element for element. Kernel layers as elsewhere: `cpu-fake` runs the
+schedule's host logic here, `hip` the real kernels on the GPU box (incl. BASELINE's batch 64)."""
+import pytest
+import torch
+
+from music2dance_amd import kernels
+from music2dance_amd.critic_step import CriticStep
+from music2dance_amd.losses import gradient_penalty
+from music2dance_amd.phase2.archis import default as p2
+from music2dance_amd.phase3.archis import default as p3
+
+
+@pytest.fixture(params=["cpu-fake", pytest.param("hip", marks=pytest.mark.gpu)])
+def dev(request):
+    if request.param == "hip":
+        assert kernels.impl().name == "hip"
+        yield torch.device("cuda:0")
+        return
+    from tests.fake_backend import FakeKernels
+    prev = kernels.set_impl(FakeKernels())
+    yield torch.device("cpu")
+    kernels.set_impl(prev)
+
+
+def _inputs(B, T, dev, audio=True, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    real = torch.rand(B, T, 69, generator=g).to(dev)
+    fake_rows = (torch.rand(B * T, 69, generator=g) * 1.5 - 0.2).to(dev)
+    alpha = torch.rand(B, 1, generator=g).to(dev)
+    aud = (0.1 * torch.randn(B, 1, 640 * T, generator=g)).to(dev) if audio else None
+    return real, fake_rows, alpha, aud
+
+
+def _autograd(critic, real, fake_rows, alpha, audio, gamma, lp):
+    """the engines' round-2 critic iteration (engine._critic_passes)"""
+    B, T = real.shape[0], real.shape[1]
+    for p in critic.parameters():
+        p.grad = None
+    real_c = real.permute(0, 2, 1).contiguous()
+    fake = fake_rows.view(B, T, 69).permute(0, 2, 1).contiguous()
+    if audio is None:
+        gp = gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=lp, device=real.device, alpha=alpha)
+        s_real, s_fake = critic.score_pair(real_c, fake)
+    else:
+        a = audio.clone()
+        with critic.shared_audio():
+            gp = gradient_penalty(critic, B, real_c, fake, a, is_seq=True, lp=lp, device=real.device, alpha=alpha)
+            s_real, s_fake = critic.score_pair(real_c, fake, a)
+    w = s_fake.mean() - s_real.mean()
+    loss = w + gamma * gp
+    loss.backward()
+    grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in critic.named_parameters()}
+    return {"loss_critic": loss.detach(), "gp": gp.detach(), "w_dist": w.detach()}, grads
+
+
+def _compare(critic, real, fake_rows, alpha, audio, gamma, lp, rtol):
+    want, ref = _autograd(critic, real, fake_rows, alpha, audio, gamma, lp)
+    step = CriticStep(critic, gamma, lp=lp)
+    got = step.run(real, fake_rows, None if audio is None else audio.clone(), alpha)
+    if real.is_cuda:
+        torch.cuda.synchronize()
+    for k in want:
+        a, b = float(got[k]), float(want[k])
+        assert abs(a - b) <= rtol * max(1.0, abs(b)), (k, a, b)
+    worst = 0.0
+    for n, p in critic.named_parameters():
+        assert (p.grad is None) == (ref[n] is None), n
+        if ref[n] is None:
+            continue
+        assert p.grad.shape == ref[n].shape, n
+        scale = ref[n].abs().max().item()
+        err = (p.grad - ref[n]).abs().max().item()
+        worst = max(worst, err / max(scale, 1e-30))
+        assert err <= rtol * scale + 1e-9, "%s: max |manual - autograd| %.3e vs max |autograd| %.3e" % (n, err, scale)
+    return worst
+
+
+@pytest.mark.parametrize("activ", ["id", "relu"])
+def test_phase3_two_branch_critic(dev, activ):
+    torch.manual_seed(0)
+    critic = p3.SequenceDiscriminator(69, 16, 12, 120, init_ker=25, activ=activ, device="cpu").to(dev)
+    real, fake_rows, alpha, audio = _inputs(2, 120, dev)
+    _compare(critic, real, fake_rows, alpha, audio, 10.0, False, 2e-4 if dev.type == "cuda" else 1e-5)
+
+
+def test_phase3_ablated_critic(dev):
+    torch.manual_seed(1)
+    critic = p3.AblatedSequenceDiscriminator(69, 16, 12, 40, init_ker=25, activ="id", device="cpu").to(dev)
+    real, fake_rows, alpha, _ = _inputs(3, 40, dev, audio=False)
+    _compare(critic, real, fake_rows, alpha, None, 10.0, False, 2e-4 if dev.type == "cuda" else 1e-5)
+
+
+@pytest.mark.parametrize("lp", [True, False])
+def test_phase2_critic(dev, lp):
+    torch.manual_seed(2)
+    critic = p2.SequenceDiscriminator(69, 16, 30, 25, 3, "cpu").to(dev)
+    real, fake_rows, alpha, _ = _inputs(4, 30, dev, audio=False)
+    _compare(critic, real, fake_rows, alpha, None, 10.0, lp, 2e-4 if dev.type == "cuda" else 1e-5)
+
+
+def test_tanh_heads_keep_the_autograd_path():
+    critic = p3.AblatedSequenceDiscriminator(69, 8, 6, 20, activ="tanh", device="cpu")
+    assert not CriticStep.supports(critic)
+    assert CriticStep.supports(p3.AblatedSequenceDiscriminator(69, 8, 6, 20, activ="relu", device="cpu"))
+
+
+@pytest.mark.gpu
+def test_full_size_batch_64_matches_autograd():
+    """BASELINE configs[2]'s critic at its size (B = 64, 120 frames): the launch plans the bench runs."""
+    import bench
+    dev = torch.device("cuda:0")
+    _, critic = bench.build_models(dev, 120)
+    real, fake_rows, alpha, audio = _inputs(64, 120, dev, seed=9)
+    with kernels.impl().weight_cache():
+        worst = _compare(critic, real, fake_rows, alpha, audio, 10.0, False, 5e-4)
+    print("manual vs autograd at B=64: worst element error relative to the tensor's largest: %.2e" % worst)

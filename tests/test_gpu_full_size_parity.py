@@ -139,9 +139,11 @@ def test_phase3_iteration_matches_oracle_at_full_size(enc, B, T, ablated):
     real_d, audio_d, slices_d = real.to(dev), audio.to(dev), slices.to(dev)
     with kernels.impl().weight_cache():
         out_c = eng._critic_body(real_d, audio_d, slices_d, noise_c.to(dev), alpha.to(dev), True)
-        d_norm_worst = _norms_close("critic", critic, o_dgrads)
+        d_norm_worst = _norms_close("critic", critic, o_dgrads)  # element bound 2e-3 (measured <= 3e-4)
         out_g = eng._generator_body(real_d, audio_d, slices_d, noise_g.to(dev))
-        g_norm_worst = _norms_close("gen", gen, o_ggrads)
+        # the generator's gradients travel through BatchNorm backward passes (differences of large sums) and BPTT: two
+        # fp32 evaluations differ by up to 5e-3 of a tensor's largest element (first encoder conv, 491 520-term sums)
+        g_norm_worst = _norms_close("gen", gen, o_ggrads, ertol=1e-2)
     _close("loss_critic", out_c["loss_critic"], o_err_c, 1e-4, 1e-5)
     _close("gp", out_c["gp"], o_gp, 1e-4)
     _close("w_dist", out_c["w_dist"], o_sfake.mean() - o_sreal.mean(), 1e-4)

@@ -182,8 +182,19 @@ def test_conv1d_masks_and_epilogue(case):
     # leaky + residual + out mask
     y = K().conv1d_fwd(xd, wd, bd, s, p, act=2, slope=slope, residual=res.to(DEV), out_mask=mask.to(DEV),
                        out_mask_slope=slope)
-    want = (F.leaky_relu(ref, slope) + res.double()) * m64
+    want = F.leaky_relu(ref, slope) * m64 + res.double()  # mask BEFORE the residual (include/m2d.h)
     assert rel_err(y, want) < 2e-5
+    # two outputs: y without the residual (the backward's activation mask), sum_out = y + residual; y into a
+    # caller-provided view of a larger buffer
+    big = torch.zeros((B + 2,) + tuple(ref.shape[1:]), device=DEV)
+    y2, so = K().conv1d_fwd(xd, wd, bd, s, p, act=1, residual=res.to(DEV), out=big[1:B + 1],
+                            sum_out=torch.empty(tuple(ref.shape), device=DEV))
+    assert y2.data_ptr() == big[1:].data_ptr() and float(big[0].abs().max()) == 0 and float(big[B + 1].abs().max()) == 0
+    assert rel_err(y2, F.relu(ref)) < 2e-5 and rel_err(so, F.relu(ref) + res.double()) < 2e-5
+    # in-place masking: out aliases out_mask
+    buf = mask.to(DEV).clone()
+    K().conv1d_fwd(xd, wd, None, s, p, out_mask=buf, out_mask_slope=0.0, out=buf)
+    assert rel_err(buf, F.conv1d(x.double(), w.double(), None, stride=s, padding=p) * (mask.double() > 0)) < 2e-5
     # masked dy in both backward halves (mask slope 0 = ReLU derivative)
     dy = gen(*ref.shape, seed=4)
     m0 = (mask.double() > 0).double()
@@ -206,6 +217,18 @@ def test_conv1d_masks_and_epilogue(case):
         (gx_plain,) = torch.autograd.grad(F.conv1d(x64, w64, None, stride=s, padding=p), x64, dy.double())
         dx = K().conv1d_bwd_data(dy.to(DEV), wd, L, s, p, out_mask=om.to(DEV), out_mask_slope=0.2)
         assert rel_err(dx, gx_plain * omf) < 2e-5
+        # skip-connection gradient added in the epilogue, BEFORE the mask: dx = mask * (conv^T(dy) + residual)
+        rs = gen(B, Cin, L, seed=8)
+        dx = K().conv1d_bwd_data(dy.to(DEV), wd, L, s, p, out_mask=om.to(DEV), out_mask_slope=0.2, residual=rs.to(DEV))
+        assert rel_err(dx, (gx_plain + rs.double()) * omf) < 2e-5
+        dx = K().conv1d_bwd_data(dy.to(DEV), wd, L, s, p, residual=rs.to(DEV))
+        assert rel_err(dx, gx_plain + rs.double()) < 2e-5
+        # bias gradient over the samples [1, B) only (rows in front pair second-order operands)
+        if ref.shape[2] >= 16 and B > 1:
+            dw2, db2 = K().conv1d_bwd_weight(xd, dy.to(DEV), ks, s, p, dy_mask=mask.to(DEV), dy_mask_slope=0.0,
+                                             with_bias=True, bias_from_sample=1)
+            assert rel_err(dw2, gw) < 3e-5
+            assert rel_err(db2, (dy.double() * m0)[1:].sum((0, 2))) < 3e-5
 
 
 GEMM_CASES = [(64, 128, 200), (7680, 256, 250), (3840, 720, 250), (33, 69, 256), (1, 1, 128), (100, 1, 128),
@@ -646,3 +669,66 @@ def test_persistent_gru_is_bit_identical_to_the_step_launches(dims):
         for l in range(L):
             assert torch.equal(out[l], ref_o[l]), (trial, l)
             assert torch.equal(saved[l], ref_s[l]), (trial, l)
+
+
+# ------------------------------------------------------------------------------ round 3: critic-step entry points
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gemm_on_column_blocks_of_wider_buffers(mode):
+    """m2d_gemm_ld: operands / output / masks are column blocks (row pitch > row length) of wider buffers."""
+    M, N, Kd = 37, 100, 128
+    g = torch.Generator().manual_seed(mode)
+    wide = lambda r, c, pad: torch.randn(r, c + pad, generator=g).to(DEV)
+    if mode == 0:
+        A, Bm = wide(M, Kd, 5), wide(N, Kd, 9)
+        a, b = A[:, 2:2 + Kd], Bm[:, 4:4 + Kd]
+        ref = a.double().cpu() @ b.double().cpu().t()
+    elif mode == 1:
+        A, Bm = wide(M, Kd, 5), wide(Kd, N, 100)
+        a, b = A[:, 2:2 + Kd], Bm[:, 100:]
+        ref = a.double().cpu() @ b.double().cpu()
+    else:
+        A, Bm = wide(Kd, M, 3), wide(Kd, N, 100)
+        a, b = A[:, 1:1 + M], Bm[:, :N]
+        ref = a.double().cpu().t() @ b.double().cpu()
+    C = torch.full((M, N + 60), 7.0, device=DEV)
+    out = C[:, 20:20 + N]
+    got = K().gemm_ld(mode, a, b, out=out)
+    assert got.data_ptr() == out.data_ptr()
+    assert rel_err(out, ref) < 2e-5
+    assert float((C[:, :20] - 7).abs().max()) == 0 and float((C[:, 20 + N:] - 7).abs().max()) == 0
+    # operand mask sharing a's pitch, output mask in place (the output block holds the mask values on entry)
+    if mode != 2:
+        am = torch.randn(A.shape, generator=g).to(DEV)
+        amv = am[:, 2:2 + Kd]
+        C2 = torch.randn(M, N + 60, generator=g).to(DEV)
+        om = C2[:, 20:20 + N].clone()
+        K().gemm_ld(mode, a, b, a_mask=amv, a_mask_slope=0.0, out_mask=C2[:, 20:20 + N], out_mask_slope=0.0,
+                    out=C2[:, 20:20 + N])
+        am64 = a.double().cpu() * (amv.double().cpu() > 0)
+        ref2 = (am64 @ (b.double().cpu().t() if mode == 0 else b.double().cpu())) * (om.double().cpu() > 0)
+        assert rel_err(C2[:, 20:20 + N], ref2) < 2e-5
+
+
+@pytest.mark.parametrize("dims", [(5, 120, 69), (3, 33, 69), (2, 300, 69), (4, 7, 5)], ids=lambda d: "x".join(map(str, d)))
+def test_pose_pack3_is_bit_exact(dims):
+    B, T, C = dims
+    g = torch.Generator().manual_seed(B)
+    real, fake, alpha = torch.rand(B, T, C, generator=g), torch.randn(B * T, C, generator=g), torch.rand(B, generator=g)
+    out = K().pose_pack3(real.to(DEV), fake.to(DEV), alpha.to(DEV)).cpu()
+    a = alpha.view(B, 1, 1)
+    interp = a * real + (1 - a) * fake.view(B, T, C)  # the reference's expression (losses.py:20), fp32
+    want = torch.cat((interp, real, fake.view(B, T, C)), 0).permute(0, 2, 1).contiguous()
+    assert torch.equal(out, want)
+
+
+def test_wgan_critic_loss_scalars():
+    B = 37
+    g = torch.Generator().manual_seed(1)
+    s = torch.randn(3 * B, generator=g)
+    p0, p1 = torch.rand((), generator=g), torch.rand((), generator=g)
+    out = K().wgan_critic_loss(s.to(DEV), B, p0.to(DEV), p1.to(DEV), 10.0).cpu().double()
+    w = s[2 * B:].double().mean() - s[B:2 * B].double().mean()
+    gp = p0.double() + p1.double()
+    assert abs(out[2] - w) < 1e-6 and abs(out[1] - gp) < 1e-6 and abs(out[0] - (w + 10 * gp)) < 1e-5
+    out = K().wgan_critic_loss(s.to(DEV), B, p0.to(DEV), None, 10.0).cpu().double()
+    assert abs(out[1] - p0.double()) < 1e-7

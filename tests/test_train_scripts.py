@@ -148,7 +148,7 @@ def test_train_scripts_run_on_a_dataset_folder(dev, tmp_path, monkeypatch):
     assert eng.total_iterations == 5
     c3 = _cfg(tmp_path, "phase3/configs/ablated.yaml", batch_size=2, num_epochs=1, n_critic_steps=2)  # (same file name)
     with pytest.raises(SystemExit, match="dataset folder"):
-        T3.main(["-c", c3, "-d", "0", "-n", "d3", "--folder", str(tmp_path / "nope")])
+        T3.main(["-c", c3, "-d", "0", "-n", "d3x", "--no-run-dir", "--folder", str(tmp_path / "nope")])
 
 
 # ------------------------------------------------------------------------------ MultiStepLR
