@@ -36,7 +36,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # GFLOP the reference's own formulation executes per sequence consumed per 8+1 cycle, by workload
 # (encoder, frames, ablated critic); shapes outside the table report no equivalent-work rate
 REF_GFLOP_PER_SEQ_CYCLE = {("default", 120, False): 31.10, ("wavegan", 120, False): 35.91,
-                           ("unet", 120, False): 52.12, ("unet", 300, True): 65.3}
+                           ("unet", 120, False): 52.12, ("unet", 300, True): 65.3,
+                           "phase2": 2.772, "phase1": 0.864e-3}
 
 P3_DEFAULT = {"lr_gen": 2e-4, "lr_critic": 2e-4, "n_critic_steps": 8, "gamma": 10, "beta": 1, "eta": 0,
               "output_size": 69}
@@ -99,14 +100,21 @@ def cpu_baseline(sample_b=32, T=120, threads=None):
                       % (sample_b, t3 - t0, t_critic, t_gen)}
 
 
-PRESETS = {  # BASELINE.json configs[2..4] at their per-GPU shapes
+PRESETS = {  # BASELINE.json configs[0..4] at their per-GPU shapes
+    "c1": dict(phase=1, batch=64, frames=1),     # phase1/configs/b1l10s128.yaml (BASELINE words it "CPU": GPU-only here)
+    "c2": dict(phase=2, batch=32, frames=120),   # phase2/configs/default.yaml at batch 32
     "c3": dict(enc_type="default", batch=64, frames=120, ablated=False),
     "c4": dict(enc_type="wavegan", batch=32, frames=120, ablated=False),  # global 256 on 8 GPUs
     "c5": dict(enc_type="unet", batch=16, frames=300, ablated=True),     # global 128 on 8 GPUs
 }
+P2_DEFAULT = {"lr_gen": 5e-4, "lr_critic": 5e-4, "n_critic_steps": 8, "gamma": 10, "eta": 50, "input_vector_size": 50,
+              "output_size": 69}
+P1_DEFAULT = {"lr_gen": 1e-4, "lr_critic": 1e-4, "n_critic_steps": 5, "gamma": 10, "latent_vector_size": 10}
 
 
 def baseline_tag(args):
+    if args.phase != 3:
+        return ""
     key = dict(enc_type=args.enc_type, batch=args.batch, frames=args.frames, ablated=args.ablated)
     for name, idx in (("c3", 2), ("c4", 3), ("c5", 4)):
         if PRESETS[name] == key:
@@ -233,6 +241,8 @@ def main():
                     help="write the roofline pass's per-shape table (family, tag, dims, launches, ms, TF/s or GB/s)")
     ap.add_argument("--graphs", default="off", choices=["on", "off"],
                     help="replay each loop body's forward/backward from a captured HIP graph (Phase3Engine.enable_graphs)")
+    ap.add_argument("--phase", type=int, default=3, choices=[1, 2, 3],
+                    help="which train script's loop body (3 = the BASELINE metric; 1 / 2: --config c1 / c2)")
     args = ap.parse_args()
     if args.config:
         for k, v in PRESETS[args.config].items():
@@ -255,14 +265,47 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    if args.frames != 120 and not args.ablated:
-        sys.exit("the audio critic only accepts 76 800-sample (120-frame) audio: use --ablated with --frames %d"
-                 % args.frames)
-    gen, critic = build_models(device, args.frames, args.enc_type, args.ablated)
-    engine = Phase3Engine(gen, critic, P3_DEFAULT, ablated=args.ablated)
+    if args.phase == 3:
+        if args.frames != 120 and not args.ablated:
+            sys.exit("the audio critic only accepts 76 800-sample (120-frame) audio: use --ablated with --frames %d"
+                     % args.frames)
+        gen, critic = build_models(device, args.frames, args.enc_type, args.ablated)
+        engine = Phase3Engine(gen, critic, P3_DEFAULT, ablated=args.ablated)
+        real, audio, slices = synthetic_phase3_batch(args.batch, args.frames, device, seed=100 + rank)
+        batch = (real, audio, slices)
+        workload = ("phase3/train.py WGAN-GP step, %s audio encoder%s, %d frames, batch %d per GPU%s; 1 generator "
+                    "iteration per 8 critic iterations" % (args.enc_type, ", ablated critic" if args.ablated else "",
+                                                           args.frames, args.batch, baseline_tag(args)))
+        ref_key = (args.enc_type, args.frames, args.ablated)
+    elif args.phase == 2:
+        from music2dance_amd.engine import Phase2Engine
+        from music2dance_amd.phase2.archis.default import SequenceDiscriminator as D2, SequenceGenerator as G2
+        torch.manual_seed(0)
+        gen = G2(50, 50, 256, 69, 2, 3, device)
+        critic = D2(69, 128, args.frames, 25, 3, device)
+        engine = Phase2Engine(gen, critic, P2_DEFAULT)
+        engine.host_noise = False  # phase2/train.py:139-140 draws the noise on the device
+        batch = (torch.rand(args.batch, args.frames, 69, generator=torch.Generator().manual_seed(100 + rank)).to(device),)
+        workload = ("phase2/train.py WGAN-LP step (GRU generator, 3-block TCN critic), %d frames, batch %d per GPU%s; "
+                    "1 generator iteration per 8 critic iterations"
+                    % (args.frames, args.batch, " (BASELINE.json configs[1])" if (args.frames, args.batch) == (120, 32) else ""))
+        ref_key = "phase2"
+    else:
+        from music2dance_amd.engine import Phase1Engine
+        from music2dance_amd.phase1.archis.residual import Discriminator as D1, Generator as G1
+        torch.manual_seed(0)
+        gen, critic = G1(10, 128, 69, 1).to(device), D1(69, 128, 1).to(device)
+        engine = Phase1Engine(gen, critic, P1_DEFAULT)
+        engine.host_noise = False  # phase1/train_wgan-gp.py:83 draws the noise on the device
+        batch = (torch.rand(args.batch, 23, 3, generator=torch.Generator().manual_seed(100 + rank)).to(device),)
+        workload = ("phase1/train_wgan-gp.py still-pose WGAN-GP step (residual MLPs, 1 block, width 128), batch %d per "
+                    "GPU%s; 1 generator iteration per 5 critic iterations"
+                    % (args.batch, " (BASELINE.json configs[0]; on the GPU: the product has no CPU path)" if args.batch == 64 else ""))
+        ref_key = "phase1"
     if args.graphs == "on":
+        if not hasattr(engine, "enable_graphs"):
+            sys.exit("--graphs on: this phase's engine has no captured-graph mode")
         engine.enable_graphs()
-    real, audio, slices = synthetic_phase3_batch(args.batch, args.frames, device, seed=100 + rank)
     gen.train(), critic.train()
     # the synthetic batch is resident and complete from here on: lets the engine start an iteration's
     # generator forward on its second stream while the previous iteration's critic kernels still run
@@ -285,7 +328,7 @@ def main():
     torch.manual_seed(1234 + rank)
     engine.total_iterations = (phase - args.warmup) % ncs  # the warm-up ends exactly at `phase`
     for _ in range(args.warmup):
-        engine.train_step(real, audio, slices, inputs_ready=ready)
+        engine.train_step(*batch, inputs_ready=ready)
     engine.flush()
     assert engine.total_iterations % ncs == phase
     # host hygiene, as the train scripts do after building their engine: a generation-2 garbage collection over
@@ -298,7 +341,7 @@ def main():
     t0 = time.perf_counter()
     step_events[0].record()
     for i in range(args.steps):
-        engine.train_step(real, audio, slices, inputs_ready=ready)
+        engine.train_step(*batch, inputs_ready=ready)
         step_events[i + 1].record()
     engine.flush()
     barrier()
@@ -327,12 +370,15 @@ def main():
         # the timed region runs the critic's pose branch on a side stream under the audio branch; an
         # event pair around a launch would then also count the other stream's kernels, so the roofline
         # pass runs the two branches one after the other: each duration is the launch's own
-        type(critic).overlap_branches = False
+        if hasattr(type(critic), "overlap_branches"):
+            type(critic).overlap_branches = False
+        if engine.manual_critic is not None:
+            engine.manual_critic.overlap = False
         engine.pipeline_generator = False  # likewise the generator forward: in line for the per-launch pass
         engine.total_iterations = phase  # same place in the 8+1 cycle as the timed window: same work
         K.prof_begin()
         for _ in range(args.steps):
-            engine.train_step(real, audio, slices)
+            engine.train_step(*batch)
         engine.flush()
         barrier()
         launches = K.prof_dump()
@@ -349,15 +395,12 @@ def main():
         seqs = args.steps * args.batch * world
         value = seqs / elapsed
         out = {
-            "metric": "%d-frame seq/sec, phase3 WGAN-GP step, batch %d per GPU" % (args.frames, args.batch),
+            "metric": ("%d-frame seq/sec, phase%d WGAN-GP step, batch %d per GPU" % (args.frames, args.phase, args.batch))
+            if args.phase != 1 else "poses/sec, phase1 WGAN-GP step, batch %d per GPU" % args.batch,
             "value": round(value, 2), "unit": "seq/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "phase3/train.py WGAN-GP step, %s audio encoder%s, %d frames, "
-                                   "batch %d per GPU%s; 1 generator iteration per 8 critic iterations"
-                                   % (args.enc_type, ", ablated critic" if args.ablated else "", args.frames, args.batch,
-                                      baseline_tag(args)),
-                       "global_batch": args.batch * world, "seq_len": args.frames,
+            "config": {"workload": workload, "global_batch": args.batch * world, "seq_len": args.frames,
                        "parallelism": "dp%d" % world, "backend": args.backend if world > 1 else None},
             "losses_last_step": last,
         }
@@ -394,12 +437,12 @@ def main():
             # the reference's own formulation executes REF_GFLOP_PER_SEQ_CYCLE per sequence consumed (SURVEY.md
             # 8(d), per workload); the engine skips work the reference discards, so this is an equivalent-work
             # rate over whole cycles, not a kernel rate
-            ref_gf = REF_GFLOP_PER_SEQ_CYCLE.get((args.enc_type, args.frames, args.ablated))
+            ref_gf = REF_GFLOP_PER_SEQ_CYCLE.get(ref_key)
             if ref_gf is not None and whole_cycles is not None:
                 out["roofline"]["reference_formulation"] = {
                     "gflop_per_seq_cycle": ref_gf,
                     "step_tflops": round(ref_gf * 1e9 * whole_cycles["value"] / 1e12, 2)}
-        default_cfg = (args.enc_type, args.frames, args.ablated) == ("default", 120, False)
+        default_cfg = args.phase == 3 and (args.enc_type, args.frames, args.ablated) == ("default", 120, False)
         if not args.no_cpu_baseline and world == 1 and default_cfg:
             try:
                 out["cpu_baseline"] = cpu_baseline()

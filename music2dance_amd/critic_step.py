@@ -64,18 +64,19 @@ class CriticStep:
         self.fconv = self.stick.fconv if hasattr(self.stick, "fconv") else self.stick.lastconv
         self.head_act = int(getattr(self.stick, "_head_act", ACT_NONE))
         self._const = {}
+        self.debug = None  # dev aid: a dict collects clones of the intermediates (tools/critic_step_debug.py)
         # the pose branch's launches are small (they leave most CUs idle between dependent kernels): they run on a
         # side stream underneath the audio branch's large convolutions, section by section
         self.overlap = self.audio is not None and getattr(type(critic), "overlap_branches", True)
         self._side = None
 
     # ------------------------------------------------------------------ helpers
-    def _constants(self, B, dev):
-        key = (B, str(dev))
+    def _constants(self, B, dev, dtype=torch.float32):
+        key = (B, str(dev), dtype)
         c = self._const.get(key)
         if c is None:
             cs = torch.cat((torch.ones(B), torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B))).view(3 * B, 1)
-            c = self._const[key] = (cs.to(dev), torch.tensor(self.gamma, dtype=torch.float32).to(dev))
+            c = self._const[key] = (cs.to(dev, dtype), torch.tensor(self.gamma, dtype=dtype).to(dev))
         return c
 
     def _fork(self, dev):
@@ -130,7 +131,8 @@ class CriticStep:
         B = real.size(0)
         T = real.numel() // (B * C)
         R = 3 * B
-        cs, gamma_t = self._constants(B, dev)
+        cs, gamma_t = self._constants(B, dev, fake_rows.dtype)
+        dbg = self.debug
         nb = len(st.blocks)
         w1, b1, _, pad1 = _conv_params(st.conv1)
         CH = w1.shape[0]
@@ -152,14 +154,14 @@ class CriticStep:
                 q.append(qk)
                 a.append(ak)
         E = Cc + (au.l6.weight.shape[0] if au is not None else 0)
-        e = torch.empty((R, E), dtype=torch.float32, device=dev)
+        e = torch.empty((R, E), dtype=fake_rows.dtype, device=dev)
         if au is not None:
             layers = [au.l1, au.l2, au.l3, au.l4, au.l5]
             Y, x = [], audio
             for conv in layers:
                 w, b, s_, pd = _conv_params(conv)
                 Lo = kernels.conv_out_len(x.shape[2], w.shape[2], s_, pd)
-                buf = torch.empty((2 * B, w.shape[0], Lo), dtype=torch.float32, device=dev)
+                buf = torch.empty((2 * B, w.shape[0], Lo), dtype=fake_rows.dtype, device=dev)
                 x = k.conv1d_fwd(x, w, b, s_, pd, ACT_RELU, out=buf[B:])
                 Y.append(buf)
             Ca = au.l6.weight.shape[0]
@@ -169,6 +171,9 @@ class CriticStep:
         with self._On(side):
             k.gemm_ld(0, a[-1].view(R, CH * T), fw2d, self.fconv.bias, self.head_act, out=e[:, :Cc])
         self._join(side, cur, e)
+        if dbg is not None:
+            dbg.update({"X3": X3.clone(), "e": e.clone(), **{"a%d" % i: t.clone() for i, t in enumerate(a)},
+                        **{"p%d" % i: t.clone() for i, t in enumerate(p)}, **{"q%d" % i: t.clone() for i, t in enumerate(q)}})
 
         # ---------------------------------------------------------------- head forward + first backward
         if self.has_head:
@@ -204,7 +209,7 @@ class CriticStep:
             pen_p, norms_p = k.gp_penalty_fwd(v_pose.view(B, -1), self.lp)
         v_audio = pen_a = None
         if au is not None:
-            ca2 = torch.empty((2 * B, Ca), dtype=torch.float32, device=dev)
+            ca2 = torch.empty((2 * B, Ca), dtype=fake_rows.dtype, device=dev)
             ca2[0:B] = de_a[0:B]
             torch.add(de_a[B:2 * B], de_a[2 * B:], out=ca2[B:])
             HD = [None] * 5
@@ -222,6 +227,11 @@ class CriticStep:
             v_audio = k.conv1d_bwd_data(HD[0][0:B], w, audio.shape[2], s_, pd)
             pen_a, norms_a = k.gp_penalty_fwd(v_audio.view(B, -1), False)
         self._join(side, cur, pen_p, v_pose)
+        if dbg is not None:
+            dbg.update({"s": s.clone(), "de_s": de_s.clone(), "v_pose": v_pose.clone(),
+                        **{"da%d" % i: t.clone() for i, t in enumerate(da)}, **{"dp%d" % i: t.clone() for i, t in enumerate(dp)}})
+            if dzp is not None:
+                dbg["dzp"] = dzp.clone()
 
         # ---------------------------------------------------------------- loss scalars, tangent seeds
         losses = k.wgan_critic_loss(s.view(-1), B, pen_p, pen_a, self.gamma)
@@ -249,6 +259,9 @@ class CriticStep:
             hm = e[0:B, Cc:] if self.head_act == ACT_RELU else None
             k.gemm_ld(0, Y[4][0:B].view(B, -1), l6w2d, out_mask=hm, out=e[0:B, Cc:])
         self._join(side, cur, e)
+        if dbg is not None:
+            dbg.update({"G0": X3[0:B].clone(), **{"ga%d" % i: t[0:B].clone() for i, t in enumerate(a)},
+                        **{"gp%d" % i: t[0:B].clone() for i, t in enumerate(p)}})
         if self.has_head:
             # tangent of the head: gz = relu'(z) * (W1 ge), in place over z's interpolated rows
             k.gemm(0, e[0:B], fc1.weight, out_mask=z[0:B], out=z[0:B])

@@ -110,7 +110,7 @@ class WganGpEngine:
         if self._gen_stream is not None:
             self._gen_params_ready = torch.cuda.current_stream().record_event()
 
-    def _generator_forward_nograd(self, fn, inputs):
+    def _generator_forward_nograd(self, fn, inputs, device=None):
         """The generator forward of a critic iteration (no autograd graph: the reference builds one and
         drops it). It reads the generator's weights and the batch, nothing the critic's optimizer
         touches, so it need not wait for the previous critic iteration: when the caller passes
@@ -120,7 +120,7 @@ class WganGpEngine:
         the previous iteration's critic GEMMs. Same kernels, same operands, same results; without
         `inputs_ready` the forward runs in line."""
         ready = self._inputs_ready
-        dev = inputs[0].device
+        dev = device if device is not None else inputs[0].device
         if ready is None or not self.pipeline_generator or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
             with torch.no_grad():
                 return fn()
@@ -440,35 +440,57 @@ class Phase2Engine(WganGpEngine):
             return to_device_async(torch.randn(B, T, self.input_size), device)
         return torch.randn(B, T, self.input_size, device=device)
 
+    def _always_ready(self, device):
+        """The generator's only input is noise the engine draws itself: its forward may always run one iteration
+        ahead on the second stream (an event that has long completed plays the loader's `inputs_ready`)."""
+        if self._inputs_ready is None and device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            if getattr(self, "_ready0", None) is None:
+                self._ready0 = torch.cuda.current_stream(device).record_event()
+            self._inputs_ready = self._ready0
+
     def critic_iteration(self, real):
+        out = self._critic_body(real, None, None)
+        self._begin_critic_step()
+        return out
+
+    def _critic_body(self, real, noise, alpha):
+        """noise / alpha: None = drawn where the reference draws them (phase2/train.py:139-140, losses.py:15)."""
         B = real.size(0)
         T = real.numel() // (B * self.output_size)
-        noise = self._noise(B, T, real.device)
-        with torch.no_grad():
-            fake_rows = self.gen(noise, [T] * B)
+        self._always_ready(real.device)
+        # (the noise is drawn inside the forward: on the generator's stream when it runs ahead)
+        fake_rows = self._generator_forward_nograd(
+            lambda: self.gen(self._noise(B, T, real.device) if noise is None else noise, [T] * B), (), real.device)
         self._finish_critic_step()
         self.optim_critic.zero_grad(set_to_none=True)  # after the deferred step used the old gradients
+        self._join_generator_forward(fake_rows)
         if self.manual_critic is not None:
-            alpha = to_device_async(torch.rand(B, 1), real.device)  # host draw, as losses.py:15
-            out = self.manual_critic.run(real, fake_rows, None, alpha, on_grads=self._poll_exchange())
-            self._begin_critic_step()
-            return out
+            if alpha is None:
+                alpha = to_device_async(torch.rand(B, 1), real.device)  # host draw, as losses.py:15
+            return self.manual_critic.run(real, fake_rows, None, alpha, on_grads=self._poll_exchange())
         fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
-        gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=True, device=real.device)
+        gp = gradient_penalty(self.critic, B, real_c, fake, is_seq=True, lp=True, device=real.device, alpha=alpha)
         s_real, s_fake = self.critic.score_pair(real_c, fake)
         err_real, err_fake = s_real.mean(), s_fake.mean()
         err_critic = err_fake - err_real + self.gamma * gp
         err_critic.backward()
-        self._begin_critic_step()
         return {"loss_critic": err_critic.detach(), "gp": gp.detach(), "w_dist": (err_fake - err_real).detach()}
 
     def generator_iteration(self, real):
+        self._finish_critic_step()
+        out = self._generator_body(real, None)
+        self._gen_step()
+        self.scheduler_critic.step()
+        self.scheduler_gen.step()
+        return out
+
+    def _generator_body(self, real, noise):
         B = real.size(0)
         T = real.numel() // (B * self.output_size)
-        self._finish_critic_step()
         self.optim_gen.zero_grad(set_to_none=True)
-        noise = self._noise(B, T, real.device)
+        if noise is None:
+            noise = self._noise(B, T, real.device)
         fake = self.gen(noise, [T] * B).view(B, T, self.output_size).permute(0, 2, 1)
         real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         with _Freeze(self.critic):
@@ -477,10 +499,96 @@ class Phase2Engine(WganGpEngine):
             err_fake = self.critic(fake).mean()
             err_gen = err_real - err_fake + self.eta * tv_loss(fake)
             err_gen.backward()
-        self._gen_step()
-        self.scheduler_critic.step()
-        self.scheduler_gen.step()
         return {"loss_gen": err_gen.detach()}
+
+    # ------------------------------------------------------------------ captured-graph mode (as Phase3Engine's)
+    def enable_graphs(self, on=True):
+        """Replay each loop body's forward / backward as one captured HIP graph per batch shape. The optimizer and
+        scheduler steps and the gradient exchange stay eager; the noise and the interpolation weights are drawn
+        where the eager path draws them, in the same order, and fed through static buffers."""
+        self._use_graphs = bool(on)
+        self._graphs = {}
+        if on and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        return self
+
+    def train_step(self, real, inputs_ready=None):
+        if not getattr(self, "_use_graphs", False) or real.device.type != "cuda":
+            return super().train_step(real, inputs_ready=inputs_ready)
+        self.total_iterations += 1
+        self._check_async()
+        self._finish_critic_step()
+        g = self._graph_for(real)
+        B, T = g["noise_c"].shape[0], g["noise_c"].shape[1]
+        g["real"].copy_(real.reshape(g["real"].shape))
+        g["noise_c"].copy_(self._noise(B, T, real.device))
+        g["alpha"].copy_(to_device_async(torch.rand(B, 1), real.device))
+        Phase3Engine._bind_grads(self.critic, g["critic_grads"])
+        g["critic"].replay()
+        self._begin_critic_step()
+        out = dict(g["critic_out"])
+        if self.total_iterations % self.n_critic_steps == 0:
+            self._finish_critic_step()
+            g["noise_g"].copy_(self._noise(B, T, real.device))
+            Phase3Engine._bind_grads(self.gen, g["gen_grads"])
+            g["gen"].replay()
+            self._gen_step()
+            self.scheduler_critic.step()
+            self.scheduler_gen.step()
+            out.update(g["gen_out"])
+        self.last = out
+        self.last_full.update(out)
+        return out
+
+    def _graph_for(self, real):
+        key = tuple(real.shape)
+        g = self._graphs.get(key)
+        if g is not None:
+            return g
+        dev = real.device
+        B = real.size(0)
+        T = real.numel() // (B * self.output_size)
+        g = {"real": torch.empty_like(real).copy_(real), "noise_c": torch.zeros(B, T, self.input_size, device=dev),
+             "noise_g": torch.zeros(B, T, self.input_size, device=dev), "alpha": torch.full((B, 1), 0.5, device=dev)}
+        K = kernels.impl()
+
+        def critic_body():
+            with K.weight_cache():
+                return self._critic_body(g["real"], g["noise_c"], g["alpha"])
+
+        def gen_body():
+            with K.weight_cache():
+                return self._generator_body(g["real"], g["noise_g"])
+
+        mods = [self.gen, self.critic]
+        saved = [[b.clone() for b in m.buffers()] for m in mods]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        quiet = [x.suspended() for x in (self.x_critic, self.x_gen) if x is not None]
+        with torch.cuda.stream(side), contextlib.ExitStack() as es:
+            for q in quiet:
+                es.enter_context(q)
+            critic_body()
+            gen_body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.optim_critic.zero_grad(set_to_none=True)
+        self.optim_gen.zero_grad(set_to_none=True)
+        g["critic"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["critic"]):
+            g["critic_out"] = critic_body()
+        g["critic_grads"] = [p.grad for p in self.critic.parameters()]
+        g["gen"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["gen"], pool=g["critic"].pool()):
+            g["gen_out"] = gen_body()
+        g["gen_grads"] = [p.grad for p in self.gen.parameters()]
+        with torch.no_grad():
+            for m, bufs in zip(mods, saved):
+                for b, v in zip(m.buffers(), bufs):
+                    b.copy_(v)
+        torch.cuda.synchronize(dev)
+        self._graphs[key] = g
+        return g
 
 
 # =========================================================================================== phase 1
