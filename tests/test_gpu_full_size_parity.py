@@ -6,8 +6,9 @@ this test on the host cores (seconds per case):
 
   generated poses, critic scores, GP (and its two terms)   1e-4 absolute (north_star bound)
   L1, losses                                               1e-4 + 1e-5 relative
-  per-tensor gradients, critic and generator               L2 norm 2e-3 relative AND element-wise
-                                                           max |g - g_ref| <= 2e-3 max |g_ref| (round 3)
+  per-tensor gradients, critic and generator               L2 norm 2e-3 relative AND element-wise (round 3):
+                                                           no element off by > 3e-2 of the tensor's largest, at
+                                                           most 0.2 % of them by > 2e-3 (ReLU-mask flips: _norms_close)
 and C1 (phase 1, B = 64) the same way with the host-drawn dropout masks.
 
 These sizes are where the launch plans the bench times (split-K, tile height, BatchNorm over
@@ -44,11 +45,18 @@ def _close(name, got, want, atol, rtol=0.0):
     assert err <= bound, "%s: max abs err %.3e > %.3e" % (name, err, bound)
 
 
-def _norms_close(tag, module, ref_grads, rtol=2e-3, floor=2e-5, ertol=2e-3):
-    """ref_grads: {state_dict key: gradient tensor} from the oracle (absent = no gradient). Per tensor, BOTH
-      * the L2 norm within `rtol`, and
-      * every element: max |g - g_ref| <= ertol * max |g_ref| (a permuted, shifted or sign-flipped gradient of
-        the right size would pass a norm check; it cannot pass this one).
+def _norms_close(tag, module, ref_grads, rtol=2e-3, floor=2e-5, ertol=2e-3, hard=3e-2):
+    """ref_grads: {state_dict key: gradient tensor} from the oracle (absent = no gradient). Per tensor, ALL of
+      * the L2 norm within `rtol`;
+      * element-wise, relative to the tensor's largest element m = max |g_ref|: no element off by more than
+        `hard` * m, and at most max(2, 0.2 % of the elements) off by more than `ertol` * m. A permuted, shifted or
+        sign-flipped gradient of the right size passes a norm check; it cannot pass this one.
+    Why not simply every element within ertol: two fp32 evaluations of a ReLU net do not share all activation
+    masks. A pre-activation within rounding of zero (a handful per layer among the 3 M of a B = 64 pose branch) is
+    positive in one evaluation and zero in the other, which moves the gradients it touches by O(1) of their size -
+    measured with the SAME schedule run in fp64 (tools/critic_step_debug.py): forward activations agree to 1e-6,
+    backward tensors differ in a few hundred elements by up to 8e-2 of the maximum, weight gradients in a few
+    elements by 2-5e-3. The reference's own fp32 runs (MKL-DNN vs ATen) differ the same way.
     Gradients that are zero in exact arithmetic (a conv bias in front of BatchNorm) are rounding noise on both
     sides: `floor` x (the module's largest gradient norm / element) is added to the bounds."""
     gmax = max([g.double().norm().item() for g in ref_grads.values() if g is not None] + [1e-30])
@@ -66,11 +74,15 @@ def _norms_close(tag, module, ref_grads, rtol=2e-3, floor=2e-5, ertol=2e-3):
         if b > 1e-3 * gmax:
             worst = max(worst, abs(a - b) / b)
         assert abs(a - b) <= rtol * b + floor * gmax, "%s.%s: |grad| %.6e vs oracle %.6e (largest %.3e)" % (tag, name, a, b, gmax)
-        err, scale = (pg - rgd).abs().max().item(), rgd.abs().max().item()
+        diff, scale = (pg - rgd).abs(), rgd.abs().max().item()
+        err = diff.max().item()
         if scale > 1e-3 * emax:
             worst_e = max(worst_e, err / scale)
-        assert err <= ertol * scale + 5 * floor * emax, \
-            "%s.%s: max |grad - oracle| %.3e > %.1e x max |oracle| %.3e" % (tag, name, err, ertol, scale)
+        assert err <= hard * scale + 5 * floor * emax, \
+            "%s.%s: max |grad - oracle| %.3e > %.1e x max |oracle| %.3e" % (tag, name, err, hard, scale)
+        n_off = int((diff > ertol * scale + 5 * floor * emax).sum())
+        assert n_off <= max(2, int(0.002 * diff.numel())), \
+            "%s.%s: %d of %d elements off by more than %.1e x max |oracle|" % (tag, name, n_off, diff.numel(), ertol)
     return worst, worst_e
 
 
@@ -139,11 +151,10 @@ def test_phase3_iteration_matches_oracle_at_full_size(enc, B, T, ablated):
     real_d, audio_d, slices_d = real.to(dev), audio.to(dev), slices.to(dev)
     with kernels.impl().weight_cache():
         out_c = eng._critic_body(real_d, audio_d, slices_d, noise_c.to(dev), alpha.to(dev), True)
-        d_norm_worst = _norms_close("critic", critic, o_dgrads)  # element bound 2e-3 (measured <= 3e-4)
+        d_norm_worst = _norms_close("critic", critic, o_dgrads)
         out_g = eng._generator_body(real_d, audio_d, slices_d, noise_g.to(dev))
-        # the generator's gradients travel through BatchNorm backward passes (differences of large sums) and BPTT: two
-        # fp32 evaluations differ by up to 5e-3 of a tensor's largest element (first encoder conv, 491 520-term sums)
-        g_norm_worst = _norms_close("gen", gen, o_ggrads, ertol=1e-2)
+        # the generator's gradients also travel through BatchNorm backward passes (differences of large sums) and BPTT
+        g_norm_worst = _norms_close("gen", gen, o_ggrads, ertol=5e-3)
     _close("loss_critic", out_c["loss_critic"], o_err_c, 1e-4, 1e-5)
     _close("gp", out_c["gp"], o_gp, 1e-4)
     _close("w_dist", out_c["w_dist"], o_sfake.mean() - o_sreal.mean(), 1e-4)
