@@ -192,7 +192,11 @@ int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float*
 int m2d_gru_persist_error(void);
 int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* const* saved,
                       const float* const* w_hh, const float* const* w_ih, float* const* dgi, float* const* dgh,
-                      float* const* dh_buf, const int* lengths, int B, int T, int H, int L, void* stream);
+                      float* const* dh_buf, const int* lengths, int B, int T, int H, int L, unsigned* counters,
+                      void* stream);
+/* `counters` of m2d_gru_stack_bwd (optional, m2d_gru_stack_counters(B, L) unsigneds of scratch owned by the call): with
+ * them the whole back-propagation through time runs as ONE persistent launch too (round 3): weight slices in LDS,
+ * dgh_l[t+1] / dgi_{l+1}[t] handed over between CUs inside the launch; bit-identical to the per-step launches. */
 
 /* ---- gradient penalty (losses.py:5-60) ----------------------------------------------------- */
 int m2d_gp_interpolate(const float* real, const float* fake, const float* alpha, float* out, int B, int n,

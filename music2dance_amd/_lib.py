@@ -53,7 +53,7 @@ SIGNATURES = {
     "m2d_gru_stack_counters": (_I, [_I, _I]),
     "m2d_gru_stack_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F, _F]),
     "m2d_gru_persist_error": (_I, []),
-    "m2d_gru_stack_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F]),
+    "m2d_gru_stack_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F, _F]),
     "m2d_gp_interpolate": (_I, [_F, _F, _F, _F, _I, _I, _F]),
     "m2d_gp_penalty_workspace_bytes": (_S, [_I]),
     "m2d_gp_penalty_fwd": (_I, [_F, _F, _F, _I, _I, _I, _F, _S, _F]),

@@ -642,8 +642,10 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_stack_bwd_kernel(cons
   const bool rok = arow < a.B, cok = bcol < H;
   const bool has_next = (t + 1) < T;
   const bool has_up = (l + 1) < a.L;
-  if (has_next) gru_mac1<NW>(a.dgh[l] + ((size_t)arow * T + (t + 1)) * 3 * H, rok, a.w_hh[l], 3 * H, H, bcol, cok, wave, lane, acc);
+  // upper-layer part first, next-step part second: the persistent kernel (below) can then multiply the layer above's
+  // gradient while it still waits for its own layer's next step; same order = same bits
   if (has_up) gru_mac1<NW>(a.dgi[l + 1] + ((size_t)arow * T + t) * 3 * H, rok, a.w_ih[l + 1], 3 * H, H, bcol, cok, wave, lane, acc);
+  if (has_next) gru_mac1<NW>(a.dgh[l] + ((size_t)arow * T + (t + 1)) * 3 * H, rok, a.w_hh[l], 3 * H, H, bcol, cok, wave, lane, acc);
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
   __syncthreads();
@@ -670,6 +672,142 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_stack_bwd_kernel(cons
   gi[u] = dr_pre; gi[H + u] = dz_pre; gi[2 * H + u] = dn_pre;
   gh[u] = dr_pre; gh[H + u] = dz_pre; gh[2 * H + u] = dn_pre * r;
   a.dh_buf[l][((size_t)(t & 1) * a.B + b) * H + u] = dh;
+}
+
+// -----------------------------------------------------------------------------------------
+// Persistent backward: ONE launch for the whole L-layer BPTT (round 3; same hand-off as the forward).
+// Workgroup (hidden tile, batch tile, layer) keeps W_hh_l[:, 16 units] and W_ih_{l+1}[:, 16 units] (2 x 3H x 16
+// floats = 92 KB at H = 240) in LDS and walks t = T-1 .. 0:
+//   upper part   dgi_{l+1}[t] (16 rows x 3H, written by the layer above's workgroups in this launch: `sc1` loads
+//                after its counter shows step t done) times W_ih_{l+1};
+//   next part    dgh_l[t+1] (own layer, all hidden tiles: the critical dependency) times W_hh_l;
+//   gates        dh = sum (+ dout for the top layer) + dh_{t+1} * z_{t+1} (the owner thread's own register),
+//                gate derivatives -> dgi_l[t], dgh_l[t] with `sc1` stores; drain, barrier, ONE lane signals.
+// K-step assignment, MFMA order and the cross-wave sum are those of m2d_gru_stack_bwd_kernel: bit-identical.
+struct GruPersistBwdArgs {
+  GruStackBwdArgs s;
+  unsigned* counters;  // [L][nbt] x GRU_CNT_STRIDE, zeroed before the launch
+  unsigned* error;
+  unsigned spin_limit;
+};
+
+#define GRU_BWD_UN 24  // k-steps per wave and contraction: covers 3H <= 4 * 8 * 24 = 768 (H <= 256)
+__global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(const GruPersistBwdArgs pa) {
+  constexpr int NW = GRU_BWD_NW;
+  constexpr int UN = GRU_BWD_UN;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GruStackBwdArgs& a = pa.s;
+  const int H = a.H, T = a.T, K = 3 * a.H;
+  float* whh = lds;                        // [3H][16]: W_hh_l[k][u0 + c]
+  float* wih = whh + (size_t)K * 16;       // [3H][16]: W_ih_{l+1}[k][u0 + c]
+  float (*red)[256] = reinterpret_cast<float (*)[256]>(wih + (size_t)K * 16);
+  __shared__ int go;
+  const int l = blockIdx.z, bt = blockIdx.y;
+  const int nth = gridDim.x, nbt = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * 16, b0 = bt * 16;
+  const bool has_up = (l + 1) < a.L;
+  for (int e = tid; e < K * 16; e += 64 * NW) {
+    const int k = e >> 4, u = u0 + (e & 15);
+    whh[e] = u < H ? a.w_hh[l][(size_t)k * H + u] : 0.f;
+    wih[e] = (has_up && u < H) ? a.w_ih[l + 1][(size_t)k * H + u] : 0.f;
+  }
+  __syncthreads();
+  const int arow = b0 + (lane & 15);
+  const bool rok = arow < a.B;
+  const int nsteps = (K + 3) / 4;
+  const int row = (tid & 255) >> 4, col = tid & 15;
+  const int b = b0 + row, u = u0 + col;
+  const bool owner = tid < 256 && b < a.B && u < H;
+  const size_t plane = (size_t)a.B * T * H;
+  const float* sv = a.saved[l];
+  float dh_next = 0.f;  // this thread's dL/dh_{t+1} (owner threads)
+  unsigned* my_cnt = pa.counters + ((size_t)l * nbt + bt) * GRU_CNT_STRIDE;
+  unsigned* up_cnt = pa.counters + ((size_t)(has_up ? l + 1 : l) * nbt + bt) * GRU_CNT_STRIDE;
+
+  for (int t = T - 1; t >= 0; --t) {
+    const bool has_next = (t + 1) < T;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // values written before the launch: fetched under the waits
+    float r = 0.f, z = 0.f, n = 0.f, hn = 0.f, hprev = 0.f, znext = 0.f, dtop = 0.f;
+    if (owner) {
+      const size_t bt_ = (size_t)b * T + t;
+      r = sv[bt_ * H + u]; z = sv[plane + bt_ * H + u]; n = sv[2 * plane + bt_ * H + u]; hn = sv[3 * plane + bt_ * H + u];
+      hprev = t > 0 ? a.out[l][(bt_ - 1) * H + u] : 0.f;
+      znext = has_next ? sv[plane + (bt_ + 1) * H + u] : 0.f;
+      dtop = has_up ? 0.f : a.dout[bt_ * H + u];
+    }
+    // ---- upper part: step t of the layer above (it runs one step ahead of this layer)
+    if (has_up) {
+      if (tid == 0) go = gru_wait_ge(up_cnt, (unsigned)nth * (unsigned)(T - t), pa.error, pa.spin_limit) ? 1 : 0;
+      __syncthreads();
+      if (!go) return;
+      float av[UN];
+      const float* ap = a.dgi[l + 1] + ((size_t)arow * T + t) * K;
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int st = wave + NW * i;
+        const int k = 4 * st + (lane >> 4);
+        av[i] = (st < nsteps && k < K && rok) ? gru_ld_sc1(ap + k) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int st = wave + NW * i;
+        const int k = 4 * st + (lane >> 4);
+        const bool kok = st < nsteps && k < K;
+        const float bv = kok ? wih[(size_t)k * 16 + (lane & 15)] : 0.f;
+        if (st < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc, 0, 0, 0);
+      }
+    }
+    // ---- next part: step t+1 of every hidden tile of this layer
+    if (has_next) {
+      if (nth > 1) {
+        __syncthreads();  // everybody is past the previous read of `go`
+        if (tid == 0) go = gru_wait_ge(my_cnt, (unsigned)nth * (unsigned)(T - 1 - t), pa.error, pa.spin_limit) ? 1 : 0;
+        __syncthreads();
+        if (!go) return;
+      }
+      float av[UN];
+      const float* ap = a.dgh[l] + ((size_t)arow * T + (t + 1)) * K;
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int st = wave + NW * i;
+        const int k = 4 * st + (lane >> 4);
+        av[i] = (st < nsteps && k < K && rok) ? gru_ld_sc1(ap + k) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int st = wave + NW * i;
+        const int k = 4 * st + (lane >> 4);
+        const bool kok = st < nsteps && k < K;
+        const float bv = kok ? whh[(size_t)k * 16 + (lane & 15)] : 0.f;
+        if (st < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
+    __syncthreads();
+    if (owner) {
+      const size_t bt_ = (size_t)b * T + t;
+      float dh = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) dh += red[w][tid];
+      if (!has_up) dh += dtop;
+      if (has_next) dh += dh_next * znext;
+      if (a.lengths && t >= a.lengths[b]) dh = 0.f;
+      const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+      const float dz_pre = dh * (hprev - n) * z * (1.f - z);
+      const float dr_pre = dn_pre * hn * r * (1.f - r);
+      float* gi = a.dgi[l] + bt_ * K;
+      float* gh = a.dgh[l] + bt_ * K;
+      gru_st_sc1(gi + u, dr_pre); gru_st_sc1(gi + H + u, dz_pre); gru_st_sc1(gi + 2 * H + u, dn_pre);
+      gru_st_sc1(gh + u, dr_pre); gru_st_sc1(gh + H + u, dz_pre); gru_st_sc1(gh + 2 * H + u, dn_pre * r);
+      dh_next = dh;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add((gru_gu32*)my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ---- persistent-launch state (per device): counters, host-visible error word, limits -------------
@@ -713,19 +851,23 @@ static GruPersistState* gru_persist_state() {
     if (hipFuncSetAttribute((const void*)m2d_gru_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             140 * 1024) != hipSuccess)
       return &ps;
+    if (hipFuncSetAttribute((const void*)m2d_gru_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            140 * 1024) != hipSuccess)
+      return &ps;
     ps.usable = true;
   }
   return ps.usable ? &ps : nullptr;
 }
 
 static size_t gru_persist_lds(int H) { return ((size_t)2 * H * 48 + (size_t)GRU_FWD_NW * 4 * 256) * sizeof(float); }
+static size_t gru_persist_bwd_lds(int H) { return ((size_t)2 * 3 * H * 16 + (size_t)GRU_BWD_NW * 256) * sizeof(float); }
 
 // every workgroup must be resident at once: one per CU (the LDS footprint allows no second one)
-static bool gru_persist_ok(dim3 grid, int H, int T) {
+static bool gru_persist_ok(dim3 grid, int H, int T, bool backward = false) {
   if (H > 256 || T < 4) return false;
   GruPersistState* ps = gru_persist_state();
   if (!ps) return false;
-  const size_t lds = gru_persist_lds(H);
+  const size_t lds = backward ? gru_persist_bwd_lds(H) : gru_persist_lds(H);
   if (lds > 140 * 1024 || (int)lds > ps->max_lds) return false;
   const int per_cu = lds > 0 ? (int)((size_t)ps->max_lds / lds) : 1;
   const long long blocks = (long long)grid.x * grid.y * grid.z;
@@ -795,7 +937,8 @@ int m2d_gru_persist_error(void) {
 // BPTT for the whole stack on the anti-diagonal. dgi[l], dgh[l]: (B, T, 3H); dh_buf[l]: 2*B*H floats.
 int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* const* saved,
                       const float* const* w_hh, const float* const* w_ih, float* const* dgi, float* const* dgh,
-                      float* const* dh_buf, const int* lengths, int B, int T, int H, int L, void* stream_) {
+                      float* const* dh_buf, const int* lengths, int B, int T, int H, int L, unsigned* counters,
+                      void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || T <= 0 || H <= 0 || L <= 0 || L > GRU_MAX_LAYERS) M2D_FAIL(M2D_ERR_ARG, "m2d_gru_stack_bwd: bad shape");
   GruStackBwdArgs a;
@@ -808,6 +951,21 @@ int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* c
   a.B = B; a.T = T; a.H = H; a.L = L;
   dim3 grid(m2d_ceil_div(H, 16), m2d_ceil_div(B, 16), L);
   M2dProfScope prof(M2D_FAM_GRU, stream, 2.0 * B * 3.0 * H * H * (double)T * (2 * L - 1), 0.0, "gru_stack_bwd", B, T, H);
+  // `counters` (optional, m2d_gru_stack_counters(B, L) unsigneds owned by this call): the whole BPTT as ONE
+  // persistent launch when every workgroup fits on the chip at once
+  if (counters && gru_persist_ok(grid, H, T, true)) {
+    GruPersistState* ps = gru_persist_state();
+    if (ps && hipMemsetAsync(counters, 0, sizeof(unsigned) * (size_t)m2d_gru_stack_counters(B, L), stream) == hipSuccess) {
+      GruPersistBwdArgs pa;
+      pa.s = a;
+      pa.counters = counters;
+      pa.error = ps->error_dev;
+      pa.spin_limit = ps->spin_limit;
+      hipLaunchKernelGGL(m2d_gru_persist_bwd_kernel, grid, dim3(64 * GRU_BWD_NW), gru_persist_bwd_lds(H), stream, pa);
+      M2D_CHECK_LAUNCH("m2d_gru_persist_bwd_kernel");
+      return M2D_OK;
+    }
+  }
   for (int e = 0; e < T + L - 1; ++e) {
     a.e = e;
     hipLaunchKernelGGL(m2d_gru_stack_bwd_kernel, grid, dim3(64 * GRU_BWD_NW), 0, stream, a);

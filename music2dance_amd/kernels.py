@@ -574,8 +574,9 @@ class HipKernels:
             raise _lib.M2dError("persistent GRU launch timed out: outputs of that call are invalid "
                                 "(several processes on one GPU? set M2D_PERSISTENT_GRU=0)")
 
-    def gru_stack_bwd(self, dout, outs, saved, w_hh, w_ih, lengths=None):
-        """BPTT of the stack; returns ([dgi_l (B,T,3H)], [dgh_l (B,T,3H)])."""
+    def gru_stack_bwd(self, dout, outs, saved, w_hh, w_ih, lengths=None, persistent=True):
+        """BPTT of the stack; returns ([dgi_l (B,T,3H)], [dgh_l (B,T,3H)]). persistent: one launch for the whole
+        recurrence when the library finds room for it (bit-identical to the step launches)."""
         L = len(outs)
         dev = _chk(dout, *outs, *saved, *w_hh, *[t for t in w_ih if t is not None])
         B, T, H = outs[0].shape
@@ -583,9 +584,12 @@ class HipKernels:
         dgh = [torch.empty((B, T, 3 * H), dtype=torch.float32, device=dev) for _ in range(L)]
         dhb = [torch.empty((2, B, H), dtype=torch.float32, device=dev) for _ in range(L)]
         keep = [self._ptr_array(v) for v in (outs, saved, w_hh, w_ih, dgi, dgh, dhb)]
+        h = _lib.lib()
+        counters = (torch.empty((h.m2d_gru_stack_counters(B, L),), dtype=torch.int32, device=dev)
+                    if persistent else None)
         with _on(dev):
-            rc = _lib.lib().m2d_gru_stack_bwd(_ptr(dout), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
-                                              keep[5][1], keep[6][1], _ptr(lengths), B, T, H, L, _stream(dev))
+            rc = h.m2d_gru_stack_bwd(_ptr(dout), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
+                                     keep[5][1], keep[6][1], _ptr(lengths), B, T, H, L, _ptr(counters), _stream(dev))
         _lib.check(rc, "m2d_gru_stack_bwd")
         return dgi, dgh
 

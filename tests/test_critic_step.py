@@ -79,7 +79,7 @@ def _compare(critic, real, fake_rows, alpha, audio, gamma, lp, rtol, flips=False
             # flips; see tests/test_gpu_full_size_parity.py::_norms_close): a few elements may move by O(1e-3 .. 1e-2)
             assert err <= 3e-2 * scale + 1e-9, "%s: max |manual - autograd| %.3e vs max |autograd| %.3e" % (n, err, scale)
             n_off = int((diff > rtol * scale + 1e-9).sum())
-            assert n_off <= max(2, int(0.002 * diff.numel())), "%s: %d of %d elements off by > %.0e" % (n, n_off, diff.numel(), rtol)
+            assert n_off <= max(2, int(0.02 * diff.numel())), "%s: %d of %d elements off by > %.0e" % (n, n_off, diff.numel(), rtol)
         else:
             assert err <= rtol * scale + 1e-9, "%s: max |manual - autograd| %.3e vs max |autograd| %.3e" % (n, err, scale)
     return worst

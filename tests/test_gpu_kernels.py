@@ -671,6 +671,41 @@ def test_persistent_gru_is_bit_identical_to_the_step_launches(dims):
             assert torch.equal(saved[l], ref_s[l]), (trial, l)
 
 
+@pytest.mark.parametrize("dims", [(64, 120, 240, 3), (16, 300, 240, 3), (32, 120, 50, 3), (64, 120, 10, 1), (5, 7, 33, 2)],
+                         ids=lambda d: "B%d-T%d-H%d-L%d" % d)
+def test_persistent_gru_backward_is_bit_identical_to_the_step_launches(dims):
+    """Back-propagation through time as ONE persistent launch (round 3) against the T + L - 1 anti-diagonal step
+    launches: same k-step assignment, MFMA order and cross-wave sum, so dgi / dgh of every layer must be equal word
+    for word - alone and under a concurrent stream of large GEMMs."""
+    B, T, H, L = dims
+    k = K()
+    g = torch.Generator().manual_seed(4)
+    gi0 = (torch.randn(B, T, 3 * H, generator=g) * 0.5).to(DEV)
+    w_hh = [(torch.randn(3 * H, H, generator=g) / math.sqrt(H)).to(DEV) for _ in range(L)]
+    w_ih = [None] + [(torch.randn(3 * H, H, generator=g) / math.sqrt(H)).to(DEV) for _ in range(L - 1)]
+    b_hh = [(torch.randn(3 * H, generator=g) * 0.1).to(DEV) for _ in range(L)]
+    b_ih = [None] + [(torch.randn(3 * H, generator=g) * 0.1).to(DEV) for _ in range(L - 1)]
+    lens = None if B != 5 else torch.tensor([7, 6, 4, 2, 1], dtype=torch.int32, device=DEV)
+    outs, saved = k.gru_stack_fwd(gi0, [None] + [w.t().contiguous() for w in w_ih[1:]], b_ih,
+                                  [w.t().contiguous() for w in w_hh], b_hh, lens, True, persistent=False)
+    dout = torch.randn(B, T, H, generator=g).to(DEV)
+    ref_gi, ref_gh = k.gru_stack_bwd(dout, outs, saved, w_hh, w_ih, lens, persistent=False)
+    a = torch.randn(4096, 4096, device=DEV)
+    side = torch.cuda.Stream()
+    for trial in range(3):
+        if trial:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    k.gemm(0, a, a)
+        dgi, dgh = k.gru_stack_bwd(dout, outs, saved, w_hh, w_ih, lens, persistent=True)
+        torch.cuda.synchronize()
+        k.check_async_errors()
+        for l in range(L):
+            assert torch.equal(dgi[l], ref_gi[l]), (trial, l)
+            assert torch.equal(dgh[l], ref_gh[l]), (trial, l)
+
+
 # ------------------------------------------------------------------------------ round 3: critic-step entry points
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_on_column_blocks_of_wider_buffers(mode):
