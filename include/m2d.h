@@ -103,6 +103,12 @@ int m2d_conv1d_bwd_weight_from(const float* x, const float* dy, float* dw, float
 int m2d_gemm_ld(int mode, const float* a, int lda, const float* b, int ldb, const float* bias, float* c, int ldc,
                 int M, int N, int K, int act, float slope, const float* a_mask, float a_mask_slope,
                 const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream);
+/* nn.Tanh of the `activ: tanh` heads (phase3/archis/default.py:75-76,102-103,134-135,309-310,339-340) and the two
+ * derivatives the penalty's double backward needs: gx = gy (1 - y^2); d gx / d y = -2 y g gy (d gx / d gy is
+ * m2d_tanh_bwd itself, applied to g). */
+int m2d_tanh_fwd(const float* x, float* y, size_t n, void* stream);
+int m2d_tanh_bwd(const float* gy, const float* y, float* gx, size_t n, void* stream);
+int m2d_tanh_bwd_bwd(const float* g, const float* gy, const float* y, float* g_y, size_t n, void* stream);
 int m2d_pose_pack3(const float* real, const float* fake, const float* alpha, float* out, int B, int T, int C,
                    void* stream);
 int m2d_wgan_critic_loss(const float* scores, int B, const float* pen0, const float* pen1, float gamma, float* out,

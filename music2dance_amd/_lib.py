@@ -33,6 +33,9 @@ SIGNATURES = {
     "m2d_conv1d_bwd_data_res": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _F, _f, _F, _S, _F]),
     "m2d_conv1d_bwd_weight_from": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _I, _F, _S, _F]),
     "m2d_gemm_ld": (_I, [_I, _F, _I, _F, _I, _F, _F, _I, _I, _I, _I, _I, _f, _F, _f, _F, _f, _F, _S, _F]),
+    "m2d_tanh_fwd": (_I, [_F, _F, _S, _F]),
+    "m2d_tanh_bwd": (_I, [_F, _F, _F, _S, _F]),
+    "m2d_tanh_bwd_bwd": (_I, [_F, _F, _F, _F, _S, _F]),
     "m2d_pose_pack3": (_I, [_F, _F, _F, _F, _I, _I, _I, _F]),
     "m2d_wgan_critic_loss": (_I, [_F, _I, _F, _F, _f, _F, _F]),
     "m2d_conv1d_fwd_windows": (_I, [_F, _I, _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _I, _f, _F, _F, _S, _F]),

@@ -607,22 +607,31 @@ struct GruStackBwdArgs {
   int B, T, H, L, e;
 };
 
+// acc += A[16 rows, K] * W[K, H][:, bcol]. K is walked in blocks of 16: wave w takes blocks w, w + NW, ...; inside a
+// block lane group q = lane >> 4 owns the four consecutive k = 16 j + 4 q + m, m = 0..3 (MFMA k-step m multiplies the
+// k's {16 j + m, + 4, + 8, + 12}): ONE 16-byte load per lane and block instead of four scattered dwords - the A rows
+// are gradients written by other CUs a step earlier, and the step is bound by the number of memory requests. The
+// persistent kernel below uses the same assignment and order (bit-identical sums).
 template <int NW>
 __device__ __forceinline__ void gru_mac1(const float* arow, bool rok, const float* w, int K, int H, int bcol, bool cok,
                                          int wave, int lane, f32x4& acc) {
-  // acc += A[16 rows, K] * W[K, H][:, bcol]
-  const int nsteps = (K + 3) / 4;
-  for (int s0 = wave; s0 < nsteps; s0 += NW * GRU_UNROLL) {
-    float av[GRU_UNROLL], bv[GRU_UNROLL];
+  const int nblk = (K + 15) / 16;
+  const int q = lane >> 4;
+  const bool vec = (K & 3) == 0;
+  for (int j = wave; j < nblk; j += NW) {
+    const int k0 = 16 * j + 4 * q;
+    float av[4], bv[4];
+    if (vec && k0 + 3 < K) {
+      const float4 v = rok ? *reinterpret_cast<const float4*>(arow + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < GRU_UNROLL; ++i) {
-      const int k = 4 * (s0 + NW * i) + (lane >> 4);
-      const bool kok = (s0 + NW * i) < nsteps && k < K;
-      av[i] = (rok && kok) ? arow[k] : 0.f;
-      bv[i] = (kok && cok) ? w[(size_t)k * H + bcol] : 0.f;
+      for (int m = 0; m < 4; ++m) av[m] = (rok && k0 + m < K) ? arow[k0 + m] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < GRU_UNROLL; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+    for (int m = 0; m < 4; ++m) bv[m] = (cok && k0 + m < K) ? w[(size_t)(k0 + m) * H + bcol] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[m], acc, 0, 0, 0);
   }
 }
 
@@ -691,13 +700,56 @@ struct GruPersistBwdArgs {
   unsigned spin_limit;
 };
 
-#define GRU_BWD_UN 24  // k-steps per wave and contraction: covers 3H <= 4 * 8 * 24 = 768 (H <= 256)
+// The persistent kernel's contraction: gru_mac1's block assignment, the A rows through `sc1` loads (16 bytes per
+// lane when K is a multiple of 4: raw buffer load, aux = sc1), W from the workgroup's LDS slice [K][16]. All loads of
+// the wave's (at most 6 at H = 240) blocks are issued before the first MFMA.
+#define GRU_BWD_MAXB 6  // blocks per wave: covers K = 3H <= 16 * 8 * 6 = 768 (H <= 256)
+typedef unsigned gru_u32x4 __attribute__((ext_vector_type(4)));
+template <int NW>
+__device__ __forceinline__ void gru_bwd_contract(const float* base, size_t row_off, bool rok, const float* wl, int K,
+                                                 int wave, int lane, bool vec, __amdgpu_buffer_rsrc_t rs, f32x4& acc) {
+  const int nblk = (K + 15) / 16;
+  const int q = lane >> 4;
+  float av[GRU_BWD_MAXB][4];
+#pragma unroll
+  for (int i = 0; i < GRU_BWD_MAXB; ++i) {
+    const int j = wave + NW * i;
+    const int k0 = 16 * j + 4 * q;
+    if (j < nblk && vec && k0 + 3 < K) {
+      // (rows past the batch read through offset 0x80000000: the descriptor's range check returns zeros)
+      const unsigned off = rok ? (unsigned)((row_off + k0) << 2) : 0x80000000u;
+      const gru_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16 /* sc1 */);
+      av[i][0] = __builtin_bit_cast(float, v[0]); av[i][1] = __builtin_bit_cast(float, v[1]);
+      av[i][2] = __builtin_bit_cast(float, v[2]); av[i][3] = __builtin_bit_cast(float, v[3]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) av[i][m] = (j < nblk && rok && k0 + m < K) ? gru_ld_sc1(base + row_off + k0 + m) : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GRU_BWD_MAXB; ++i) {
+    const int j = wave + NW * i;
+    if (j < nblk) {
+      const int k0 = 16 * j + 4 * q;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float bv = (k0 + m < K) ? wl[(size_t)(k0 + m) * 16 + (lane & 15)] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][m], bv, acc, 0, 0, 0);
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(const GruPersistBwdArgs pa) {
   constexpr int NW = GRU_BWD_NW;
-  constexpr int UN = GRU_BWD_UN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GruStackBwdArgs& a = pa.s;
   const int H = a.H, T = a.T, K = 3 * a.H;
+  const bool vec = (K & 3) == 0;
+  const unsigned gbytes = (unsigned)((size_t)a.B * T * K * sizeof(float));  // < 2^31: checked by the launcher
+  const __amdgpu_buffer_rsrc_t gh_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dgh[blockIdx.z], (short)0, (int)gbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gi_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.dgi[(int)blockIdx.z + 1 < a.L ? blockIdx.z + 1 : blockIdx.z], (short)0, (int)gbytes, 0x00020000);
   float* whh = lds;                        // [3H][16]: W_hh_l[k][u0 + c]
   float* wih = whh + (size_t)K * 16;       // [3H][16]: W_ih_{l+1}[k][u0 + c]
   float (*red)[256] = reinterpret_cast<float (*)[256]>(wih + (size_t)K * 16);
@@ -715,7 +767,6 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
   __syncthreads();
   const int arow = b0 + (lane & 15);
   const bool rok = arow < a.B;
-  const int nsteps = (K + 3) / 4;
   const int row = (tid & 255) >> 4, col = tid & 15;
   const int b = b0 + row, u = u0 + col;
   const bool owner = tid < 256 && b < a.B && u < H;
@@ -742,22 +793,7 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
       if (tid == 0) go = gru_wait_ge(up_cnt, (unsigned)nth * (unsigned)(T - t), pa.error, pa.spin_limit) ? 1 : 0;
       __syncthreads();
       if (!go) return;
-      float av[UN];
-      const float* ap = a.dgi[l + 1] + ((size_t)arow * T + t) * K;
-#pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int st = wave + NW * i;
-        const int k = 4 * st + (lane >> 4);
-        av[i] = (st < nsteps && k < K && rok) ? gru_ld_sc1(ap + k) : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int st = wave + NW * i;
-        const int k = 4 * st + (lane >> 4);
-        const bool kok = st < nsteps && k < K;
-        const float bv = kok ? wih[(size_t)k * 16 + (lane & 15)] : 0.f;
-        if (st < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc, 0, 0, 0);
-      }
+      gru_bwd_contract<NW>(a.dgi[l + 1], ((size_t)arow * T + t) * K, rok, wih, K, wave, lane, vec, gi_rs, acc);
     }
     // ---- next part: step t+1 of every hidden tile of this layer
     if (has_next) {
@@ -767,22 +803,7 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
         __syncthreads();
         if (!go) return;
       }
-      float av[UN];
-      const float* ap = a.dgh[l] + ((size_t)arow * T + (t + 1)) * K;
-#pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int st = wave + NW * i;
-        const int k = 4 * st + (lane >> 4);
-        av[i] = (st < nsteps && k < K && rok) ? gru_ld_sc1(ap + k) : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int st = wave + NW * i;
-        const int k = 4 * st + (lane >> 4);
-        const bool kok = st < nsteps && k < K;
-        const float bv = kok ? whh[(size_t)k * 16 + (lane & 15)] : 0.f;
-        if (st < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc, 0, 0, 0);
-      }
+      gru_bwd_contract<NW>(a.dgh[l], ((size_t)arow * T + (t + 1)) * K, rok, whh, K, wave, lane, vec, gh_rs, acc);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) red[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
@@ -953,7 +974,7 @@ int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* c
   M2dProfScope prof(M2D_FAM_GRU, stream, 2.0 * B * 3.0 * H * H * (double)T * (2 * L - 1), 0.0, "gru_stack_bwd", B, T, H);
   // `counters` (optional, m2d_gru_stack_counters(B, L) unsigneds owned by this call): the whole BPTT as ONE
   // persistent launch when every workgroup fits on the chip at once
-  if (counters && gru_persist_ok(grid, H, T, true)) {
+  if (counters && gru_persist_ok(grid, H, T, true) && (long long)B * T * 3 * H * 4 < 0x7fffffffLL) {
     GruPersistState* ps = gru_persist_state();
     if (ps && hipMemsetAsync(counters, 0, sizeof(unsigned) * (size_t)m2d_gru_stack_counters(B, L), stream) == hipSuccess) {
       GruPersistBwdArgs pa;

@@ -217,6 +217,25 @@ __global__ void __launch_bounds__(256) m2d_affine_cols_kernel(const float* x, co
   }
 }
 
+// ---------------------------------------------------------------- tanh heads (`activ: tanh`)
+// The 'tanh' switch of the encoders / critics (phase3/archis/default.py:75-76,102-103,134-135,309-310,339-340) on
+// the (N, code) head tensors, with the two derivatives the gradient penalty's double backward needs:
+//   y = tanh(x);   gx = gy * (1 - y^2);   d(gx)/d(gy) = g * (1 - y^2),  d(gx)/d(y) = -2 * y * g * gy
+__global__ void __launch_bounds__(256) m2d_tanh_fwd_kernel(const float* x, float* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = tanhf(x[i]);
+}
+__global__ void __launch_bounds__(256) m2d_tanh_bwd_kernel(const float* gy, const float* y, float* gx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = y[i];
+    gx[i] = gy[i] * (1.f - v * v);
+  }
+}
+__global__ void __launch_bounds__(256) m2d_tanh_bwd_bwd_kernel(const float* g, const float* gy, const float* y,
+                                                               float* g_y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    g_y[i] = -2.f * y[i] * g[i] * gy[i];
+}
+
 // ---------------------------------------------------------------- critic-iteration input pack
 // The critic iteration's three pose batches in ONE channels-first buffer (3B, C, T) - [interpolated | real | fake] -
 // from the loader's real poses (B, T, C) and the generator's rows (B*T, C) (phase3/train.py:196-199 permute +
@@ -483,6 +502,29 @@ int m2d_affine_cols(const float* x, const float* scale, const float* shift, floa
   hipLaunchKernelGGL(m2d_affine_cols_kernel, dim3(grid_for(rows * (size_t)cols)), dim3(256), 0, stream, x, scale,
                      shift, y, rows, cols);
   M2D_CHECK_LAUNCH("m2d_affine_cols");
+  return M2D_OK;
+}
+
+// nn.Tanh of the 'tanh' heads and its derivatives (see the kernels): closed under differentiation like the conv ops
+int m2d_tanh_fwd(const float* x, float* y, size_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return M2D_OK;
+  hipLaunchKernelGGL(m2d_tanh_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
+  M2D_CHECK_LAUNCH("m2d_tanh_fwd");
+  return M2D_OK;
+}
+int m2d_tanh_bwd(const float* gy, const float* y, float* gx, size_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return M2D_OK;
+  hipLaunchKernelGGL(m2d_tanh_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, gy, y, gx, n);
+  M2D_CHECK_LAUNCH("m2d_tanh_bwd");
+  return M2D_OK;
+}
+int m2d_tanh_bwd_bwd(const float* g, const float* gy, const float* y, float* g_y, size_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return M2D_OK;
+  hipLaunchKernelGGL(m2d_tanh_bwd_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, g, gy, y, g_y, n);
+  M2D_CHECK_LAUNCH("m2d_tanh_bwd_bwd");
   return M2D_OK;
 }
 

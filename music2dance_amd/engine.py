@@ -60,7 +60,8 @@ class WganGpEngine:
         # stay valid through the critic iterations of a cycle)
         self._keep_packs = os.environ.get("M2D_KEEP_PACKS", "1") != "0"
         self._critic_params = [p for p in critic.parameters() if p.dim() == 3] if self._keep_packs else None
-        self._gen_params = [p for p in gen.parameters() if p.dim() == 3] if self._keep_packs else None
+        # (the generator's 2-D GRU weights too: their transposes are cached the same way)
+        self._gen_params = [p for p in gen.parameters() if p.dim() in (2, 3)] if self._keep_packs else None
         self.total_iterations = 0
         # the critic's exchange (every iteration) starts bucket by bucket underneath its own backward pass
         self.x_critic = GradExchange(critic.parameters()).overlap_backward() if data_parallel else None

@@ -138,6 +138,7 @@ class HipKernels:
         else:
             for w in tensors:
                 self._packed.pop(id(w), None)
+                self._packed.pop((id(w), "T"), None)
 
     def packed_weights(self, w):
         """(w_fwd (Cin, ks, Cout), w_bwd (Cout, ks, Cin)): the K-major images of a conv weight the forward / backward-data
@@ -371,6 +372,52 @@ class HipKernels:
                                         out_mask_slope, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream(dev))
         _lib.check(rc, "m2d_gemm_ld")
         return c
+
+    # ---------------------------------------------------------------- tanh heads
+    def tanh_fwd(self, x):
+        dev = _chk(x)
+        y = torch.empty_like(x)
+        with _on(dev):
+            rc = _lib.lib().m2d_tanh_fwd(_ptr(x), _ptr(y), x.numel(), _stream(dev))
+        _lib.check(rc, "m2d_tanh_fwd")
+        return y
+
+    def tanh_bwd(self, gy, y):
+        """gy * (1 - y^2)"""
+        dev = _chk(gy, y)
+        gx = torch.empty_like(gy)
+        with _on(dev):
+            rc = _lib.lib().m2d_tanh_bwd(_ptr(gy), _ptr(y), _ptr(gx), gy.numel(), _stream(dev))
+        _lib.check(rc, "m2d_tanh_bwd")
+        return gx
+
+    def tanh_bwd_bwd(self, g, gy, y):
+        """-2 * y * g * gy: the gradient of tanh_bwd(gy, y) w.r.t. y for cotangent g"""
+        dev = _chk(g, gy, y)
+        out = torch.empty_like(y)
+        with _on(dev):
+            rc = _lib.lib().m2d_tanh_bwd_bwd(_ptr(g), _ptr(gy), _ptr(y), _ptr(out), y.numel(), _stream(dev))
+        _lib.check(rc, "m2d_tanh_bwd_bwd")
+        return out
+
+    def transposed(self, w):
+        """w.t().contiguous() of a 2-D weight (the GRU kernels read W^T), kept like the packed conv images: built
+        once per weight tensor inside a weight_cache() scope, dropped by invalidate_packed()."""
+        stream = _stream(w.device)
+        key = (id(w), "T")
+        if self._cache_depth > 0:
+            ent = self._packed.get(key)
+            if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == stream:
+                return ent[3]
+        wt = w.t().contiguous()
+        if self._cache_depth > 0:
+            packed = self._packed
+
+            def _drop(_ref, key=key):
+                packed.pop(key, None)
+
+            packed[key] = (weakref.ref(w, _drop), w._version, stream, wt)
+        return wt
 
     # ---------------------------------------------------------------- critic iteration: pack + loss
     def pose_pack3(self, real, fake_rows, alpha, out=None):

@@ -299,6 +299,52 @@ def conv1d_windows(track, T, hop, window, weight, bias=None, stride=1, padding=0
     return (y, sums) if with_stats else y
 
 
+# --------------------------------------------------------------------------------------- tanh heads
+class _Tanh(Function):
+    """nn.Tanh of the `activ: tanh` heads, twice differentiable through _TanhBwd (the critics' heads sit under the
+    gradient penalty's double backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        y = K().tanh_fwd(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if gy is None:
+            return None
+        (y,) = ctx.saved_tensors
+        return _TanhBwd.apply(gy, y)
+
+
+class _TanhBwd(Function):
+    """gx = gy * (1 - y^2); differentiable w.r.t. gy (the same map applied to g) and y (-2 y g gy)."""
+
+    @staticmethod
+    def forward(ctx, gy, y):
+        ctx.set_materialize_grads(False)
+        gy = _c(gy)
+        ctx.save_for_backward(gy, y)
+        return K().tanh_bwd(gy, y)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        gy, y = ctx.saved_tensors
+        g = _c(g)
+        g_gy = K().tanh_bwd(g, y) if ctx.needs_input_grad[0] else None
+        g_y = K().tanh_bwd_bwd(g, gy, y) if ctx.needs_input_grad[1] else None
+        return g_gy, g_y
+
+
+def tanh(x):
+    return _Tanh.apply(x)
+
+
 # --------------------------------------------------------------------------------------- linear
 class _LinearAct(Function):
     @staticmethod
@@ -479,7 +525,7 @@ class _GRULayer(Function):
         H = w_hh.shape[1]
         k = K()
         gi = k.gemm(0, x.view(B * T, I), w_ih, b_ih).view(B, T, 3 * H)
-        out, saved = k.gru_layer_fwd(gi, w_hh.t().contiguous(), b_hh, lengths, save)
+        out, saved = k.gru_layer_fwd(gi, k.transposed(w_hh), b_hh, lengths, save)
         if save:
             ctx.save_for_backward(x, w_ih, w_hh, out, saved, lengths)
         return out
@@ -520,8 +566,8 @@ class _GRUStack(Function):
         H = w_hh[0].shape[1]
         k = K()
         gi0 = k.gemm(0, x.view(B * T, I), w_ih[0], b_ih[0]).view(B, T, 3 * H)
-        outs, saved = k.gru_stack_fwd(gi0, [None] + [w.t().contiguous() for w in w_ih[1:]], [None] + b_ih[1:],
-                                      [w.t().contiguous() for w in w_hh], b_hh, lengths, save)
+        outs, saved = k.gru_stack_fwd(gi0, [None] + [k.transposed(w) for w in w_ih[1:]], [None] + b_ih[1:],
+                                      [k.transposed(w) for w in w_hh], b_hh, lengths, save)
         if save:
             ctx.save_for_backward(x, lengths, *w_ih, *w_hh, *outs, *saved)
             ctx.L = L

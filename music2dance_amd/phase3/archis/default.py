@@ -49,7 +49,7 @@ def _conv_bn(conv, bn, x, act, slope=0.0):
 def _head(module, conv, x, in_act=None):
     """last conv of an encoder / critic branch followed by the 'id'|'relu'|'tanh' switch"""
     y = conv(x, act=module._head_act, in_act=in_act)
-    return torch.tanh(y) if module._head_tanh else y
+    return ops.tanh(y) if module._head_tanh else y
 
 
 class NoiseGen(nn.Module):

@@ -102,6 +102,18 @@ class FakeKernels:
                 out_mask_slope=0.0, out=None):
         return self.gemm(mode, a, b, bias, act, slope, a_mask, a_mask_slope, out_mask, out_mask_slope, out)
 
+    def tanh_fwd(self, x):
+        return torch.tanh(x)
+
+    def tanh_bwd(self, gy, y):
+        return gy * (1 - y * y)
+
+    def tanh_bwd_bwd(self, g, gy, y):
+        return -2 * y * g * gy
+
+    def transposed(self, w):
+        return w.t().contiguous()
+
     def pose_pack3(self, real, fake_rows, alpha, out=None):
         B, T, C = real.shape
         fake = fake_rows.view(B, T, C)
