@@ -392,6 +392,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     p.O.cdiv_inv = b.rdiv_inv;
     p.O.c_off = 0;
     p.O.c_pos_off = 0;
+    p.O.c_lim = 0;  // every column (n, j), j < L, is an output position: no window test (16-byte epilogue rows)
     return m2d_gemm_launch(p, /*a_kfast=*/false, /*b_kfast=*/false, /*allow_split=*/true, ws, ws_bytes,
                            (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }

@@ -83,6 +83,9 @@ struct M2dOutMap {
   const float* residual;
   float* sum_out;
   int mask_last;
+  // set by the launcher when the tile can leave as 16-byte rows (m2d_tile_epilogue_wide): unit column stride, every
+  // pitch / offset / column count a multiple of 4, 16-byte aligned pointers, no window / redirect column
+  int wide;
   float mask_slope;
   float slope;            // LeakyReLU slope for act == 2
   int bias_mode;

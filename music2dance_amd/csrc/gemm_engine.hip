@@ -382,7 +382,118 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
   }
 }
 
-template <int BM, int BN, bool AKF, bool BKF, bool MASKED>
+// Wide tile epilogue: every 32x32 accumulator tile goes through a wave-private 4 KB LDS image (the stage buffers are
+// free after the last chunk) and leaves as 16-byte rows - 8 rows x 128 bytes per store instruction instead of 2 rows
+// x 128 bytes as dwords: a quarter of the store (and mask / residual load) instructions. Bias, activation, mask,
+// residual, second output and the row statistics are applied on the way out, in the same order as m2d_epilogue.
+// Requires O.wide (launcher-checked): unit column stride, all pitches / offsets / N multiples of 4, no column window.
+__device__ __forceinline__ float4 m2d_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void m2d_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int BM, int BN>
+__device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, const M2dOutMap& O, int N, int split,
+                                                       int m0, int n0, int wm, int wn, int lane, float* wl,
+                                                       f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int rl0 = lane >> 3, c4 = (lane & 7) * 4;  // read-back: lane -> row rl0 + 8 * it, columns c4 .. c4 + 3
+  const bool stats = O.row_part != nullptr && p.splits <= 1;
+  // one 32x32 tile at a time: its 16 registers die at the dump, so the pass over the image runs in the registers the
+  // main loop leaves free (the accumulators of the tiles still to come stay live) - and the loop over the four
+  // row groups is NOT unrolled: interleaving them would buy nothing but registers, i.e. resident waves
+  // BM = 128: both tiles of a 32-row band are dumped together (2 x 4 KB per wave = the whole 32 KB of stage buffers),
+  // so 32 accumulator registers die at once and the pass fits under the main loop's 89 registers (five waves per SIMD)
+  constexpr int NT = (BM == 128) ? TN : 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j0 = 0; j0 < TN; j0 += NT) {
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wl[jj * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[i][j0 + jj][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int jj = 0; jj < NT; ++jj) {
+      const int j = j0 + jj;
+      const float* wt = wl + jj * 1024;
+      const int col = n0 + wn * (TN * 32) + j * 32 + c4;
+      const bool cv = col < N;
+      int caddr = 0;
+      if (p.splits <= 1) {
+        int chi, clo;
+        m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
+        caddr = chi * O.c_hi_stride + clo + O.c_off;
+      }
+#pragma unroll 1
+      for (int it = 0; it < 4; ++it) {
+        const int rl = rl0 + 8 * it;
+        const int row = m0 + wm * (TM * 32) + i * 32 + rl;
+        const bool ok = row < p.M && cv;
+        float4 v = m2d_ld4(wt + rl * 32 + c4);
+        float a1 = 0.f, a2 = 0.f;
+        if (ok) {
+          if (p.splits > 1) {
+            m2d_st4(p.slab + (size_t)split * p.M * p.N + (size_t)row * p.N + col, v);
+          } else {
+            const int addr = row * O.m_stride + caddr;
+            if (O.bias_mode == 1) {
+              const float b = O.bias[row];
+              v.x += b; v.y += b; v.z += b; v.w += b;
+            } else if (O.bias_mode == 2) {
+              const float4 b = m2d_ld4(O.bias + col);
+              v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            if (O.act == 1) {
+              v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            } else if (O.act == 2) {
+              v.x = v.x > 0.f ? v.x : v.x * O.slope; v.y = v.y > 0.f ? v.y : v.y * O.slope;
+              v.z = v.z > 0.f ? v.z : v.z * O.slope; v.w = v.w > 0.f ? v.w : v.w * O.slope;
+            }
+            if (O.residual && O.mask_last) {
+              const float4 q = m2d_ld4(O.residual + addr);
+              v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            if (O.mask) {
+              const float4 m = m2d_ld4(O.mask + addr);
+              v.x *= m.x > 0.f ? 1.f : O.mask_slope; v.y *= m.y > 0.f ? 1.f : O.mask_slope;
+              v.z *= m.z > 0.f ? 1.f : O.mask_slope; v.w *= m.w > 0.f ? 1.f : O.mask_slope;
+            }
+            if (O.residual && !O.mask_last) {
+              const float4 q = m2d_ld4(O.residual + addr);
+              const float4 sum = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
+              if (O.sum_out) m2d_st4(O.sum_out + addr, sum);
+              else v = sum;
+            }
+            m2d_st4(O.out + addr, v);
+            a1 = (v.x + v.y) + (v.z + v.w);
+            a2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          }
+        }
+        if (stats) {  // this tile's 32 columns of the row: the 8 lanes that share it; one partial per (row, 32-column tile)
+#pragma unroll
+          for (int off = 4; off > 0; off >>= 1) {
+            a1 += __shfl_xor(a1, off, 64);
+            a2 += __shfl_xor(a2, off, 64);
+          }
+          if ((lane & 7) == 0 && row < p.M) {
+            float* dst = O.row_part + ((size_t)((blockIdx.x * WN + wn) * TN + j) * p.M + row) * 2;
+            dst[0] = a1;
+            dst[1] = a2;
+          }
+        }
+      }
+      }
+      __builtin_amdgcn_wave_barrier();  // the image is read before the next tiles overwrite it (one wave, in order)
+    }
+  }
+}
+
+template <int BM, int BN, bool AKF, bool BKF, bool MASKED, bool WIDE>
 __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p) {
   constexpr int LDA = BM + M2D_LDPAD;
   constexpr int LDB = BN + M2D_LDPAD;
@@ -499,7 +610,10 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
     }
   }
 
-  m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+  // (two instantiations, not a branch: with both epilogues in one kernel every accumulator stays live across the
+  // choice and the kernel needs 30 more registers, i.e. one resident wave per SIMD fewer)
+  if constexpr (WIDE) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+  else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 }
 
 // ---- LDS-direct staging variant ------------------------------------------------------------------------------------
@@ -539,7 +653,7 @@ __device__ __forceinline__ void m2d_chunk_mma_dl(const float* stage, int wm, int
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool WIDE>
 __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams p) {
   constexpr int WM = BM >= 64 ? 2 : 1;
   constexpr int WN = 4 / WM;
@@ -638,7 +752,10 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
       __syncthreads();
     }
   }
-  m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+  // (two instantiations, not a branch: with both epilogues in one kernel every accumulator stays live across the
+  // choice and the kernel needs 30 more registers, i.e. one resident wave per SIMD fewer)
+  if constexpr (WIDE) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+  else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 }
 
 // Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue. Eight
@@ -902,10 +1019,11 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_spli
 
 template <int BM, bool AKF, bool BKF>
 static void launch_tile(const M2dGemmParams& p, dim3 grid, hipStream_t stream) {
-  if (p.A.mask || p.B.mask)
-    hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, true>), grid, dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, false>), grid, dim3(256), 0, stream, p);
+  const bool masked = p.A.mask || p.B.mask;
+  if (masked && p.O.wide) hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, true, true>), grid, dim3(256), 0, stream, p);
+  else if (masked) hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, true, false>), grid, dim3(256), 0, stream, p);
+  else if (p.O.wide) hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, false, true>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((m2d_gemm_kernel<BM, 128, AKF, BKF, false, false>), grid, dim3(256), 0, stream, p);
 }
 
 // M2D_DL=0: keep row-fast / row-fast launches on the register-staging kernel (A/B lever)
@@ -919,7 +1037,8 @@ static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hi
   {
     if (!akf && !bkf && dl_enabled() && !p.A.mask && !p.B.mask && !p.A.ones_row_p1 && !p.B.ones_row_p1 &&
         p.A.rdiv2 <= 0 && p.B.rdiv2 <= 0 && p.A.kdiv2 <= 0 && p.B.kdiv2 <= 0) {
-      hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128>), grid, dim3(256), 0, stream, p);
+      if (p.O.wide) hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, true>), grid, dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, false>), grid, dim3(256), 0, stream, p);
       return 0;
     }
   }
@@ -1060,6 +1179,21 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
       g_plan_cache[key] = std::make_pair(bm, splits);
     }
   }
+  // 16-byte epilogue rows (m2d_tile_epilogue_wide) when the output map allows it (M2D_WIDE_EPILOGUE=0: never)
+  {
+    static const bool wide_on = [] { const char* e = getenv("M2D_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15u) == 0; };
+    const M2dOutMap& o = p.O;
+    bool w = wide_on && !p.bwd_data && (p.N % 4) == 0 && o.redirect_col_p1 == 0;
+    if (splits > 1) {
+      w = w && al16(ws);
+    } else {
+      w = w && o.c_lo_stride == 1 && o.c_lim <= 0 && (o.cdiv % 4) == 0 && (o.c_hi_stride % 4) == 0 &&
+          (o.m_stride % 4) == 0 && (o.c_off % 4) == 0 && al16(o.out) && al16(o.mask) && al16(o.residual) &&
+          al16(o.sum_out) && (o.bias_mode != 2 || al16(o.bias));
+    }
+    p.O.wide = w ? 1 : 0;
+  }
   double flops = 2.0 * p.M * (double)p.N * p.K;
   if (p.bwd_data) {
     flops = 0.0;
@@ -1078,7 +1212,8 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
     M2D_CHECK_LAUNCH(what);
     if (p.O.row_part) {
       if (!p.O.row_sums) M2D_FAIL(M2D_ERR_ARG, "%s: row statistics without a destination", what);
-      const int wn = bm >= 64 ? 2 : 4;
+      // partials per row: one per wave column of every N tile; the 16-byte epilogue writes one per 32-column tile
+      const int wn = p.O.wide ? 4 : (bm >= 64 ? 2 : 4);
       const int rc = m2d_rowsums_reduce(p.O.row_part, m2d_ceil_div(p.N, 128) * wn, p.M, p.O.row_sums,
                                         m2d_rowstats_scratch(p.O.row_part, p.M, p.N), stream);
       if (rc) return rc;

@@ -704,7 +704,8 @@ struct GruPersistBwdArgs {
 // lane when K is a multiple of 4: raw buffer load, aux = sc1), W from the workgroup's LDS slice [K][16]. All loads of
 // the wave's (at most 6 at H = 240) blocks are issued before the first MFMA.
 #define GRU_BWD_MAXB 6  // blocks per wave: covers K = 3H <= 16 * 8 * 6 = 768 (H <= 256)
-typedef unsigned gru_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gru_u32x4 __attribute__((__vector_size__(16)));
+typedef float gru_f32x4 __attribute__((__vector_size__(16)));
 template <int NW>
 __device__ __forceinline__ void gru_bwd_contract(const float* base, size_t row_off, bool rok, const float* wl, int K,
                                                  int wave, int lane, bool vec, __amdgpu_buffer_rsrc_t rs, f32x4& acc) {
@@ -718,9 +719,11 @@ __device__ __forceinline__ void gru_bwd_contract(const float* base, size_t row_o
     if (j < nblk && vec && k0 + 3 < K) {
       // (rows past the batch read through offset 0x80000000: the descriptor's range check returns zeros)
       const unsigned off = rok ? (unsigned)((row_off + k0) << 2) : 0x80000000u;
+      // (whole-vector bit cast: element-wise __builtin_bit_cast(float, v[i]) on the builtin's result is narrowed to
+      // ONE dword load by hipcc 7.2 - every element then reads as the first)
       const gru_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16 /* sc1 */);
-      av[i][0] = __builtin_bit_cast(float, v[0]); av[i][1] = __builtin_bit_cast(float, v[1]);
-      av[i][2] = __builtin_bit_cast(float, v[2]); av[i][3] = __builtin_bit_cast(float, v[3]);
+      const gru_f32x4 f = __builtin_bit_cast(gru_f32x4, v);
+      av[i][0] = f[0]; av[i][1] = f[1]; av[i][2] = f[2]; av[i][3] = f[3];
     } else {
 #pragma unroll
       for (int m = 0; m < 4; ++m) av[i][m] = (j < nblk && rok && k0 + m < K) ? gru_ld_sc1(base + row_off + k0 + m) : 0.f;

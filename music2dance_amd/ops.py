@@ -586,7 +586,8 @@ class _GRUStack(Function):
         B, T, I = x.shape
         H = w_hh[0].shape[1]
         k = K()
-        dgi, dgh = k.gru_stack_bwd(_c(dout), outs, saved, w_hh, [None] + w_ih[1:], lengths)
+        dgi, dgh = k.gru_stack_bwd(_c(dout), outs, saved, w_hh, [None] + w_ih[1:], lengths,
+                                   persistent=os.environ.get("M2D_GRU_BWD_PERSIST", "1") != "0")
         grads = []
         for l in range(L):
             dgi2, dgh2 = dgi[l].view(B * T, 3 * H), dgh[l].view(B * T, 3 * H)
