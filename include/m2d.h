@@ -93,6 +93,20 @@ int m2d_conv1d_fwd_sum(const float* x, const float* w, const float* w_packed, co
                        float* sum_out, int B, int Cin, int L, int Cout, int ks, int stride, int pad, int act,
                        float slope, const float* residual, const float* out_mask, float out_mask_slope, void* ws,
                        size_t ws_bytes, void* stream);
+/* Tap-vectorised stride-4 forward (round 3): for the audio critic's k25 / s4 layers (phase3/archis/default.py:298-303)
+ * the four taps 4g..4g+3 of one output position are 16 aligned bytes of x and consecutive positions are 16 bytes
+ * apart, so the conv's B operand is staged with `buffer_load_dwordx4 ... lds` (a contiguous kilobyte per wave) and
+ * read back as ds_read_b128 fragments; weights come from the packed image Wk4[(ci, tap group)][Cout][4]
+ * (m2d_conv1d_pack_weights_k4, m2d_conv1d_k4_packed_elems floats; phantom taps are zeros). Same results as
+ * m2d_conv1d_fwd up to summation order; m2d_conv1d_k4_applicable says whether a layer qualifies (stride 4,
+ * L % 4 == 0, Cin % 4 == 0, Cin >= 16, Cout >= 64). sum_out: optional second output as in m2d_conv1d_fwd_sum. */
+int m2d_conv1d_k4_applicable(int Cin, int L, int Cout, int ks, int stride, int pad);
+size_t m2d_conv1d_k4_packed_elems(int Cout, int Cin, int ks, int pad);
+int m2d_conv1d_pack_weights_k4(const float* w, float* out, int Cout, int Cin, int ks, int pad, void* stream);
+int m2d_conv1d_fwd_k4(const float* x, const float* w_k4, const float* bias, float* y, float* sum_out, int B, int Cin,
+                      int L, int Cout, int ks, int stride, int pad, int act, float slope, const float* residual,
+                      const float* out_mask, float out_mask_slope, double* stats, void* ws, size_t ws_bytes,
+                      void* stream);
 int m2d_conv1d_bwd_data_res(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
                             int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
                             const float* residual, const float* out_mask, float out_mask_slope, void* ws,

@@ -30,6 +30,10 @@ SIGNATURES = {
     "m2d_conv1d_pack_weights": (_I, [_F, _F, _F, _I, _I, _I, _F]),
     "m2d_conv1d_bwd_weight": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _S, _F]),
     "m2d_conv1d_fwd_sum": (_I, [_F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _I, _f, _F, _F, _f, _F, _S, _F]),
+    "m2d_conv1d_k4_applicable": (_I, [_I, _I, _I, _I, _I, _I]),
+    "m2d_conv1d_k4_packed_elems": (_S, [_I, _I, _I, _I]),
+    "m2d_conv1d_pack_weights_k4": (_I, [_F, _F, _I, _I, _I, _I, _F]),
+    "m2d_conv1d_fwd_k4": (_I, [_F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _I, _f, _F, _F, _f, _F, _F, _S, _F]),
     "m2d_conv1d_bwd_data_res": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _F, _f, _F, _S, _F]),
     "m2d_conv1d_bwd_weight_from": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _I, _F, _S, _F]),
     "m2d_gemm_ld": (_I, [_I, _F, _I, _F, _I, _F, _F, _I, _I, _I, _I, _I, _f, _F, _f, _F, _f, _F, _S, _F]),

@@ -253,6 +253,122 @@ int m2d_conv1d_fwd_sum(const float* x, const float* w, const float* w_packed, co
                          out_mask_slope, ws, ws_bytes, stream, nullptr, nullptr, sum_out);
 }
 
+}  // extern "C"
+
+// ---- tap-vectorised stride-4 forward (gemm_engine: m2d_conv_k4_kernel) ------------------------------------------------
+static inline int k4_shift(int pad) { return ((pad + 3) / 4) * 4 - pad; }                 // P - pad: phantom taps in front
+static inline int k4_groups(int ks, int pad) { return (ks + k4_shift(pad) + 3) / 4; }       // tap groups per channel
+
+// Wk4[(ci * NG + g) * Cout * 4 + co * 4 + m] = W[co][ci][4 g + m - (P - pad)], zero for taps outside [0, ks)
+__global__ void __launch_bounds__(256) m2d_pack_weights_k4_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                                    int Cout, int Cin, int ks, int ng, int shift) {
+  const size_t total = (size_t)Cin * ng * Cout * 4;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int m = (int)(idx & 3);
+    const size_t r = idx >> 2;
+    const int co = (int)(r % Cout);
+    const size_t kg = r / Cout;
+    const int g = (int)(kg % ng), ci = (int)(kg / ng);
+    const int tap = 4 * g + m - shift;
+    out[idx] = (tap >= 0 && tap < ks) ? w[((size_t)co * Cin + ci) * ks + tap] : 0.f;
+  }
+}
+
+extern "C" {
+
+// 1 when m2d_conv1d_fwd_k4 takes the layer: stride 4, L a multiple of 4 (tap groups never straddle a row end), Cin a
+// multiple of 4 in [16, 64], Cout >= 64, not a full-length kernel. Cin <= 64: measured at B = 64 (one box, alternating
+// runs), generic -> tap-vectorised: 32 -> 64 channels 402 -> 365 us, 64 -> 128: 365 -> 348, 128 -> 256: 325 -> 338 .. 370,
+// 256 -> 512: 301 -> 317. The kernel runs 97 - 111 TFLOP/s on the 28 tap slots it multiplies, but 3 of them are phantom
+// (k25: 12 %), and the wide layers' gathers were already served from L1 by the generic engine.
+int m2d_conv1d_k4_applicable(int Cin, int L, int Cout, int ks, int stride, int pad) {
+  const int Lout = conv_out_len(L, ks, stride, pad);
+  return stride == 4 && (L % 4) == 0 && (Cin % 4) == 0 && Cin >= 16 && Cin <= 64 && Cout >= 64 && Lout > 1 && ks >= 4 &&
+         k4_groups(ks, pad) >= 2;
+}
+
+// elements of the packed image m2d_conv1d_pack_weights_k4 writes: Cin * NG * Cout * 4
+size_t m2d_conv1d_k4_packed_elems(int Cout, int Cin, int ks, int pad) {
+  return (size_t)Cin * k4_groups(ks, pad) * Cout * 4;
+}
+
+int m2d_conv1d_pack_weights_k4(const float* w, float* out, int Cout, int Cin, int ks, int pad, void* stream) {
+  if (Cout <= 0 || Cin <= 0 || ks <= 0 || pad < 0 || !w || !out) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_pack_weights_k4: bad arguments");
+  const size_t total = m2d_conv1d_k4_packed_elems(Cout, Cin, ks, pad);
+  if (!fits_i32((long long)total)) M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_pack_weights_k4: too large");
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(m2d_pack_weights_k4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, ks,
+                     k4_groups(ks, pad), k4_shift(pad));
+  M2D_CHECK_LAUNCH("m2d_pack_weights_k4_kernel");
+  return M2D_OK;
+}
+
+// nn.Conv1d forward (stride 4) through the tap-vectorised kernel; `w_k4` from m2d_conv1d_pack_weights_k4 (same pad).
+// Epilogue arguments as m2d_conv1d_fwd / m2d_conv1d_fwd_sum (sum_out optional). Workspace: m2d_conv1d_workspace_bytes(0, ...).
+int m2d_conv1d_fwd_k4(const float* x, const float* w_k4, const float* bias, float* y, float* sum_out, int B, int Cin,
+                      int L, int Cout, int ks, int stride, int pad, int act, float slope, const float* residual,
+                      const float* out_mask, float out_mask_slope, double* stats, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (!m2d_conv1d_k4_applicable(Cin, L, Cout, ks, stride, pad))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd_k4: layer not eligible (stride 4, L %% 4 == 0, Cin %% 4 == 0, Cin >= 16, Cout >= 64)");
+  if (B <= 0 || !x || !w_k4 || !y) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd_k4: bad arguments");
+  if (sum_out && !residual) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd_k4: sum_out needs a residual");
+  const int Lout = conv_out_len(L, ks, stride, pad);
+  if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout))
+    M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd_k4: tensor exceeds 2^31 elements");
+  const int ng = k4_groups(ks, pad), P = pad + k4_shift(pad);
+  M2dGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = Cout;
+  p.N = B * Lout;
+  p.K = Cin * ks;   // real taps (reported work); the kernel multiplies Cin * ng * 4
+  p.nhi = Cin;
+  p.kdiv = 4 * ng;
+  p.k4_ng = ng;
+  p.phases = 1;
+  p.A.base = w_k4;
+  p.A.nbytes = m2d_extent_bytes((long long)m2d_conv1d_k4_packed_elems(Cout, Cin, ks, pad));
+  p.A.nrows = Cout;
+  p.A.r_lo_stride = Cout * 4;   // floats per tap group of the packed image
+  M2dOperand& b = p.B;
+  b.base = x;
+  b.nbytes = m2d_extent_bytes((long long)B * Cin * L);
+  b.nrows = p.N;
+  b.rdiv = Lout;
+  b.rdiv_inv = 1.f / (float)Lout;
+  b.r_hi_stride = Cin * L;
+  b.r_lo_stride = stride;
+  b.r_off = -P;
+  b.r_pos_mul = stride;
+  b.r_pos_off = -P;
+  b.k_hi_stride = L;
+  b.lim = L;
+  m2d_outmap_plain(p.O, y, Lout, 1);
+  p.O.cdiv = Lout;
+  p.O.cdiv_inv = 1.f / (float)Lout;
+  p.O.c_hi_stride = Cout * Lout;
+  p.O.c_lo_stride = 1;
+  p.O.bias = bias;
+  p.O.bias_mode = bias ? 1 : 0;
+  p.O.act = act;
+  p.O.slope = slope;
+  p.O.residual = residual;
+  p.O.sum_out = sum_out;
+  p.O.mask = out_mask;
+  p.O.mask_slope = out_mask_slope;
+  if (stats) {
+    if (!ws || ws_bytes < m2d_rowstats_bytes(p.M, p.N)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd_k4: no room for the statistics partials");
+    p.O.row_part = (float*)ws;
+    p.O.row_sums = stats;
+  }
+  return m2d_conv_k4_launch(p, /*allow_split=*/true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_fwd");
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // The first conv of an audio encoder applied to the windows of a padded track WITHOUT writing the
 // windows: replaces utils.slice_audio_batch (utils.py:329-353) + nn.Conv1d(1, Cout, ...) on the
 // (B*T, 1, window) slices (phase3/archis/default.py:27-28,64,90,117). track: (B, S) floats, window t of

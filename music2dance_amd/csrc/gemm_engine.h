@@ -138,6 +138,9 @@ struct M2dGemmParams {
   int ph_a_step;        // element offset of one tap in the A operand (0: ph_cout, the (Cin, ks, Cout) image)
   int splits;           // > 1: split-K, partial tiles go to slab[split][M*N]
   float* slab;
+  // tap-vectorised stride-4 forward conv (m2d_conv_k4_kernel): K is walked in groups of 4 consecutive taps of one
+  // channel, k4_ng groups per channel; B.k_hi_stride = the channel pitch (L)
+  int k4_ng;
 };
 
 struct M2dGemmPlan {
@@ -150,6 +153,9 @@ static inline int m2d_chunks(int nhi, int kdiv) { return nhi * ((kdiv + M2D_BK -
 M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty = 1.0);
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what);
+// the same for the tap-vectorised stride-4 forward conv (p.k4_ng > 0; operands as documented at the kernel)
+int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_bytes, hipStream_t stream,
+                       const char* what);
 
 static inline unsigned m2d_extent_bytes(long long elements) {
   const long long b = elements * 4;

@@ -758,6 +758,134 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 }
 
+// ---- tap-vectorised stride-4 forward conv ----------------------------------------------------------------------------
+// y[n, co, l] = sum_{ci, t} W[co, ci, t] x[n, ci, 4 l + t - pad]  (the audio critic's k25 / s4 layers,
+// phase3/archis/default.py:298-303, and the forward-mode tangent of the penalty through them).
+// With stride 4 the four taps t' = 4 g .. 4 g + 3 (t' = t + P - pad, P = pad rounded up to a multiple of 4) of one
+// output position are 16 contiguous, 16-byte ALIGNED bytes of x, and consecutive output positions are exactly 16
+// bytes apart: ONE `buffer_load_dwordx4 ... lds` per wave moves 64 rows x 4 taps as a contiguous kilobyte - where the
+// generic engine gathers the same floats as four dword loads that each touch a quarter of eight cache lines.
+// The LDS image is [tap group][row][4 taps]; a lane's fragment read is one ds_read_b128 (4 k's) instead of four
+// ds_read_b32, and the MFMA k-pairing follows (lanes 0-31 supply k = 8 s + m, lanes 32-63 k = 8 s + 4 + m: any
+// pairing is a valid contraction order as long as both operands use it). Per wave and 16-deep chunk: 4 LDS-DMA
+// instructions and 8 fragment reads for 32 MFMAs (generic LDS-direct kernel: 16 and 32).
+// K order: group index kg = ci * NG + g, NG = ceil((ks + P - pad) / 4) groups per channel (k25, pad 11: 7 groups = 28
+// taps, the 3 phantom taps carry zero weights: 12 % more MFMA work than the 25 real taps, paid back by the loads);
+// weights come pre-packed as Wk4[kg][Cout][4] (m2d_conv1d_pack_weights_k4). Groups never straddle the row ends
+// because L % 4 == 0 (launcher-checked), so padding is a per-lane out-of-range offset, as elsewhere.
+template <int BM, int BN, bool WIDE>
+__global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams p) {
+  static_assert(BM == 64 || BM == 128, "k4 kernel: 64- or 128-row tiles");
+  constexpr int WM = 2, WN = 2;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  constexpr int HA = BM / 64, HB = BN / 64;   // 64-row DMA pieces per tap group
+  constexpr int STAGE = 16 * (BM + BN);       // floats: 4 groups x (BM + BN) rows x 4 taps
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const M2dOperand& A = p.A;
+  const M2dOperand& B = p.B;
+  const int N = p.N;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int split = blockIdx.z;
+  const __amdgpu_buffer_rsrc_t ra = m2d_rsrc(A.base, A.nbytes);
+  const __amdgpu_buffer_rsrc_t rb = m2d_rsrc(B.base, B.nbytes);
+  // per-lane constants: wave w stages tap group (4 c + w) of every chunk c, all its 64-row pieces
+  unsigned va[HA], vb[HB];
+  int posb[HB];
+#pragma unroll
+  for (int h = 0; h < HA; ++h) {
+    const int row = m0 + h * 64 + lane;
+    va[h] = row < p.M ? (unsigned)row << 4 : M2D_OOB;
+  }
+#pragma unroll
+  for (int h = 0; h < HB; ++h) {
+    const int g = n0 + h * 64 + lane;
+    const bool rv = g < N;
+    int hi, lo;
+    m2d_divmod(rv ? g : 0, B.rdiv, B.rdiv_inv, hi, lo);
+    vb[h] = (unsigned)(hi * B.r_hi_stride + lo * B.r_lo_stride + B.r_off) << 2;
+    posb[h] = rv ? lo * B.r_pos_mul + B.r_pos_off : M2D_BAD;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ng = p.k4_ng;
+  const int nkg = p.nhi * ng;                      // nhi = Cin
+  const int nchunks = (nkg + 3) >> 2;
+  const int cps = (nchunks + p.splits - 1) / p.splits;
+  const int c0 = split * cps;
+  const int c1 = (c0 + cps < nchunks) ? (c0 + cps) : nchunks;
+  if (c0 < c1) {
+    // wave-uniform cursor of THIS wave's tap group: kg = 4 c + wave = (ci, g)
+    int kg = 4 * c0 + wave;
+    int ci = kg / ng;
+    int g = kg - ci * ng;
+    auto stage = [&](float* st) {
+      const bool kok = kg < nkg;
+      const int sa = kg * (A.r_lo_stride << 2);                // A.r_lo_stride = Cout * 4 floats per group
+      const int sb = (ci * B.k_hi_stride + 4 * g) << 2;
+      float* da = st + (wave * BM) * 4;
+      float* db = st + 16 * BM + (wave * BN) * 4;
+#pragma unroll
+      for (int h = 0; h < HA; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (m2d_lds_f*)(da + h * 256), 16, (int)(kok ? va[h] : M2D_OOB), sa, 0, 0);
+#pragma unroll
+      for (int h = 0; h < HB; ++h) {
+        // (the group's offset is added on the vector side: the hardware range check sees the vector offset only, and
+        // a row's own offset is negative for the first positions of the first sample - "x - P" in front of the tensor)
+        const bool ok = kok && (unsigned)(posb[h] + 4 * g) < (unsigned)B.lim;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (m2d_lds_f*)(db + h * 256), 16, (int)(ok ? vb[h] + (unsigned)sb : M2D_OOB), 0, 0, 0);
+      }
+      kg += 4;
+      g += 4;
+      if (g >= ng) { g -= ng; ci += 1; }
+      if (g >= ng) { g -= ng; ci += 1; }  // ng < 4 (short kernels): at most two wraps per step for ng >= 2
+    };
+    stage(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+      const int cur = (c - c0) & 1;
+      stage(smem + (cur ^ 1) * STAGE);  // chunk c + 1 (past the end: zeros or the next split's data, harmless)
+      const float* as = smem + cur * STAGE + (wm * (TM * 32) + l31) * 4;
+      const float* bs = smem + cur * STAGE + 16 * BM + (wn * (TN * 32) + l31) * 4;
+      float4 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[s2][i] = *reinterpret_cast<const float4*>(as + ((2 * s2 + lh) * BM + i * 32) * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[s2][j] = *reinterpret_cast<const float4*>(bs + ((2 * s2 + lh) * BN + j * 32) * 4);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2][i].x, fb[s2][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2][i].y, fb[s2][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2][i].z, fb[s2][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2][i].w, fb[s2][j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  const M2dOutMap& O = p.O;
+  if constexpr (WIDE) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+  else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+}
+
 // Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue. Eight
 // independent partial chains (slab z goes to chain z % 8, chains combined pairwise) keep eight
 // loads per thread in flight: one dependent chain over up to 128 slabs is latency-bound.
@@ -1086,6 +1214,22 @@ static bool autotune_enabled() {
   return on == 1;
 }
 
+// 16-byte epilogue rows (m2d_tile_epilogue_wide) when the output map allows it (M2D_WIDE_EPILOGUE=0: never)
+static void decide_wide(M2dGemmParams& p, int splits, const void* ws) {
+  static const bool wide_on = [] { const char* e = getenv("M2D_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15u) == 0; };
+  const M2dOutMap& o = p.O;
+  bool w = wide_on && !p.bwd_data && (p.N % 4) == 0 && o.redirect_col_p1 == 0;
+  if (splits > 1) {
+    w = w && al16(ws);
+  } else {
+    w = w && o.c_lo_stride == 1 && o.c_lim <= 0 && (o.cdiv % 4) == 0 && (o.c_hi_stride % 4) == 0 &&
+        (o.m_stride % 4) == 0 && (o.c_off % 4) == 0 && al16(o.out) && al16(o.mask) && al16(o.residual) &&
+        al16(o.sum_out) && (o.bias_mode != 2 || al16(o.bias));
+  }
+  p.O.wide = w ? 1 : 0;
+}
+
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what) {
   if (p.M <= 0 || p.N <= 0) return M2D_OK;
@@ -1179,21 +1323,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
       g_plan_cache[key] = std::make_pair(bm, splits);
     }
   }
-  // 16-byte epilogue rows (m2d_tile_epilogue_wide) when the output map allows it (M2D_WIDE_EPILOGUE=0: never)
-  {
-    static const bool wide_on = [] { const char* e = getenv("M2D_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
-    auto al16 = [](const void* q) { return ((uintptr_t)q & 15u) == 0; };
-    const M2dOutMap& o = p.O;
-    bool w = wide_on && !p.bwd_data && (p.N % 4) == 0 && o.redirect_col_p1 == 0;
-    if (splits > 1) {
-      w = w && al16(ws);
-    } else {
-      w = w && o.c_lo_stride == 1 && o.c_lim <= 0 && (o.cdiv % 4) == 0 && (o.c_hi_stride % 4) == 0 &&
-          (o.m_stride % 4) == 0 && (o.c_off % 4) == 0 && al16(o.out) && al16(o.mask) && al16(o.residual) &&
-          al16(o.sum_out) && (o.bias_mode != 2 || al16(o.bias));
-    }
-    p.O.wide = w ? 1 : 0;
-  }
+  decide_wide(p, splits, ws);
   double flops = 2.0 * p.M * (double)p.N * p.K;
   if (p.bwd_data) {
     flops = 0.0;
@@ -1214,6 +1344,57 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
       if (!p.O.row_sums) M2D_FAIL(M2D_ERR_ARG, "%s: row statistics without a destination", what);
       // partials per row: one per wave column of every N tile; the 16-byte epilogue writes one per 32-column tile
       const int wn = p.O.wide ? 4 : (bm >= 64 ? 2 : 4);
+      const int rc = m2d_rowsums_reduce(p.O.row_part, m2d_ceil_div(p.N, 128) * wn, p.M, p.O.row_sums,
+                                        m2d_rowstats_scratch(p.O.row_part, p.M, p.N), stream);
+      if (rc) return rc;
+    }
+  }
+  return M2D_OK;
+}
+
+template <int BM>
+static void k4_launch_tile(const M2dGemmParams& p, dim3 grid, hipStream_t stream) {
+  if (p.O.wide) hipLaunchKernelGGL((m2d_conv_k4_kernel<BM, 128, true>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((m2d_conv_k4_kernel<BM, 128, false>), grid, dim3(256), 0, stream, p);
+}
+
+int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_bytes, hipStream_t stream,
+                       const char* what) {
+  if (p.M <= 0 || p.N <= 0) return M2D_OK;
+  if (p.A.nbytes == 0 || p.B.nbytes == 0 || p.k4_ng <= 0)
+    M2D_FAIL(M2D_ERR_RANGE, "%s: operand larger than 2 GiB (buffer addressing), empty, or no tap groups", what);
+  if (p.M >= (1 << 24) || p.N >= (1 << 24)) M2D_FAIL(M2D_ERR_RANGE, "%s: extent >= 2^24", what);
+  const int nchunks = (p.nhi * p.k4_ng + 3) / 4;
+  if (p.O.row_part) allow_split = false;
+  PlanCand cand[M2D_MAX_CAND];
+  const int nc = plan_candidates(p.M, p.N, nchunks, 1, allow_split, 1.0, cand);
+  int bm = 128, splits = 1;
+  for (int i = 0; i < nc; ++i) {
+    const size_t need = cand[i].splits > 1 ? (size_t)cand[i].splits * (size_t)p.M * (size_t)p.N * sizeof(float) : 0;
+    if (need == 0 || (ws != nullptr && ws_bytes >= need)) {
+      bm = cand[i].bm < 64 ? 64 : cand[i].bm;
+      splits = cand[i].splits;
+      break;
+    }
+  }
+  p.splits = splits;
+  p.slab = splits > 1 ? (float*)ws : nullptr;
+  decide_wide(p, splits, ws);
+  const dim3 grid((unsigned)m2d_ceil_div(p.N, 128), (unsigned)m2d_ceil_div(p.M, bm), (unsigned)splits);
+  {
+    M2dProfScope prof(M2D_FAM_GEMM, stream, 2.0 * p.M * (double)p.N * p.K, 0.0, what, p.M, p.N, p.K);
+    if (bm == 64) k4_launch_tile<64>(p, grid, stream);
+    else k4_launch_tile<128>(p, grid, stream);
+    if (splits > 1) {
+      const size_t total = (size_t)p.M * p.N;
+      unsigned blocks = (unsigned)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(m2d_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    }
+    M2D_CHECK_LAUNCH(what);
+    if (p.O.row_part) {
+      if (!p.O.row_sums) M2D_FAIL(M2D_ERR_ARG, "%s: row statistics without a destination", what);
+      const int wn = p.O.wide ? 4 : 2;
       const int rc = m2d_rowsums_reduce(p.O.row_part, m2d_ceil_div(p.N, 128) * wn, p.M, p.O.row_sums,
                                         m2d_rowstats_scratch(p.O.row_part, p.M, p.N), stream);
       if (rc) return rc;

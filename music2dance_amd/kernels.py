@@ -139,6 +139,8 @@ class HipKernels:
             for w in tensors:
                 self._packed.pop(id(w), None)
                 self._packed.pop((id(w), "T"), None)
+                for key in [k for k in self._packed if isinstance(k, tuple) and k[0] == id(w)]:
+                    self._packed.pop(key, None)
 
     def packed_weights(self, w):
         """(w_fwd (Cin, ks, Cout), w_bwd (Cout, ks, Cin)): the K-major images of a conv weight the forward / backward-data
@@ -165,6 +167,42 @@ class HipKernels:
             packed[key] = (weakref.ref(w, _drop), w._version, stream, wf, wb)
         return wf, wb
 
+    _K4 = os.environ.get("M2D_K4", "1") != "0"  # A/B lever: 0 = stride-4 forwards through the generic engine
+    _K4_OK = {}
+
+    def _k4(self, Cin, L, Cout, ks, stride, pad):
+        if not self._K4 or stride != 4:
+            return False
+        key = (Cin, L, Cout, ks, stride, pad)
+        ok = self._K4_OK.get(key)
+        if ok is None:
+            ok = self._K4_OK[key] = bool(_lib.lib().m2d_conv1d_k4_applicable(Cin, L, Cout, ks, stride, pad))
+        return ok
+
+    def packed_k4(self, w, pad):
+        """Wk4[(ci, tap group)][Cout][4]: the image the tap-vectorised stride-4 forward reads (cached like the others)."""
+        stream = _stream(w.device)
+        key = (id(w), "k4", pad)
+        if self._cache_depth > 0:
+            ent = self._packed.get(key)
+            if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == stream:
+                return ent[3]
+        Cout, Cin, ks = w.shape
+        h = _lib.lib()
+        out = torch.empty((h.m2d_conv1d_k4_packed_elems(Cout, Cin, ks, pad),), dtype=torch.float32, device=w.device)
+        with _on(w.device):
+            rc = h.m2d_conv1d_pack_weights_k4(_ptr(w), _ptr(out), Cout, Cin, ks, pad, stream)
+        _lib.check(rc, "m2d_conv1d_pack_weights_k4")
+        self.pack_launches += 1
+        if self._cache_depth > 0:
+            packed = self._packed
+
+            def _drop(_ref, key=key):
+                packed.pop(key, None)
+
+            packed[key] = (weakref.ref(w, _drop), w._version, stream, out)
+        return out
+
     @staticmethod
     def _thin(Cin, ks, stride):
         return Cin == 1 and ks == 25 and stride == 4
@@ -185,11 +223,25 @@ class HipKernels:
         assert tuple(y.shape) == (B, Cout, Lout)
         h = _lib.lib()
         full_length = Lout == 1 and pad == 0 and L == ks
+        if sum_out is not None:
+            assert not with_stats and residual is not None and tuple(sum_out.shape) == tuple(y.shape)
+        if self._k4(Cin, L, Cout, ks, stride, pad):
+            # tap-vectorised stride-4 forward (audio critic l2..l5 and the penalty's tangent through them)
+            wk4 = self.packed_k4(w, pad)
+            ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 0, B, Cin, L, Cout, ks, stride, pad), dev)
+            sums = torch.empty((2 * Cout,), dtype=torch.float64, device=dev) if with_stats else None
+            with _on(dev):
+                rc = h.m2d_conv1d_fwd_k4(_ptr(x), _ptr(wk4), _ptr(bias), _ptr(y), _ptr(sum_out), B, Cin, L, Cout, ks,
+                                         stride, pad, act, slope, _ptr(residual), _ptr(out_mask), out_mask_slope,
+                                         _ptr(sums), _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream(dev))
+            _lib.check(rc, "m2d_conv1d_fwd_k4")
+            if sum_out is not None:
+                return y, sum_out
+            return (y, sums) if with_stats else y
         wp = self.packed_weights(w)[0] if (Cin >= 16 and not full_length) else None
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 0, B, Cin, L, Cout, ks, stride, pad), dev)
         nws = 0 if ws is None else ws.numel() * 4
         if sum_out is not None:
-            assert not with_stats and residual is not None and tuple(sum_out.shape) == tuple(y.shape)
             with _on(dev):
                 rc = h.m2d_conv1d_fwd_sum(_ptr(x), _ptr(w), _ptr(wp), _ptr(bias), _ptr(y), _ptr(sum_out), B, Cin, L,
                                           Cout, ks, stride, pad, act, slope, _ptr(residual), _ptr(out_mask),
