@@ -21,7 +21,10 @@ def conv_case(cin, L, cout, ks, s, p, which, b=B):
 a = torch.randn(4096, 4096, device=dev); b = torch.randn(4096, 4096, device=dev)
 for _ in range(3): K.gemm(0, a, b)
 torch.cuda.synchronize()
-conv_case(64, 4800, 128, 25, 4, 11, 0)     # audio l3 fwd
+conv_case(32, 19200, 64, 25, 4, 11, 0)     # audio l2 fwd (round 3: tap-vectorised kernel)
+conv_case(64, 4800, 128, 25, 4, 11, 0)     # audio l3 fwd (tap-vectorised)
+conv_case(128, 1200, 256, 25, 4, 11, 0)    # audio l4 fwd (generic LDS-direct kernel)
+conv_case(256, 300, 512, 25, 4, 11, 0)     # audio l5 fwd
 conv_case(32, 19200, 64, 25, 4, 11, 2)     # audio l2 bwd_weight
 conv_case(256, 300, 512, 25, 4, 11, 1)     # audio l5 bwd_data
 conv_case(512, 4, 1024, 4, 2, 1, 0, b=7680)  # encoder c5 fwd
