@@ -283,7 +283,8 @@ extern "C" {
 // (k25: 12 %), and the wide layers' gathers were already served from L1 by the generic engine.
 int m2d_conv1d_k4_applicable(int Cin, int L, int Cout, int ks, int stride, int pad) {
   const int Lout = conv_out_len(L, ks, stride, pad);
-  return stride == 4 && (L % 4) == 0 && (Cin % 4) == 0 && Cin >= 16 && Cin <= 64 && Cout >= 64 && Lout > 1 && ks >= 4 &&
+  static const int max_cin = [] { const char* e = getenv("M2D_K4_MAXCIN"); return e ? atoi(e) : 64; }();  // A/B lever
+  return stride == 4 && (L % 4) == 0 && (Cin % 4) == 0 && Cin >= 16 && Cin <= max_cin && Cout >= 64 && Lout > 1 && ks >= 4 &&
          k4_groups(ks, pad) >= 2;
 }
 

@@ -393,7 +393,9 @@ size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout) {
 // epilogue reads the mask and writes the result as dwordx4 runs of 128*NT bytes per channel row
 // (measured at B = 64: 79 us plain / 107 us masked, against 71 / 161 us for dword accesses
 // straight from the accumulator layout, and ~117 us for the vector-ALU kernel).
-template <int KS, int S, int NT>
+// REP: consecutive position groups per wave (round-3 experiment: letting the stores of group i drain under the
+// gathers and MFMAs of group i + 1 did not pay - see THIN_FWD_REP).
+template <int KS, int S, int NT, int REP>
 __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
   constexpr int NS = (KS + 1) / 2;
   constexpr int NP = 32 * NT;    // positions per wave
@@ -412,8 +414,9 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
     const int k = 2 * ks + h;
     wa[ks] = k < KS ? a.w[c31 * KS + k] : 0.f;
   }
-  const int p0 = (blockIdx.x * 4 + wave) * NP;  // first position of this wave
-  if (p0 >= a.Lout) return;
+  for (int rep = 0; rep < REP; ++rep) {
+  const int p0 = ((blockIdx.x * 4 + wave) * REP + rep) * NP;  // first position of this wave's group
+  if (p0 >= a.Lout) break;
   float xb[2][NS];
   auto fetch = [&](int t, float (&dst)[NS]) {
     const int l = p0 + t * 32 + c31;
@@ -498,11 +501,13 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
         s2 += __shfl_xor(s2, off, 64);
       }
       if (cq == 0) {
-        float* dst = a.stats + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 64 + 2 * co;
+        float* dst = a.stats + ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * REP + rep) * 64 + 2 * co;
         dst[0] = s1;
         dst[1] = s2;
       }
     }
+  }
+  __builtin_amdgcn_wave_barrier();  // the image is read before the next group overwrites it (one wave, in order)
   }
 }
 
@@ -513,7 +518,10 @@ struct M2dWinView {
 int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, double* scratch, hipStream_t stream);  // gemm_engine.hip
 
 // per-wave partials + the scratch of the two-stage row sum (256 groups x 32 rows x fp64 pair)
-static size_t thin_fwd_stats_part(int B, int Lout) { return (size_t)B * m2d_ceil_div(Lout, 256) * 4 * 64 * sizeof(float); }
+// measured (B = 64): REP = 4 -> 80 us plain / 122 us masked against 78 / 106 us for one group per wave: kept at 1
+#define THIN_FWD_REP 1
+static int thin_fwd_gridx(int Lout) { return m2d_ceil_div(Lout, 256 * THIN_FWD_REP); }
+static size_t thin_fwd_stats_part(int B, int Lout) { return (size_t)B * thin_fwd_gridx(Lout) * 4 * THIN_FWD_REP * 64 * sizeof(float); }
 size_t m2d_thin_fwd_stats_ws(int B, int Lout) { return thin_fwd_stats_part(B, Lout) + (size_t)256 * 32 * 2 * sizeof(double); }
 
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
@@ -534,10 +542,10 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
-  hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2>), dim3(m2d_ceil_div(Lout, 256), B), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2, THIN_FWD_REP>), dim3(thin_fwd_gridx(Lout), B), dim3(256), 0, stream, a);
   M2D_CHECK_LAUNCH("thin_fwd_mfma_kernel");
   if (stats)
-    return m2d_rowsums_reduce(a.stats, B * m2d_ceil_div(Lout, 256) * 4, 32, stats,
+    return m2d_rowsums_reduce(a.stats, B * thin_fwd_gridx(Lout) * 4 * THIN_FWD_REP, 32, stats,
                               (double*)((char*)a.stats + thin_fwd_stats_part(B, Lout)), stream);
   return M2D_OK;
 }

@@ -758,6 +758,18 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 }
 
+// LDS byte address of a pointer into a __shared__ array, and a 16-byte LDS read the compiler does not see as a memory
+// access (see m2d_conv_k4_kernel)
+typedef float m2d_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned m2d_lds_addr(const float* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+}
+__device__ __forceinline__ m2d_f32x4 m2d_ds_read_b128(unsigned addr) {
+  m2d_f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
 // ---- tap-vectorised stride-4 forward conv ----------------------------------------------------------------------------
 // y[n, co, l] = sum_{ci, t} W[co, ci, t] x[n, ci, 4 l + t - pad]  (the audio critic's k25 / s4 layers,
 // phase3/archis/default.py:298-303, and the forward-mode tangent of the penalty through them).
@@ -782,7 +794,9 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
   constexpr int HA = BM / 64, HB = BN / 64;   // 64-row DMA pieces per tap group
   constexpr int STAGE = 16 * (BM + BN);       // floats: 4 groups x (BM + BN) rows x 4 taps
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index as a SCALAR: the tap-group cursor below is wave-uniform state; derived from a vector register it
+  // would live in VGPRs and every LDS-DMA would be wrapped in a waterfall loop to make its scalar offset uniform)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
   const int l31 = lane & 31, lh = lane >> 5;
   const M2dOperand& A = p.A;
@@ -855,27 +869,41 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
     for (int c = c0; c < c1; ++c) {
       const int cur = (c - c0) & 1;
       stage(smem + (cur ^ 1) * STAGE);  // chunk c + 1 (past the end: zeros or the next split's data, harmless)
-      const float* as = smem + cur * STAGE + (wm * (TM * 32) + l31) * 4;
-      const float* bs = smem + cur * STAGE + 16 * BM + (wn * (TN * 32) + l31) * 4;
-      float4 fa[2][TM], fb[2][TN];
+      // Fragment reads through inline asm: hipcc otherwise puts an `s_waitcnt vmcnt(0)` in front of the first ds_read of
+      // the chunk (it cannot tell that the LDS-DMA just issued fills the OTHER stage), which serialises staging and
+      // multiplying. The ordering the hardware needs is explicit here: this stage was filled, waited for (vmcnt(0)) and
+      // fenced by the barrier at the end of the previous iteration; its reads are waited for below before the MFMAs.
+      const unsigned as = m2d_lds_addr(smem + cur * STAGE + (wm * (TM * 32) + l31) * 4);
+      const unsigned bs = m2d_lds_addr(smem + cur * STAGE + 16 * BM + (wn * (TN * 32) + l31) * 4);
+      // 64-row tiles read both 8-deep halves of the chunk up front (24 registers); 128-row tiles one half at a time:
+      // 32 fragment registers beside 64 accumulators would not fit the 96 registers of five waves per SIMD
+      constexpr bool UPFRONT = BM == 64;
+      m2d_f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        if (UPFRONT ? s2 == 0 : true) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[s2][i] = *reinterpret_cast<const float4*>(as + ((2 * s2 + lh) * BM + i * 32) * 4);
+          for (int h2 = (UPFRONT ? 0 : s2); h2 < (UPFRONT ? 2 : s2 + 1); ++h2) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[s2][j] = *reinterpret_cast<const float4*>(bs + ((2 * s2 + lh) * BN + j * 32) * 4);
-      }
+            for (int i = 0; i < TM; ++i) fa[UPFRONT ? h2 : 0][i] = m2d_ds_read_b128(as + (((2 * h2 + lh) * BM + i * 32) << 4));
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
+            for (int j = 0; j < TN; ++j) fb[UPFRONT ? h2 : 0][j] = m2d_ds_read_b128(bs + (((2 * h2 + lh) * BN + j * 32) << 4));
+          }
+        }
+        // reads return in order: the first half's TM + TN are in when at most the second half's are outstanding
+        if (UPFRONT && s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2][i].x, fb[s2][j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2][i].y, fb[s2][j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2][i].z, fb[s2][j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2][i].w, fb[s2][j].w, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][0], fb[UPFRONT ? s2 : 0][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][1], fb[UPFRONT ? s2 : 0][j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][2], fb[UPFRONT ? s2 : 0][j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][3], fb[UPFRONT ? s2 : 0][j][3], acc[i][j], 0, 0, 0);
           }
+        if (!UPFRONT) __builtin_amdgcn_sched_barrier(0);  // the second half's reads reuse the fragment registers
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
