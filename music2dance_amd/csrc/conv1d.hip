@@ -125,6 +125,33 @@ __global__ void __launch_bounds__(256) m2d_pack_weights_kernel(const float* __re
   }
 }
 
+// Sub-pixel image of a strided backward-data conv: wsp[(t * Cout + co) * (Cin * s) + ci * s + r] = w[co][ci][r + s * t]
+// (zero for taps >= ks): K-major, rows (ci, phase r) contiguous
+__global__ void __launch_bounds__(256) m2d_pack_weights_subpixel_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                                          int Cout, int Cin, int ks, int s, int nt) {
+  const size_t total = (size_t)nt * Cout * Cin * s;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int m = (int)(idx % (size_t)(Cin * s));
+    const size_t k = idx / (size_t)(Cin * s);
+    const int ci = m / s, r = m - ci * s;
+    const int co = (int)(k % Cout), t = (int)(k / Cout);
+    const int tap = r + s * t;
+    out[idx] = tap < ks ? w[((size_t)co * Cin + ci) * ks + tap] : 0.f;
+  }
+}
+
+// Strided backward-data in its sub-pixel form when the layer has few input channels: rows (ci, phase), one GEMM for all
+// phases (M = Cin * s instead of s GEMMs with M = Cin). Measured need: the 32-channel audio layer ran 32-row tiles at
+// 67 TFLOP/s, the worst large launch of the step. Cost: ceil(ks / s) * s tap slots instead of ks (k25 / s4: 28, + 12 %).
+static inline bool bwd_subpixel(int Cin, int Cout, int ks, int stride) {
+  static const bool on = [] { const char* e = getenv("M2D_SUBPIXEL"); return !(e && e[0] == '0'); }();
+  static const int max_rows = [] { const char* e = getenv("M2D_SUBPIXEL_MAXROWS"); return e ? atoi(e) : 128; }();  // A/B lever
+  return on && stride > 1 && Cin * stride <= max_rows && Cin * stride >= 64 && Cout >= 16 && ks > stride;
+}
+static inline size_t subpixel_bytes(int Cout, int Cin, int ks, int stride) {
+  return ((((size_t)((ks + stride - 1) / stride) * Cout * Cin * stride) * sizeof(float)) + 255) & ~(size_t)255;
+}
+
 static int pack_weights(const float* w, float* wf, float* wb, int Cout, int Cin, int ks, hipStream_t stream) {
   const size_t total = (size_t)Cout * Cin * ks;
   unsigned blocks = (unsigned)((total + 255) / 256);
@@ -425,6 +452,85 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     p.O.mask_last = 1;
     return m2d_gemm_launch(p, true, false, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }
+  if (bwd_subpixel(Cin, Cout, ks, stride)) {
+    // dx[n, ci, s q + r - pad] = sum_{t, co} w[co, ci, r + s t] dy[n, co, q - t]: rows (ci, r), K = (t, co), columns (n, q)
+    const int s = stride, nt = (ks + s - 1) / s;
+    const size_t pb = subpixel_bytes(Cout, Cin, ks, s);
+    if (!ws || ws_bytes < pb) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_bwd_data: workspace too small for the sub-pixel weights");
+    {
+      const size_t total = (size_t)nt * Cout * Cin * s;
+      unsigned blocks = (unsigned)((total + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(m2d_pack_weights_subpixel_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)ws,
+                         Cout, Cin, ks, s, nt);
+    }
+    const float* wsp = (const float*)ws;
+    ws = (char*)ws + pb;
+    ws_bytes -= pb;
+    // q range over all phases: s q + r - pad in [0, L) for some r
+    const int qmin = pad / s;                              // r = s - 1 reaches furthest left: ceil((pad - s + 1) / s)
+    const int qlo = (pad - (s - 1) + s - 1) / s > 0 ? (pad - (s - 1) + s - 1) / s : 0;
+    const int qhi = (L - 1 + pad) / s;                     // r = 0 reaches furthest right
+    (void)qmin;
+    const int nq = qhi - qlo + 1;
+    p.M = Cin * s;
+    p.N = B * nq;
+    p.K = Cout * nt;
+    p.nhi = nt;
+    p.kdiv = Cout;
+    p.lo_outer = 1;
+    p.phases = 1;
+    m2d_operand_plain(p.A, wsp, p.M, 1, p.M, (long long)nt * Cout * p.M);   // A(m, k = (t, co)) = wsp[(t * Cout + co) * M + m]
+    p.A.k_hi_stride = Cout * p.M;
+    M2dOperand& b = p.B;
+    b.base = dy;
+    b.nbytes = m2d_extent_bytes((long long)B * Cout * Lout);
+    b.mask = dy_mask;
+    b.mask_slope = dy_mask_slope;
+    b.nrows = p.N;
+    b.rdiv = nq;
+    b.rdiv_inv = 1.f / (float)nq;
+    b.r_hi_stride = Cout * Lout;
+    b.r_lo_stride = 1;
+    b.r_off = qlo;
+    b.r_pos_mul = 1;
+    b.r_pos_off = qlo;
+    b.k_hi_stride = -1;
+    b.k_lo_stride = Lout;
+    b.k_pos_hi = -1;
+    b.k_pos_lo = 0;
+    b.k_safe_lo = 0;
+    b.k_safe_hi = 0x7fffffff;
+    b.lim = Lout;
+    // out(m = (ci, r), col = (n, q)) = dx[n * Cin * L + ci * L + s * q + r - pad], written iff s q + r - pad in [0, L)
+    m2d_outmap_plain(p.O, dx, L, 1);
+    p.O.m_div = s;
+    p.O.m_lo_stride = 1;
+    p.O.m_pos_mul = 1;
+    p.O.cdiv = nq;
+    p.O.cdiv_inv = b.rdiv_inv;
+    p.O.c_hi_stride = Cin * L;
+    p.O.c_lo_stride = s;
+    p.O.c_off = s * qlo - pad;
+    p.O.c_pos_mul = s;
+    p.O.c_pos_off = s * qlo - pad;
+    p.O.c_lim = L;
+    p.O.mask = out_mask;
+    p.O.mask_slope = out_mask_slope;
+    p.O.residual = residual;
+    p.O.mask_last = 1;
+    p.O.quad = s == 4 ? 1 : 0;  // M = 4 Cin
+    // reported work: the real taps (as the polyphase form counts them), not the padded K
+    for (int r = 0; r < s; ++r) {
+      const int taps = r < ks ? (ks - r + s - 1) / s : 0;
+      const int q0 = r >= pad ? 0 : (pad - r + s - 1) / s;
+      const int top = L - 1 + pad - r;
+      const int nqr = top >= 0 ? (top / s - q0 + 1) : 0;
+      if (nqr > 0) p.work_flops += 2.0 * Cin * (double)B * nqr * Cout * taps;
+    }
+    return m2d_gemm_launch(p, /*a_kfast=*/false, /*b_kfast=*/false, /*allow_split=*/false, ws, ws_bytes,
+                           (hipStream_t)stream, "m2d_conv1d_bwd_data");
+  }
   if (!w_packed) {
     const size_t pb = pack_bytes(Cout, Cin, ks);
     if (!ws || ws_bytes < pb)
@@ -681,6 +787,7 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
   if (which == 1) {
     if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(B, Cin * ks, m2d_chunks(1, Cout), 1, true).ws_bytes;
     if (stride == 1) return m2d_gemm_plan(Cin, B * L, m2d_chunks(ks, Cout), 1, true).ws_bytes + pack_bytes(Cout, Cin, ks);
+    if (bwd_subpixel(Cin, Cout, ks, stride)) return subpixel_bytes(Cout, Cin, ks, stride) + pack_bytes(Cout, Cin, ks);
     return pack_bytes(Cout, Cin, ks);
   }
   // sized for the launch with the bias column (one more column), which is never smaller

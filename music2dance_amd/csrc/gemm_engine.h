@@ -86,11 +86,20 @@ struct M2dOutMap {
   // set by the launcher when the tile can leave as 16-byte rows (m2d_tile_epilogue_wide): unit column stride, every
   // pitch / offset / column count a multiple of 4, 16-byte aligned pointers, no window / redirect column
   int wide;
+  // set by the caller (sub-pixel backward-data at stride 4): rows 4 c .. 4 c + 3 of one column are four consecutive
+  // addresses, which is exactly what one lane holds in four accumulator registers - the tile leaves as (4-byte
+  // aligned) 16-byte stores (m2d_tile_epilogue_quad). Requires m_div == 4, m_lo_stride == 1, m_pos_mul == 1, a window
+  // (c_lim > 0), M a multiple of 4, no split-K / statistics / redirect / second output / per-column bias.
+  int quad;
   float mask_slope;
   float slope;            // LeakyReLU slope for act == 2
   int bias_mode;
   int act;                // 0 none, 1 ReLU, 2 LeakyReLU
   int m_stride;
+  // optional two-level row map (m_div > 0): row -> (mhi, mlo) = divmod(row, m_div), row offset = mhi * m_stride +
+  // mlo * m_lo_stride, and the column window test uses pos(col) + mlo * m_pos_mul. The sub-pixel form of a strided
+  // backward-data conv writes row (ci, phase r) to ci * L + r and tests 4 q + r - pad against [0, L).
+  int m_div, m_lo_stride, m_pos_mul;
   int cdiv;
   float cdiv_inv;
   int c_hi_stride, c_lo_stride, c_off;
@@ -141,6 +150,9 @@ struct M2dGemmParams {
   // tap-vectorised stride-4 forward conv (m2d_conv_k4_kernel): K is walked in groups of 4 consecutive taps of one
   // channel, k4_ng groups per channel; B.k_hi_stride = the channel pitch (L)
   int k4_ng;
+  // > 0: the algorithmic FLOPs of the launch when the walked K holds structural zeros (phantom taps): what the
+  // profiler reports instead of 2 M N K
+  double work_flops;
 };
 
 struct M2dGemmPlan {

@@ -327,7 +327,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (32 * WM);
   constexpr int TN = BN / (32 * WN);
-  int caddr[TN], colj[TN];
+  int caddr[TN], colj[TN], posj[TN];
   bool cvj[TN], cokj[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -337,7 +337,8 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
     m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
     caddr[j] = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
     bool cok = cv;
-    if (O.c_lim > 0) cok = cok && ((unsigned)(clo * O.c_pos_mul + O.c_pos_off) < (unsigned)O.c_lim);
+    posj[j] = clo * O.c_pos_mul + O.c_pos_off;
+    if (O.c_lim > 0 && O.m_div <= 0) cok = cok && ((unsigned)posj[j] < (unsigned)O.c_lim);
     colj[j] = col;
     cvj[j] = cv;
     cokj[j] = cok;
@@ -357,8 +358,9 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
             if (cvj[j]) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + colj[j]] = acc[i][j][r];
           } else if (colj[j] + 1 == O.redirect_col_p1) {
             O.col_out[row] = acc[i][j][r];
-          } else if (cokj[j]) {
-            const int addr = row * O.m_stride + caddr[j];
+          } else if (cokj[j] && (O.m_div <= 0 || (unsigned)(posj[j] + (row % O.m_div) * O.m_pos_mul) < (unsigned)O.c_lim)) {
+            const int addr = (O.m_div > 0 ? (row / O.m_div) * O.m_stride + (row % O.m_div) * O.m_lo_stride
+                                          : row * O.m_stride) + caddr[j];
             const float v = m2d_epilogue(O, acc[i][j][r], row, colj[j], addr);
             O.out[addr] = v;
             s1 += v;
@@ -653,7 +655,94 @@ __device__ __forceinline__ void m2d_chunk_mma_dl(const float* stage, int wm, int
   }
 }
 
-template <int BM, int BN, bool WIDE>
+// Quad tile epilogue (O.quad): the four accumulator registers 4 g .. 4 g + 3 of a lane are rows 4 c .. 4 c + 3 of one
+// column, i.e. four consecutive elements of the sub-pixel output - one 16-byte store per register group instead of
+// four dword stores a stride of 16 bytes apart. Addresses are 4-byte aligned only (the row offset is s q - pad).
+typedef float m2d_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int BM, int BN>
+__device__ __forceinline__ void m2d_tile_epilogue_quad(const M2dGemmParams& p, const M2dOutMap& O, int N, int m0, int n0,
+                                                       int wm, int wn, int l31, int lh,
+                                                       f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+    if (col >= N) continue;
+    int chi, clo;
+    m2d_divmod(col, O.cdiv, O.cdiv_inv, chi, clo);
+    const int caddr = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
+    const int pos = clo * O.c_pos_mul + O.c_pos_off;
+    const bool whole = pos >= 0 && pos + 3 < O.c_lim;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
+        if (row >= p.M) continue;
+        const int addr = (row >> 2) * O.m_stride + caddr;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[i][j][4 * g + e];
+          if (O.bias_mode == 1) x += O.bias[row + e];
+          if (O.act == 1) x = x > 0.f ? x : 0.f;
+          else if (O.act == 2) x = x > 0.f ? x : x * O.slope;
+          v[e] = x;
+        }
+        if (whole) {
+          if (O.mask_last) {
+            if (O.residual) {
+              const m2d_f32x4u rr = *reinterpret_cast<const m2d_f32x4u*>(O.residual + addr);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            }
+            if (O.mask) {
+              const m2d_f32x4u mm = *reinterpret_cast<const m2d_f32x4u*>(O.mask + addr);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= (mm[e] > 0.f ? 1.f : O.mask_slope);
+            }
+          } else {
+            if (O.mask) {
+              const m2d_f32x4u mm = *reinterpret_cast<const m2d_f32x4u*>(O.mask + addr);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= (mm[e] > 0.f ? 1.f : O.mask_slope);
+            }
+            if (O.residual) {
+              const m2d_f32x4u rr = *reinterpret_cast<const m2d_f32x4u*>(O.residual + addr);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            }
+          }
+          m2d_f32x4u o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = v[e];
+          *reinterpret_cast<m2d_f32x4u*>(O.out + addr) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if ((unsigned)(pos + e) >= (unsigned)O.c_lim) continue;
+            float x = v[e];
+            if (O.mask_last) {
+              if (O.residual) x += O.residual[addr + e];
+              if (O.mask) x *= (O.mask[addr + e] > 0.f ? 1.f : O.mask_slope);
+            } else {
+              if (O.mask) x *= (O.mask[addr + e] > 0.f ? 1.f : O.mask_slope);
+              if (O.residual) x += O.residual[addr + e];
+            }
+            O.out[addr + e] = x;
+          }
+        }
+      }
+    }
+  }
+}
+
+// EPI: 0 dword epilogue, 1 wide (16-byte rows through LDS), 2 quad (sub-pixel rows)
+template <int BM, int BN, int EPI>
 __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams p) {
   constexpr int WM = BM >= 64 ? 2 : 1;
   constexpr int WN = 4 / WM;
@@ -754,7 +843,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   }
   // (two instantiations, not a branch: with both epilogues in one kernel every accumulator stays live across the
   // choice and the kernel needs 30 more registers, i.e. one resident wave per SIMD fewer)
-  if constexpr (WIDE) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+  if constexpr (EPI == 1) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+  else if constexpr (EPI == 2) m2d_tile_epilogue_quad<BM, BN>(p, O, N, m0, n0, wm, wn, l31, lh, acc);
   else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 }
 
@@ -940,9 +1030,11 @@ __global__ void __launch_bounds__(256) m2d_splitk_reduce_kernel(const M2dGemmPar
     int chi, clo;
     m2d_divmod(col, p.O.cdiv, p.O.cdiv_inv, chi, clo);
     bool ok = true;
-    if (p.O.c_lim > 0) ok = (unsigned)(clo * p.O.c_pos_mul + p.O.c_pos_off) < (unsigned)p.O.c_lim;
+    const int mlo = p.O.m_div > 0 ? row % p.O.m_div : 0;
+    if (p.O.c_lim > 0) ok = (unsigned)(clo * p.O.c_pos_mul + p.O.c_pos_off + mlo * p.O.m_pos_mul) < (unsigned)p.O.c_lim;
     if (ok) {
-      const int addr = row * p.O.m_stride + chi * p.O.c_hi_stride + clo * p.O.c_lo_stride + p.O.c_off;
+      const int raddr = p.O.m_div > 0 ? (row / p.O.m_div) * p.O.m_stride + mlo * p.O.m_lo_stride : row * p.O.m_stride;
+      const int addr = raddr + chi * p.O.c_hi_stride + clo * p.O.c_lo_stride + p.O.c_off;
       p.O.out[addr] = m2d_epilogue(p.O, s, row, col, addr);
     }
   }
@@ -1193,8 +1285,9 @@ static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hi
   {
     if (!akf && !bkf && dl_enabled() && !p.A.mask && !p.B.mask && !p.A.ones_row_p1 && !p.B.ones_row_p1 &&
         p.A.rdiv2 <= 0 && p.B.rdiv2 <= 0 && p.A.kdiv2 <= 0 && p.B.kdiv2 <= 0) {
-      if (p.O.wide) hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, true>), grid, dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, false>), grid, dim3(256), 0, stream, p);
+      if (p.O.wide) hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 1>), grid, dim3(256), 0, stream, p);
+      else if (p.O.quad && p.splits <= 1) hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 2>), grid, dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 0>), grid, dim3(256), 0, stream, p);
       return 0;
     }
   }
@@ -1251,7 +1344,7 @@ static void decide_wide(M2dGemmParams& p, int splits, const void* ws) {
   if (splits > 1) {
     w = w && al16(ws);
   } else {
-    w = w && o.c_lo_stride == 1 && o.c_lim <= 0 && (o.cdiv % 4) == 0 && (o.c_hi_stride % 4) == 0 &&
+    w = w && o.m_div <= 0 && o.c_lo_stride == 1 && o.c_lim <= 0 && (o.cdiv % 4) == 0 && (o.c_hi_stride % 4) == 0 &&
         (o.m_stride % 4) == 0 && (o.c_off % 4) == 0 && al16(o.out) && al16(o.mask) && al16(o.residual) &&
         al16(o.sum_out) && (o.bias_mode != 2 || al16(o.bias));
   }
@@ -1352,7 +1445,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
     }
   }
   decide_wide(p, splits, ws);
-  double flops = 2.0 * p.M * (double)p.N * p.K;
+  double flops = p.work_flops > 0.0 ? p.work_flops : 2.0 * p.M * (double)p.N * p.K;
   if (p.bwd_data) {
     flops = 0.0;
     for (int r = 0; r < p.phases; ++r) {
