@@ -263,7 +263,7 @@ class FakeKernels:
             outs.append(o), saved.append(s)
         return outs, (saved if save else None)
 
-    def gru_stack_bwd(self, dout, outs, saved, w_hh, w_ih, lengths=None):
+    def gru_stack_bwd(self, dout, outs, saved, w_hh, w_ih, lengths=None, persistent=True):
         L = len(outs)
         dgi, dgh = [None] * L, [None] * L
         d = dout
