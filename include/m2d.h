@@ -159,32 +159,37 @@ size_t m2d_gemm_workspace_bytes(int mode, int M, int N, int K);
 /* ---- BatchNorm1d (train/eval forward, train backward) + per-channel sums -----------------
  * reference: phase3/archis/default.py:65,68,91,94,118-127,154,179-180,217. */
 size_t m2d_bn_workspace_bytes(int C);
+/* `scratch` (optional, every reducing call below): m2d_bn_scratch_bytes(C) bytes the caller zeroed ONCE and owns per
+ * stream. A call that gets it accumulates there, lets the block that arrives last finish the op (mean / invstd /
+ * running buffers; dgamma / dbeta; the float sums) and leaves the scratch zeroed again: one launch instead of memset +
+ * reduce + finalize. Two streams must not share a scratch. NULL: the three-launch form, no state between calls. */
+size_t m2d_bn_scratch_bytes(int C);
 int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                float* running_var, float* y, float* save_mean, float* save_invstd, int B, int C, int L,
                float eps, float momentum, int training, int act, float slope, const float* residual, void* ws,
-               size_t ws_bytes, void* stream);
+               size_t ws_bytes, void* scratch, void* stream);
 int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                const float* save_invstd, float* dx, float* dgamma, float* dbeta, int B, int C, int L, int act,
-               float slope, void* ws, size_t ws_bytes, void* stream);
+               float slope, void* ws, size_t ws_bytes, void* scratch, void* stream);
 /* The same in two halves, statistics as raw fp64 sums (sums[2c] = sum x, sums[2c+1] = sum x^2 over `count`
  * elements per channel; backward: sum dz, sum dz*xhat). Lets a producing conv supply the forward sums
  * (m2d_conv1d_fwd `stats`) and lets data-parallel ranks all-reduce them between the halves
  * (synchronised BatchNorm: global-batch statistics; `count` is then the global element count,
  * `sums_global` the all-reduced buffer, `sums_local` this rank's own for dgamma / dbeta). */
-int m2d_bn_stats(const float* x, double* sums, int B, int C, int L, void* stream);
+int m2d_bn_stats(const float* x, double* sums, int B, int C, int L, void* scratch, void* stream);
 int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
                     int C, int L, float eps, float momentum, int act, float slope, const float* residual,
                     void* stream);
 int m2d_bn_bwd_stats(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                      const float* save_invstd, double* sums, int B, int C, int L, int act, float slope,
-                     void* stream);
+                     void* scratch, void* stream);
 int m2d_bn_bwd_sums(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                     const float* save_invstd, const double* sums_local, const double* sums_global, double count,
                     float* dx, float* dgamma, float* dbeta, int B, int C, int L, int act, float slope, void* ws,
                     size_t ws_bytes, void* stream);
 int m2d_channel_sums(const float* x, const float* mask, float slope, float* out, int B, int C, int L, void* ws,
-                     size_t ws_bytes, void* stream);
+                     size_t ws_bytes, void* scratch, void* stream);
 
 /* ---- GRU recurrence (one layer, all T steps) ---------------------------------------------
  * reference: nn.GRU inside NoiseGen, phase3/archis/default.py:349-355,

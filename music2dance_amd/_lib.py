@@ -48,13 +48,14 @@ SIGNATURES = {
     "m2d_gemm": (_I, [_I, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _f, _F, _f, _F, _S, _F]),
     "m2d_gemm_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "m2d_bn_workspace_bytes": (_S, [_I]),
-    "m2d_bn_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _I, _f, _F, _F, _S, _F]),
-    "m2d_bn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F]),
-    "m2d_bn_stats": (_I, [_F, _F, _I, _I, _I, _F]),
+    "m2d_bn_scratch_bytes": (_S, [_I]),
+    "m2d_bn_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _I, _f, _F, _F, _S, _F, _F]),
+    "m2d_bn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F, _F]),
+    "m2d_bn_stats": (_I, [_F, _F, _I, _I, _I, _F, _F]),
     "m2d_bn_fwd_sums": (_I, [_F, _F, _c.c_double, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _f, _F, _F]),
-    "m2d_bn_bwd_stats": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F]),
+    "m2d_bn_bwd_stats": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _F]),
     "m2d_bn_bwd_sums": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _c.c_double, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F]),
-    "m2d_channel_sums": (_I, [_F, _F, _f, _F, _I, _I, _I, _F, _S, _F]),
+    "m2d_channel_sums": (_I, [_F, _F, _f, _F, _I, _I, _I, _F, _S, _F, _F]),
     "m2d_gru_layer_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
     "m2d_gru_layer_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _F]),
     "m2d_gru_stack_counters": (_I, [_I, _I]),

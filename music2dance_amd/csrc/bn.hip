@@ -41,7 +41,46 @@ struct BnReduceArgs {
   int rows_per_block;
   int mode, act;
   float slope;
+  // Self-cleaning accumulation (callers that pass a zero-kept scratch, m2d_bn_scratch_bytes): `acc` is that scratch,
+  // `ticket` its arrival counter; the block that arrives last reads the totals, finishes the op (fin) and leaves
+  // scratch and ticket zeroed for the next launch on the stream - no memset and no finalize launch.
+  unsigned* ticket;
+  int fin;             // 1: totals -> sums_out; 2: forward statistics; 3: backward means + parameter gradients;
+                       // 4: float channel sums -> f_out
+  double* sums_out;    // fin 1
+  float* f0;           // fin 2: save_mean    fin 3: dgamma   fin 4: out
+  float* f1;           // fin 2: save_invstd  fin 3: dbeta
+  float* f2;           // fin 2: running_mean fin 3: s_dz
+  float* f3;           // fin 2: running_var  fin 3: s_dzx
+  double count;
+  float eps, momentum;
 };
+
+// (the launches on ONE stream share a scratch; two streams need two)
+__device__ __forceinline__ void bn_finish(const BnReduceArgs& a, int c, double s0, double s1) {
+  if (a.fin == 1) {
+    a.sums_out[2 * c] = s0;
+    a.sums_out[2 * c + 1] = s1;
+  } else if (a.fin == 2) {
+    const double mu = s0 / a.count;
+    double var = s1 / a.count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    a.f0[c] = (float)mu;
+    a.f1[c] = (float)(1.0 / sqrt(var + (double)a.eps));
+    if (a.f2) {
+      const double unbiased = a.count > 1.0 ? var * (a.count / (a.count - 1.0)) : var;
+      a.f2[c] = (float)((1.0 - a.momentum) * (double)a.f2[c] + a.momentum * mu);
+      a.f3[c] = (float)((1.0 - a.momentum) * (double)a.f3[c] + a.momentum * unbiased);
+    }
+  } else if (a.fin == 3) {
+    a.f1[c] = (float)s0;
+    a.f0[c] = (float)s1;
+    a.f2[c] = (float)(s0 / a.count);
+    a.f3[c] = (float)(s1 / a.count);
+  } else if (a.fin == 4) {
+    a.f0[c] = (float)s0;
+  }
+}
 
 // one element's contribution to the two running sums
 __device__ __forceinline__ void bn_accum(const BnReduceArgs& a, float xv, float dyv, float mv, float g, float bt,
@@ -162,6 +201,26 @@ __global__ void __launch_bounds__(256) m2d_bn_reduce_kernel(const BnReduceArgs a
       if (a.mode != 2) atomicAdd(&a.acc[2 * c0 + 1], sh1[0]);
     }
   }
+  if (!a.ticket) return;
+  // last block to arrive finishes the op and re-zeroes the scratch
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (t == 0) {
+    const unsigned n = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (n + 1u == gridDim.x * gridDim.y) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int c = t; c < a.C; c += 256) {
+    const double s0 = __hip_atomic_load(&a.acc[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double s1 = a.mode != 2 ? __hip_atomic_load(&a.acc[2 * c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    a.acc[2 * c] = 0.0;
+    a.acc[2 * c + 1] = 0.0;
+    bn_finish(a, c, s0, s1);
+  }
+  if (t == 0) *a.ticket = 0u;
 }
 
 static int launch_reduce(BnReduceArgs& a, hipStream_t stream) {
@@ -179,7 +238,7 @@ static int launch_reduce(BnReduceArgs& a, hipStream_t stream) {
   if (nsplit < 1) nsplit = 1;
   a.rows_per_block = m2d_ceil_div(a.B, nsplit);
   nsplit = m2d_ceil_div(a.B, a.rows_per_block);
-  if (hipMemsetAsync(a.acc, 0, sizeof(double) * 2 * a.C, stream) != hipSuccess)
+  if (!a.ticket && hipMemsetAsync(a.acc, 0, sizeof(double) * 2 * a.C, stream) != hipSuccess)
     M2D_FAIL(M2D_ERR_HIP, "bn reduce: memset failed");
   hipLaunchKernelGGL(m2d_bn_reduce_kernel, dim3(groups, nsplit), dim3(256), 0, stream, a);
   M2D_CHECK_LAUNCH("m2d_bn_reduce_kernel");
@@ -316,11 +375,24 @@ extern "C" {
 // bytes of scratch every bn / channel-sum call needs (fp64 accumulators + 2 float rows)
 size_t m2d_bn_workspace_bytes(int C) { return (size_t)C * (2 * sizeof(double) + 2 * sizeof(float)) + 64; }
 
+// bytes of the optional zero-kept scratch (`scratch` arguments below): fp64 accumulators + the arrival counter. The
+// caller zeroes it ONCE; every call that takes it leaves it zeroed. One scratch per stream (launches of one stream
+// reuse it in order); with scratch == NULL the calls memset their accumulators and finalise in a second launch.
+size_t m2d_bn_scratch_bytes(int C) { return (size_t)C * 2 * sizeof(double) + 64; }
+static inline void bn_use_scratch(BnReduceArgs& r, void* scratch, int C) {
+  r.acc = (double*)scratch;
+  r.ticket = (unsigned*)((double*)scratch + 2 * (size_t)C);
+}
+
 static int bn_check(const char* who, int B, int C, int L) {
   if (B <= 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "%s: bad shape", who);
   if ((long long)C * L >= 16777216LL) M2D_FAIL(M2D_ERR_RANGE, "%s: C*L too large", who);
   return M2D_OK;
 }
+
+static int bn_apply_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                        const float* save_invstd, const float* s_dz, const float* s_dzx, float* dx, int B, int C, int L,
+                        int act, float slope, hipStream_t stream);
 
 static int bn_apply_fwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
                         float* y, int B, int C, int L, int act, float slope, const float* residual, hipStream_t stream) {
@@ -342,13 +414,18 @@ static int bn_apply_fwd(const float* x, const float* gamma, const float* beta, c
 // Split from the normalisation so that (a) a producing conv can hand the sums over from its own
 // epilogue (m2d_conv1d_fwd's `stats`) and (b) data-parallel ranks can all-reduce them
 // (synchronised BatchNorm: global-batch statistics).
-int m2d_bn_stats(const float* x, double* sums, int B, int C, int L, void* stream_) {
+int m2d_bn_stats(const float* x, double* sums, int B, int C, int L, void* scratch, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int rc = bn_check("m2d_bn_stats", B, C, L)) return rc;
   BnReduceArgs r;
   memset(&r, 0, sizeof(r));
   r.x = x;
   r.acc = sums;
+  if (scratch) {
+    bn_use_scratch(r, scratch, C);
+    r.fin = 1;
+    r.sums_out = sums;
+  }
   r.B = B; r.C = C; r.L = L;
   r.mode = 0;
   M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 4.0 * B * C * (double)L, "bn_stats", B, C, L);
@@ -378,12 +455,29 @@ int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const floa
 int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                float* running_var, float* y, float* save_mean, float* save_invstd, int B, int C, int L,
                float eps, float momentum, int training, int act, float slope, const float* residual,
-               void* ws, size_t ws_bytes, void* stream_) {
+               void* ws, size_t ws_bytes, void* scratch, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int rc = bn_check("m2d_bn_fwd", B, C, L)) return rc;
   if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_fwd: workspace too small");
+  if (training && scratch) {
+    // statistics + mean / invstd / running buffers in one launch, then the apply pass
+    BnReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.x = x;
+    bn_use_scratch(r, scratch, C);
+    r.fin = 2;
+    r.f0 = save_mean; r.f1 = save_invstd; r.f2 = running_mean; r.f3 = running_mean ? running_var : nullptr;
+    r.count = (double)B * L; r.eps = eps; r.momentum = momentum;
+    r.B = B; r.C = C; r.L = L;
+    r.mode = 0;
+    {
+      M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 4.0 * B * C * (double)L, "bn_stats", B, C, L);
+      if (int rc = launch_reduce(r, stream)) return rc;
+    }
+    return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream);
+  }
   if (training) {
-    if (int rc = m2d_bn_stats(x, (double*)ws, B, C, L, stream_)) return rc;
+    if (int rc = m2d_bn_stats(x, (double*)ws, B, C, L, nullptr, stream_)) return rc;
     return m2d_bn_fwd_sums(x, (const double*)ws, (double)B * L, gamma, beta, running_mean, running_var, y, save_mean,
                            save_invstd, B, C, L, eps, momentum, act, slope, residual, stream_);
   }
@@ -398,7 +492,7 @@ int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* run
 // dz = dy * act'(bn(x)) recomputed from x (no y needed).
 int m2d_bn_bwd_stats(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                      const float* save_invstd, double* sums, int B, int C, int L, int act, float slope,
-                     void* stream_) {
+                     void* scratch, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int rc = bn_check("m2d_bn_bwd_stats", B, C, L)) return rc;
   BnReduceArgs r;
@@ -406,6 +500,11 @@ int m2d_bn_bwd_stats(const float* dy, const float* x, const float* gamma, const 
   r.x = x; r.dy = dy;
   r.gamma = gamma; r.beta = beta; r.mean = save_mean; r.invstd = save_invstd;
   r.acc = sums;
+  if (scratch) {
+    bn_use_scratch(r, scratch, C);
+    r.fin = 1;
+    r.sums_out = sums;
+  }
   r.B = B; r.C = C; r.L = L;
   r.mode = 1; r.act = act; r.slope = slope;
   M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.0 * 4.0 * B * C * (double)L, "bn_bwd_reduce", B, C, L);
@@ -428,6 +527,12 @@ int m2d_bn_bwd_sums(const float* dy, const float* x, const float* gamma, const f
   hipLaunchKernelGGL(m2d_bn_finalize_bwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream, sums_local,
                      sums_global, dgamma, dbeta, s_dz, s_dzx, C, count);
   M2D_CHECK_LAUNCH("m2d_bn_finalize_bwd_kernel");
+  return bn_apply_bwd(dy, x, gamma, beta, save_mean, save_invstd, s_dz, s_dzx, dx, B, C, L, act, slope, stream);
+}
+
+static int bn_apply_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                        const float* save_invstd, const float* s_dz, const float* s_dzx, float* dx, int B, int C, int L,
+                        int act, float slope, hipStream_t stream) {
   BnApplyArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.dy = dy;
@@ -444,10 +549,31 @@ int m2d_bn_bwd_sums(const float* dy, const float* x, const float* gamma, const f
 // Training-mode backward (single process): the two calls above on the workspace.
 int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
                const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
-               int B, int C, int L, int act, float slope, void* ws, size_t ws_bytes, void* stream_) {
+               int B, int C, int L, int act, float slope, void* ws, size_t ws_bytes, void* scratch, void* stream_) {
   if (int rc = bn_check("m2d_bn_bwd", B, C, L)) return rc;
   if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_bwd: workspace too small");
-  if (int rc = m2d_bn_bwd_stats(dy, x, gamma, beta, save_mean, save_invstd, (double*)ws, B, C, L, act, slope, stream_))
+  if (scratch) {
+    hipStream_t stream = (hipStream_t)stream_;
+    float* s_dz = (float*)((double*)ws + 2 * (size_t)C);
+    float* s_dzx = s_dz + C;
+    BnReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.x = x; r.dy = dy;
+    r.gamma = gamma; r.beta = beta; r.mean = save_mean; r.invstd = save_invstd;
+    bn_use_scratch(r, scratch, C);
+    r.fin = 3;
+    r.f0 = dgamma; r.f1 = dbeta; r.f2 = s_dz; r.f3 = s_dzx;
+    r.count = (double)B * L;
+    r.B = B; r.C = C; r.L = L;
+    r.mode = 1; r.act = act; r.slope = slope;
+    {
+      M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.0 * 4.0 * B * C * (double)L, "bn_bwd_reduce", B, C, L);
+      if (int rc = launch_reduce(r, stream)) return rc;
+    }
+    return bn_apply_bwd(dy, x, gamma, beta, save_mean, save_invstd, s_dz, s_dzx, dx, B, C, L, act, slope, stream);
+  }
+  if (int rc = m2d_bn_bwd_stats(dy, x, gamma, beta, save_mean, save_invstd, (double*)ws, B, C, L, act, slope, nullptr,
+                                stream_))
     return rc;
   return m2d_bn_bwd_sums(dy, x, gamma, beta, save_mean, save_invstd, (const double*)ws, (const double*)ws,
                          (double)B * L, dx, dgamma, dbeta, B, C, L, act, slope, ws, ws_bytes, stream_);
@@ -457,19 +583,25 @@ int m2d_bn_bwd(const float* dy, const float* x, const float* gamma, const float*
 // Bias gradient of conv1d (C = Cout) and of linear layers (L = 1), with the fused
 // activation derivative.
 int m2d_channel_sums(const float* x, const float* mask, float slope, float* out, int B, int C, int L,
-                     void* ws, size_t ws_bytes, void* stream_) {
+                     void* ws, size_t ws_bytes, void* scratch, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_channel_sums: bad shape");
-  if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_channel_sums: workspace too small");
+  if (!scratch && (ws_bytes < m2d_bn_workspace_bytes(C) || !ws))
+    M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_channel_sums: workspace too small");
   BnReduceArgs r;
   memset(&r, 0, sizeof(r));
   r.x = x; r.mask = mask; r.slope = slope;
   r.acc = (double*)ws;
+  if (scratch) {
+    bn_use_scratch(r, scratch, C);
+    r.fin = 4;
+    r.f0 = out;
+  }
   r.B = B; r.C = C; r.L = L;
   r.mode = 2;
   M2dProfScope prof(M2D_FAM_REDUCE, stream, 0.0, (mask ? 8.0 : 4.0) * B * C * (double)L, "channel_sums", B, C, L);
   int rc = launch_reduce(r, stream);
-  if (rc) return rc;
+  if (rc || scratch) return rc;
   hipLaunchKernelGGL(m2d_acc_to_float_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
                      (const double*)ws, out, C);
   M2D_CHECK_LAUNCH("m2d_acc_to_float_kernel");

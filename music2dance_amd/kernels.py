@@ -95,6 +95,19 @@ def _ws(nbytes, dev):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
 
 
+_BN_SCRATCH = {}
+
+
+def _bn_scratch(dev, C):
+    """The zero-kept accumulator scratch of the reducing BatchNorm / channel-sum calls (include/m2d.h:
+    m2d_bn_scratch_bytes): one per (device, stream), zeroed once here and left zeroed by every call."""
+    key = (dev.index, _stream(dev))
+    t = _BN_SCRATCH.get(key)
+    if t is None or t.numel() * 8 < 16 * C + 64:
+        t = _BN_SCRATCH[key] = torch.zeros((2 * max(C, 1024) + 8,), dtype=torch.float64, device=dev)
+    return t
+
+
 def conv_out_len(L, ks, stride, pad):
     return (L + 2 * pad - ks) // stride + 1
 
@@ -502,9 +515,8 @@ class HipKernels:
         L = x.shape[2] if x.dim() == 3 else 1
         out = torch.empty((C,), dtype=torch.float32, device=dev)
         h = _lib.lib()
-        ws = _ws(_ws_bytes('m2d_bn_workspace_bytes', C), dev)
         with _on(dev):
-            rc = h.m2d_channel_sums(_ptr(x), _ptr(mask), slope, _ptr(out), B, C, L, _ptr(ws), ws.numel() * 4,
+            rc = h.m2d_channel_sums(_ptr(x), _ptr(mask), slope, _ptr(out), B, C, L, 0, 0, _ptr(_bn_scratch(dev, C)),
                                     _stream(dev))
         _lib.check(rc, "m2d_channel_sums")
         return out
@@ -522,7 +534,8 @@ class HipKernels:
         with _on(dev):
             rc = h.m2d_bn_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
                               _ptr(save_mean), _ptr(save_invstd), B, C, L, eps, momentum, 1 if training else 0,
-                              act, slope, _ptr(residual), _ptr(ws), ws.numel() * 4, _stream(dev))
+                              act, slope, _ptr(residual), _ptr(ws), ws.numel() * 4,
+                              _ptr(_bn_scratch(dev, C)) if training else 0, _stream(dev))
         _lib.check(rc, "m2d_bn_fwd")
         return y, save_mean, save_invstd
 
@@ -538,7 +551,7 @@ class HipKernels:
         L = x.shape[2] if x.dim() == 3 else 1
         sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
         with _on(dev):
-            rc = _lib.lib().m2d_bn_stats(_ptr(x), _ptr(sums), B, C, L, _stream(dev))
+            rc = _lib.lib().m2d_bn_stats(_ptr(x), _ptr(sums), B, C, L, _ptr(_bn_scratch(dev, C)), _stream(dev))
         _lib.check(rc, "m2d_bn_stats")
         return sums
 
@@ -569,7 +582,8 @@ class HipKernels:
         sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
         with _on(dev):
             rc = _lib.lib().m2d_bn_bwd_stats(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(save_mean),
-                                             _ptr(save_invstd), _ptr(sums), B, C, L, act, slope, _stream(dev))
+                                             _ptr(save_invstd), _ptr(sums), B, C, L, act, slope,
+                                             _ptr(_bn_scratch(dev, C)), _stream(dev))
         _lib.check(rc, "m2d_bn_bwd_stats")
         return sums
 
@@ -602,7 +616,7 @@ class HipKernels:
         with _on(dev):
             rc = h.m2d_bn_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_invstd),
                               _ptr(dx), _ptr(dgamma), _ptr(dbeta), B, C, L, act, slope, _ptr(ws), ws.numel() * 4,
-                              _stream(dev))
+                              _ptr(_bn_scratch(dev, C)), _stream(dev))
         _lib.check(rc, "m2d_bn_bwd")
         return dx, dgamma, dbeta
 

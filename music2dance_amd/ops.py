@@ -471,10 +471,15 @@ class _BatchNormAct(Function):
         x, residual = _c(x), _c(residual)
         world = 1
         if training:
+            world = _sync_world()
+        if training and sums is None and world == 1:
+            # one process, no sums handed over: statistics, mean / invstd and the running buffers in one launch
+            y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, True, eps, momentum, act, slope,
+                                         residual)
+        elif training:
             # batch statistics as raw sums: from the producing conv's epilogue when it supplied them
             if sums is None:
                 sums = K().bn_stats(x)
-            world = _sync_world()
             if world > 1:
                 sums = _all_reduce_sums(sums)
             count = float(world) * (x.numel() // x.shape[1])

@@ -21,7 +21,45 @@ def _free_port():
     return port
 
 
+def _watchdog(name, seconds=240):
+    """A stuck worker dumps every thread's Python stack (gpurun_out/ travels back from the GPU box) and exits, so the
+    parent fails in minutes instead of waiting out its queue."""
+    import faulthandler
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "stuck_%s_%d.log" % (name, os.getpid()))
+    f = open(path, "w")
+    faulthandler.dump_traceback_later(seconds, exit=True, file=f)
+
+    def _done():  # a worker that finished leaves no file
+        faulthandler.cancel_dump_traceback_later()
+        f.close()
+        if os.path.getsize(path) == 0:
+            os.unlink(path)
+    import atexit
+    atexit.register(_done)
+    return f
+
+
+def _recv(q, procs, n, timeout):
+    """n results from the workers; fails as soon as a worker has died without reporting."""
+    import queue, time
+    out, t0 = [], time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=5))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or all(p.exitcode is not None for p in procs):
+                raise AssertionError("worker exited without a result: exit codes %s" % [p.exitcode for p in procs])
+            if time.time() - t0 > timeout:
+                [p.kill() for p in procs]
+                raise AssertionError("workers timed out after %d s" % timeout)
+    return out
+
+
 def _worker(rank, world, port, graphs, q):
+    _wd = _watchdog("two_ranks_r%d" % rank)
     os.environ["M2D_PERSISTENT_GRU"] = "0"  # two processes on ONE GPU: persistent kernels could starve each other
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -56,7 +94,7 @@ def test_two_ranks_one_gpu(graphs):
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, graphs, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted(q.get(timeout=300) for _ in range(world))
+    res = sorted(_recv(q, procs, world, 300))
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     (_, v0, s0), (_, v1, s1) = res
@@ -72,6 +110,7 @@ def _rccl_worker(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _wd = _watchdog("rccl")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     import bench
@@ -118,7 +157,7 @@ def test_rccl_backend_exchange_world_size_one():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
     p.start()
-    ok, sigs = q.get(timeout=300)
+    ok, sigs = _recv(q, [p], 1, 300)[0]
     p.join(120)
     assert p.exitcode == 0 and ok
     (l0, s0, n0), (l1, s1, n1) = sigs
@@ -136,6 +175,7 @@ def _rccl_graphs_worker(port, q):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert os.environ.get("M2D_PERSISTENT_GRU", "1") != "0"
+    _wd = _watchdog("rccl_graphs")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     import bench
@@ -169,7 +209,7 @@ def test_rccl_two_shapes_graphs_equal_eager_with_persistent_gru_and_hook_overlap
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_graphs_worker, args=(_free_port(), q))
     p.start()
-    sigs = q.get(timeout=600)
+    sigs = _recv(q, [p], 1, 300)[0]
     p.join(120)
     assert p.exitcode == 0
     (l0, s0, n0, h0), (l1, s1, n1, h1) = sigs
