@@ -118,11 +118,13 @@ class CriticStep:
 
     # ------------------------------------------------------------------ the pass
     @torch.no_grad()
-    def run(self, real, fake_rows, audio=None, alpha=None, on_grads=None):
+    def run(self, real, fake_rows, audio=None, alpha=None, on_grads=None, fake_ready=None):
         """real: (B, T, C) poses [any view of B*T*C], fake_rows: (B*T, C) generator rows (no graph), audio:
         (B, 1, S) for the two-branch critic, alpha: (B, 1) or (B,) interpolation weights on the device.
         Sets p.grad of every critic parameter (they must be None on entry: the engines zero with set_to_none);
         on_grads: called whenever further gradients are in place (GradExchange.poll).
+        fake_ready: event after which `fake_rows` is complete (a generator forward still running on its own stream):
+        only the pose branch waits for it - the audio branch's forward does not read the poses and starts at once.
         -> {"loss_critic", "gp", "w_dist"} (0-dim device tensors)."""
         k = K()
         st, au = self.stick, self.audio
@@ -141,6 +143,10 @@ class CriticStep:
 
         # ---------------------------------------------------------------- forward
         side, cur = self._fork(dev)
+        if fake_ready is not None:
+            first = side if side is not None else cur
+            first.wait_event(fake_ready)
+            fake_rows.record_stream(first)
         with self._On(side):
             X3 = k.pose_pack3(real.reshape(B, T, C), fake_rows, alpha.reshape(B))
             a = [k.conv1d_fwd(X3, w1, b1, 1, pad1, ACT_RELU)]

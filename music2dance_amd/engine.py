@@ -163,6 +163,18 @@ class WganGpEngine:
         self._main_mark = main.record_event()
         out.record_stream(main)
 
+    def _hand_over_generator_forward(self, out):
+        """As _join_generator_forward, but the main stream does not wait: -> the completion event (or None) for the
+        consumer to wait on where it first reads `out` (CriticStep.run: its pose branch)."""
+        pend, self._fake_pending = self._fake_pending, None
+        if pend is None:
+            return None
+        assert pend[0] is out
+        main = torch.cuda.current_stream(out.device)
+        self._main_mark = main.record_event()
+        out.record_stream(main)
+        return pend[1]
+
     def flush(self):
         self._finish_critic_step()
         self._check_async()
@@ -229,11 +241,13 @@ class Phase3Engine(WganGpEngine):
         self.optim_critic.zero_grad(set_to_none=True)
         audio_c = audio.unsqueeze(1)
         if self.manual_critic is not None:
-            self._join_generator_forward(fake_rows)
+            # the audio branch's forward does not read the poses: after a generator step, when the generator forward
+            # cannot run ahead, it starts while that forward is still going; only the pose branch waits for it
+            fake_ready = self._hand_over_generator_forward(fake_rows)
             if alpha is None:  # drawn on the host generator where the reference draws it (losses.py:15)
                 alpha = to_device_async(torch.rand(B, 1), real.device)
             return self.manual_critic.run(real, fake_rows, None if self.ablated else audio_c, alpha,
-                                          on_grads=self._poll_exchange())
+                                          on_grads=self._poll_exchange(), fake_ready=fake_ready)
         real_c = real.view(B, T, self.output_size).permute(0, 2, 1).contiguous()
         with self.critic.shared_audio() if not self.ablated else contextlib.nullcontext():
             self._join_generator_forward(fake_rows)
