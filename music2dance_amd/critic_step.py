@@ -144,7 +144,7 @@ class CriticStep:
         # ---------------------------------------------------------------- forward
         side, cur = self._fork(dev)
         if fake_ready is not None:
-            first = side if side is not None else cur
+            first = side if side is not None else torch.cuda.current_stream(dev)
             first.wait_event(fake_ready)
             fake_rows.record_stream(first)
         with self._On(side):

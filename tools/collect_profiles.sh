@@ -20,6 +20,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_overlap -
 python3 $R/tools/gap_analysis.py $O/${TAG}_prof_overlap > $O/${TAG}_gaps.txt 2>&1
 M2D_BRANCH_OVERLAP=0 M2D_GEN_PIPELINE=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $ARGS > /dev/null 2>&1
 M2D_BRANCH_OVERLAP=0 M2D_GEN_PIPELINE=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python3 $ARGS > /dev/null 2>&1
+# steady-state launch census (no bench prologue / roofline pass / CPU baseline in the trace)
+rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_steady -- python3 $R/tools/steady.py 16 > $O/${TAG}_steady.log 2>&1
+python3 $R/tools/tail_count.py $O/${TAG}_steady 16 > $O/${TAG}_launch_census.txt 2>&1
+rm -rf $O/${TAG}_steady
 cd $R
 find $O/${TAG}_prof $O/${TAG}_prof_overlap -name "*kernel_trace.csv" -delete
 python3 tools/pmc_summary.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write > $O/${TAG}_pmc_traffic.json
