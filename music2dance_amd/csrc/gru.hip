@@ -284,9 +284,9 @@ __device__ __forceinline__ void gru_mac(const float* arow, bool rok, const float
 // 8 waves split K: at H = 240 a wave multiplies 8 k-steps per contraction instead of 15 (the
 // dependent MFMA chain and the operand burst per wave halve; the step is latency-bound)
 #define GRU_FWD_NW 8
+#define GRU_FWD_MAXB 2  // blocks of 16 k per wave: covers H <= 16 * 8 * 2 = 256
 __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_stack_fwd_kernel(const GruStackFwdArgs a) {
   constexpr int NW = GRU_FWD_NW;
-  constexpr int UN = GRU_UNROLL * 4 / NW;  // k-steps per wave in the single-batch path (covers H <= 256)
   __shared__ float red[NW][4][256];
   const int l = blockIdx.z;
   const int t = a.d - l;
@@ -304,46 +304,70 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_stack_fwd_kernel(cons
   // Both contractions (hidden: h_l[t-1] W_hh^T, input: h_{l-1}[t] W_ih^T) have K = H. When a
   // wave's share fits one batch (H <= 4 * NW * UN = 256) ALL operand loads of both are
   // issued before the first MFMA: one memory round trip per step instead of two.
-  const int nsteps = (H + 3) / 4;
   const bool use_h = t > 0, use_i = l > 0;
-  if (nsteps <= NW * UN) {
-    float ah[UN], bh[UN][3], ai[UN], bi[UN][3];
+  if (H <= 16 * NW * GRU_FWD_MAXB) {
+    // K = H in blocks of 16: wave w takes blocks w, w + NW; inside a block lane group q = lane >> 4 owns the four
+    // consecutive k = 16 j + 4 q + m (MFMA k-step m multiplies the k's {16 j + m, + 4, + 8, + 12}): ONE 16-byte load
+    // per lane and block - the rows were written by other CUs a step earlier and the step is bound by the number of
+    // memory requests. The persistent kernel (below) uses the same assignment and order: bit-identical sums.
+    const int nblk = (H + 15) / 16;
+    const int q = lane >> 4;
+    const bool vec = (H & 3) == 0;
+    float ah[GRU_FWD_MAXB][4], ai[GRU_FWD_MAXB][4], bh[GRU_FWD_MAXB][4][3], bi[GRU_FWD_MAXB][4][3];
     const float* hrow = a.out[l] + ((size_t)arow * T + (use_h ? t - 1 : 0)) * H;
     const float* irow = a.out[use_i ? l - 1 : 0] + ((size_t)arow * T + t) * H;
     const float* wh = a.w_hh_t[l];
     const float* wi = a.w_ih_t[use_i ? l : 0];
 #pragma unroll
-    for (int i = 0; i < UN; ++i) {
-      const int st = wave + NW * i;
-      const int k = 4 * st + (lane >> 4);
-      const bool kok = st < nsteps && k < H;
-      const size_t wo = (size_t)(kok ? k : 0) * 3 * H + (cok ? bcol : 0);
-      const bool okh = use_h && kok, oki = use_i && kok;
-      ah[i] = (okh && rok) ? hrow[k] : 0.f;
-      ai[i] = (oki && rok) ? irow[k] : 0.f;
+    for (int i = 0; i < GRU_FWD_MAXB; ++i) {
+      const int j = wave + NW * i;
+      const int k0 = 16 * j + 4 * q;
+      const bool jok = j < nblk;
+      if (jok && vec && k0 + 3 < H) {
+        const float4 vh = (use_h && rok) ? *reinterpret_cast<const float4*>(hrow + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vi = (use_i && rok) ? *reinterpret_cast<const float4*>(irow + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ah[i][0] = vh.x; ah[i][1] = vh.y; ah[i][2] = vh.z; ah[i][3] = vh.w;
+        ai[i][0] = vi.x; ai[i][1] = vi.y; ai[i][2] = vi.z; ai[i][3] = vi.w;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        bh[i][j] = (okh && cok) ? wh[wo + j * H] : 0.f;
-        bi[i][j] = (oki && cok) ? wi[wo + j * H] : 0.f;
+        for (int m = 0; m < 4; ++m) {
+          const bool ok = jok && rok && k0 + m < H;
+          ah[i][m] = (ok && use_h) ? hrow[k0 + m] : 0.f;
+          ai[i][m] = (ok && use_i) ? irow[k0 + m] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const bool ok = jok && cok && k0 + m < H;
+        const size_t wo = (size_t)(ok ? k0 + m : 0) * 3 * H + (cok ? bcol : 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          bh[i][m][g] = (ok && use_h) ? wh[wo + g * H] : 0.f;
+          bi[i][m][g] = (ok && use_i) ? wi[wo + g * H] : 0.f;
+        }
       }
     }
     // input part first, hidden part second: the persistent kernel (below) can then multiply the layer
     // below's output while it still waits for its own layer's previous step; same order = same bits
     if (use_i) {
 #pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][1], acc[1], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], bi[i][2], acc[3], 0, 0, 0);
-      }
+      for (int i = 0; i < GRU_FWD_MAXB; ++i)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], bi[i][m][0], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], bi[i][m][1], acc[1], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], bi[i][m][2], acc[3], 0, 0, 0);
+        }
     }
     if (use_h) {
 #pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][1], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], bh[i][2], acc[2], 0, 0, 0);
-      }
+      for (int i = 0; i < GRU_FWD_MAXB; ++i)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], bh[i][m][0], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], bh[i][m][1], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], bh[i][m][2], acc[2], 0, 0, 0);
+        }
     }
   } else {
     if (use_i) {
@@ -407,29 +431,30 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_stack_fwd_kernel(cons
 // Persistent forward: ONE launch for the whole L-layer, T-step recurrence.
 // Workgroup (hidden tile, batch tile, layer) keeps its weight slices - W_hh^T[:, 16 units x 3 gates]
 // and, for layers >= 1, W_ih^T likewise: 2 x H x 48 floats = 92 KB at H = 240 - in LDS for all T
-// steps (the per-step launches re-read them from L2 every step), and loops over t:
-//   wait    own layer finished step t-1 and the layer below finished step t for this batch tile:
-//           one lane polls two agent-scope counters (relaxed `sc1` loads, s_sleep back-off, bounded);
-//   load    the 16 x H rows of h_l[t-1] and h_{l-1}[t] with `sc1` loads (they were written by other
-//           CUs in this launch: plain loads could hit stale L1 lines);
-//   compute the same MFMA / reduction order as m2d_gru_stack_fwd_kernel (bit-identical results);
-//   publish h_l[t] with `sc1` (write-through) stores, every storing wave drains (s_waitcnt
-//           vmcnt(0)), workgroup barrier, ONE lane adds 1 to the layer's counter.
-// This is row 1 of the guide's table of hand-offs that need no acquire fence (one signalling lane per
-// storing workgroup after drain + barrier; consumer: sc1 poll, barrier, sc1 loads; one workgroup per
-// CU - the LDS footprint enforces it). All workgroups must be resident at once (L x ceil(B/16) x
-// ceil(H/16) <= CUs, checked by the launcher); every spin is bounded: on a timeout the workgroup
-// raises `*error` (pinned host memory) and every workgroup leaves, so the kernel always terminates.
-#define GRU_CNT_STRIDE 64  // one counter per 256-byte line: pollers of different tiles do not share a memory channel line
+// steps (the per-step launches re-read them from L2 every step), and loops over t.
+// Hand-off between workgroups: THE DATA IS THE FLAG. The launcher fills every layer's output with a sentinel bit
+// pattern (0xFFFFFFFF, a NaN no arithmetic here produces); a producer publishes h_l[t] with write-through (`sc1`)
+// dword stores and goes on; a consumer loads the 16 x H rows it needs with `sc1` loads (16 bytes per lane) and
+// repeats the loads that still show the sentinel. Every dword is valid or sentinel on its own (4-byte stores are
+// single-copy atomic), so nothing has to be ordered: no counters, no drain of the stores, no signalling lane, no
+// acquire - one L2 round trip on the step's critical path instead of four (counter add, counter poll, barrier,
+// operand load). The round-2/3 form (counter per (layer, batch tile), `sc1` poll, drain + barrier + add) took
+// 7.5 us per step at H = 240; this one is bounded by store -> L2 -> load plus the 24 MFMAs and the gate math.
+// Compute is m2d_gru_stack_fwd_kernel's: same k assignment, MFMA order and cross-wave sum (bit-identical results).
+// All workgroups must be resident at once (checked by the launcher); every spin is bounded: on a timeout the wave
+// raises `*error` (pinned host memory), every spinning wave sees it and leaves, so the kernel always terminates.
+#define GRU_SENTINEL 0xFFFFFFFFu
+#define GRU_CNT_STRIDE 64  // (backward) one counter per 256-byte line: pollers of different tiles do not share a line
 struct GruPersistArgs {
   GruStackFwdArgs s;
-  unsigned* counters;  // [L][nbt], zeroed before the launch
   unsigned* error;     // host-visible word
   unsigned spin_limit;
 };
 
 typedef __attribute__((address_space(1))) unsigned gru_gu32;
 typedef __attribute__((address_space(1))) float gru_gf32;
+typedef unsigned int gru_u32x4 __attribute__((__vector_size__(16)));
+typedef float gru_f32x4 __attribute__((__vector_size__(16)));
 
 __device__ __forceinline__ float gru_ld_sc1(const float* p) {
   return __hip_atomic_load((gru_gf32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -451,21 +476,78 @@ __device__ __forceinline__ bool gru_wait_ge(unsigned* cnt, unsigned want, unsign
   }
 }
 
+// One lane's share (this wave's blocks) of a 16-row operand, through `sc1` loads; -> true when an element that is
+// needed still shows the sentinel. rs: buffer descriptor over the (B, T, H) tensor; row_off: element offset of the
+// lane's row at the step.
+__device__ __forceinline__ bool gru_load_rows(__amdgpu_buffer_rsrc_t rs, const float* base, size_t row_off, bool rok, int H,
+                                              int nblk, bool vec, int wave, int q, float (&av)[GRU_FWD_MAXB][4]) {
+  constexpr int NW = GRU_FWD_NW;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < GRU_FWD_MAXB; ++i) {
+    const int j = wave + NW * i;
+    const int k0 = 16 * j + 4 * q;
+    if (j < nblk && rok) {
+      if (vec && k0 + 3 < H) {
+        // (whole-vector bit cast: see gru_bwd_contract)
+        const gru_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((row_off + k0) << 2), 0, 16 /* sc1 */);
+        bad = bad || v[0] == GRU_SENTINEL || v[1] == GRU_SENTINEL || v[2] == GRU_SENTINEL || v[3] == GRU_SENTINEL;
+        const gru_f32x4 f = __builtin_bit_cast(gru_f32x4, v);
+        av[i][0] = f[0]; av[i][1] = f[1]; av[i][2] = f[2]; av[i][3] = f[3];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float x = 0.f;
+          if (k0 + m < H) {
+            x = gru_ld_sc1(base + row_off + k0 + m);
+            bad = bad || __builtin_bit_cast(unsigned, x) == GRU_SENTINEL;
+          }
+          av[i][m] = x;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) av[i][m] = 0.f;
+    }
+  }
+  return bad;
+}
+
+// Both operands of a step (the layer below's h[t], the own layer's h[t-1]): all loads go out together, and the ones
+// that came back with a sentinel are repeated until every lane of the wave has its data. -> false on timeout / error
+// elsewhere.
+__device__ __forceinline__ bool gru_spin_operands(bool use_i, __amdgpu_buffer_rsrc_t low_rs, const float* low, size_t low_off,
+                                                  bool use_h, __amdgpu_buffer_rsrc_t own_rs, const float* own, size_t own_off,
+                                                  bool rok, int H, int nblk, bool vec, int wave, int q, unsigned* error,
+                                                  unsigned limit, float (&ai)[GRU_FWD_MAXB][4], float (&ah)[GRU_FWD_MAXB][4]) {
+  bool need_i = use_i, need_h = use_h;
+  for (unsigned spins = 0;; ++spins) {
+    if (need_i) need_i = gru_load_rows(low_rs, low, low_off, rok, H, nblk, vec, wave, q, ai);
+    if (need_h) need_h = gru_load_rows(own_rs, own, own_off, rok, H, nblk, vec, wave, q, ah);
+    if (!__builtin_amdgcn_ballot_w64(need_i || need_h)) return true;  // wave-uniform: every lane has its operands
+    if ((spins & 63u) == 63u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
+    if (spins >= limit) {
+      __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(const GruPersistArgs pa) {
   constexpr int NW = GRU_FWD_NW;
-  constexpr int UN = GRU_UNROLL * 4 / NW;  // k-steps per wave: covers H <= 256
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GruStackFwdArgs& a = pa.s;
   const int H = a.H, T = a.T;
   float* wh = lds;                       // [H][48]: column g * 16 + c = gate g, unit u0 + c
   float* wi = wh + (size_t)H * 48;       // [H][48] (layers >= 1)
   float (*red)[4][256] = reinterpret_cast<float (*)[4][256]>(wi + (size_t)H * 48);
-  __shared__ int go;
+  __shared__ int dead;
   const int l = blockIdx.z, bt = blockIdx.y;
-  const int nth = gridDim.x, nbt = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * 16, b0 = bt * 16;
   const bool use_i = l > 0;
+  if (tid == 0) dead = 0;
   // weight slices -> LDS (once)
   for (int e = tid; e < H * 48; e += 64 * NW) {
     const int k = e / 48, c = e - k * 48;
@@ -477,7 +559,12 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
   __syncthreads();
   const int arow = b0 + (lane & 15);
   const bool rok = arow < a.B;
-  const int nsteps = (H + 3) / 4;
+  const int nblk = (H + 15) / 16;
+  const int q = lane >> 4;
+  const bool vec = (H & 3) == 0;
+  const unsigned obytes = (unsigned)((size_t)a.B * T * H * sizeof(float));  // < 2^31: checked by the launcher
+  const __amdgpu_buffer_rsrc_t own_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.out[l], (short)0, (int)obytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t low_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.out[use_i ? l - 1 : l], (short)0, (int)obytes, 0x00020000);
   const int row = (tid & 255) >> 4, col = tid & 15;
   const int b = b0 + row, u = u0 + col;
   const bool owner = tid < 256 && b < a.B && u < H;
@@ -487,8 +574,6 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
     bhr = a.b_hh[l][u]; bhz = a.b_hh[l][H + u]; bhn = a.b_hh[l][2 * H + u];
     if (use_i) { bir = a.b_ih[l][u]; biz = a.b_ih[l][H + u]; bin = a.b_ih[l][2 * H + u]; }
   }
-  unsigned* my_cnt = pa.counters + ((size_t)l * nbt + bt) * GRU_CNT_STRIDE;
-  unsigned* lo_cnt = pa.counters + ((size_t)(use_i ? l - 1 : 0) * nbt + bt) * GRU_CNT_STRIDE;
 
   for (int t = 0; t < T; ++t) {
     const bool use_h = t > 0;
@@ -501,57 +586,47 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
       const float* gi = a.gi0 + ((size_t)b * T + t) * 3 * H;
       gir = gi[u]; giz = gi[H + u]; gin = gi[2 * H + u];
     }
-    // ---- input part: needs step t of the layer below, which usually finished a step ago
+    // ---- operands: step t of the layer below (usually there already) and step t-1 of every hidden tile of this
+    //      layer (the critical dependency)
+    float ai[GRU_FWD_MAXB][4], ah[GRU_FWD_MAXB][4];
+    if (!gru_spin_operands(use_i, low_rs, a.out[use_i ? l - 1 : l], ((size_t)arow * T + t) * H, use_h, own_rs, a.out[l],
+                           ((size_t)arow * T + (use_h ? t - 1 : 0)) * H, rok, H, nblk, vec, wave, q, pa.error,
+                           pa.spin_limit, ai, ah))
+      return;  // timeout or error elsewhere (waves that have left are not counted by the barriers)
     if (use_i) {
-      if (tid == 0) go = gru_wait_ge(lo_cnt, (unsigned)nth * (unsigned)(t + 1), pa.error, pa.spin_limit) ? 1 : 0;
-      __syncthreads();
-      if (!go) return;  // timeout or error elsewhere: every workgroup leaves
-      float ai[UN];
-      const float* irow = a.out[l - 1] + ((size_t)arow * T + t) * H;
 #pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int st = wave + NW * i;
-        const int k = 4 * st + (lane >> 4);
-        ai[i] = (st < nsteps && k < H && rok) ? gru_ld_sc1(irow + k) : 0.f;
-      }
+      for (int i = 0; i < GRU_FWD_MAXB; ++i) {
+        const int j = wave + NW * i;
+        if (j < nblk) {
+          const int k0 = 16 * j + 4 * q;
 #pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int st = wave + NW * i;
-        const int k = 4 * st + (lane >> 4);
-        const bool kok = st < nsteps && k < H;
-        const float* wr = wi + (size_t)(kok ? k : 0) * 48 + (lane & 15);
-        const float b0v = kok ? wr[0] : 0.f, b1v = kok ? wr[16] : 0.f, b2v = kok ? wr[32] : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], b0v, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], b1v, acc[1], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], b2v, acc[3], 0, 0, 0);
+          for (int m = 0; m < 4; ++m) {
+            const bool kok = k0 + m < H;
+            const float* wr = wi + (size_t)(kok ? k0 + m : 0) * 48 + (lane & 15);
+            const float b0v = kok ? wr[0] : 0.f, b1v = kok ? wr[16] : 0.f, b2v = kok ? wr[32] : 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], b0v, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], b1v, acc[1], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], b2v, acc[3], 0, 0, 0);
+          }
+        }
       }
     }
-    // ---- hidden part: needs step t-1 of every hidden tile of this layer (the critical dependency)
     if (use_h) {
-      if (nth > 1) {  // a workgroup that is its layer's only hidden tile depends on nobody but itself
-        __syncthreads();  // everybody is past the previous read of `go`
-        if (tid == 0) go = gru_wait_ge(my_cnt, (unsigned)nth * (unsigned)t, pa.error, pa.spin_limit) ? 1 : 0;
-        __syncthreads();
-        if (!go) return;
-      }
-      float ah[UN];
-      const float* hrow = a.out[l] + ((size_t)arow * T + (t - 1)) * H;
 #pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int st = wave + NW * i;
-        const int k = 4 * st + (lane >> 4);
-        ah[i] = (st < nsteps && k < H && rok) ? gru_ld_sc1(hrow + k) : 0.f;
-      }
+      for (int i = 0; i < GRU_FWD_MAXB; ++i) {
+        const int j = wave + NW * i;
+        if (j < nblk) {
+          const int k0 = 16 * j + 4 * q;
 #pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int st = wave + NW * i;
-        const int k = 4 * st + (lane >> 4);
-        const bool kok = st < nsteps && k < H;
-        const float* wr = wh + (size_t)(kok ? k : 0) * 48 + (lane & 15);
-        const float b0v = kok ? wr[0] : 0.f, b1v = kok ? wr[16] : 0.f, b2v = kok ? wr[32] : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], b0v, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], b1v, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], b2v, acc[2], 0, 0, 0);
+          for (int m = 0; m < 4; ++m) {
+            const bool kok = k0 + m < H;
+            const float* wr = wh + (size_t)(kok ? k0 + m : 0) * 48 + (lane & 15);
+            const float b0v = kok ? wr[0] : 0.f, b1v = kok ? wr[16] : 0.f, b2v = kok ? wr[32] : 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], b0v, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], b1v, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], b2v, acc[2], 0, 0, 0);
+          }
+        }
       }
     }
 #pragma unroll
@@ -577,7 +652,7 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
       float h = (1.f - z) * n + z * hprev;
       if (a.lengths && t >= a.lengths[b]) h = 0.f;
       hprev = h;
-      gru_st_sc1(a.out[l] + bt_ * H + u, h);
+      gru_st_sc1(a.out[l] + bt_ * H + u, h);  // published: consumers spin on the value itself
       if (a.saved[l]) {
         const size_t plane = (size_t)a.B * T * H;
         float* sv = a.saved[l];
@@ -587,10 +662,7 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
         sv[3 * plane + bt_ * H + u] = hn;
       }
     }
-    // publish: every storing wave drains its write-through stores, then ONE lane signals
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add((gru_gu32*)my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // `red` is free for the next step
   }
 }
 
@@ -704,8 +776,6 @@ struct GruPersistBwdArgs {
 // lane when K is a multiple of 4: raw buffer load, aux = sc1), W from the workgroup's LDS slice [K][16]. All loads of
 // the wave's (at most 6 at H = 240) blocks are issued before the first MFMA.
 #define GRU_BWD_MAXB 6  // blocks per wave: covers K = 3H <= 16 * 8 * 6 = 768 (H <= 256)
-typedef unsigned int gru_u32x4 __attribute__((__vector_size__(16)));
-typedef float gru_f32x4 __attribute__((__vector_size__(16)));
 template <int NW>
 __device__ __forceinline__ void gru_bwd_contract(const float* base, size_t row_off, bool rok, const float* wl, int K,
                                                  int wave, int lane, bool vec, __amdgpu_buffer_rsrc_t rs, f32x4& acc) {
@@ -922,16 +992,23 @@ int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float*
   a.B = B; a.T = T; a.H = H; a.L = L;
   dim3 grid(m2d_ceil_div(H, 16), m2d_ceil_div(B, 16), L);
   M2dProfScope prof(M2D_FAM_GRU, stream, 2.0 * B * 3.0 * H * H * (double)T * (2 * L - 1), 0.0, "gru_stack_fwd", B, T, H);
-  // `counters` (optional: m2d_gru_stack_counters(B, L) unsigneds of scratch owned by this call): run the
-  // recurrence as ONE persistent launch when every workgroup fits on the chip at once
-  if (counters && gru_persist_ok(grid, H, T)) {
+  // `counters` non-NULL (the backward's scratch size; the forward only takes it as the request): run the recurrence
+  // as ONE persistent launch when every workgroup fits on the chip at once
+  if (counters && gru_persist_ok(grid, H, T) && (long long)B * T * H * 4 < 0x7fffffffLL) {
     GruPersistState* ps = gru_persist_state();
     if (ps) {
-      const size_t cbytes = sizeof(unsigned) * (size_t)m2d_gru_stack_counters(B, L);
-      if (hipMemsetAsync(counters, 0, cbytes, stream) == hipSuccess) {
+      // every output starts as the sentinel the consumers spin on (one memset when the layers' outputs are one
+      // allocation, as kernels.py makes them)
+      const size_t obytes = sizeof(float) * (size_t)B * T * H;
+      bool contiguous = true;
+      for (int l = 1; l < L; ++l) contiguous = contiguous && (out[l] == out[l - 1] + (size_t)B * T * H);
+      bool ok = true;
+      if (contiguous) ok = hipMemsetAsync(out[0], 0xFF, obytes * L, stream) == hipSuccess;
+      else
+        for (int l = 0; l < L; ++l) ok = ok && hipMemsetAsync(out[l], 0xFF, obytes, stream) == hipSuccess;
+      if (ok) {
         GruPersistArgs pa;
         pa.s = a;
-        pa.counters = counters;
         pa.error = ps->error_dev;
         pa.spin_limit = ps->spin_limit;
         hipLaunchKernelGGL(m2d_gru_persist_fwd_kernel, grid, dim3(64 * GRU_FWD_NW), gru_persist_lds(H), stream, pa);

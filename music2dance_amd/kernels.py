@@ -665,7 +665,8 @@ class HipKernels:
         dev = _chk(gi0, *[t for t in list(w_ih_t) + list(b_ih) + list(w_hh_t) + list(b_hh) if t is not None])
         B, T, H3 = gi0.shape
         H = H3 // 3
-        outs = [torch.empty((B, T, H), dtype=torch.float32, device=dev) for _ in range(L)]
+        # (one allocation: the persistent launch pre-fills every layer's output with its hand-off sentinel in one memset)
+        outs = list(torch.empty((L, B, T, H), dtype=torch.float32, device=dev).unbind(0))
         saved = [torch.empty((4, B, T, H), dtype=torch.float32, device=dev) for _ in range(L)] if save else None
         keep = [self._ptr_array(v) for v in (w_ih_t, b_ih, w_hh_t, b_hh, outs)]
         sv = self._ptr_array(saved) if save else (None, None)

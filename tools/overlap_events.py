@@ -14,9 +14,10 @@ for _i in range(int(os.environ.get("STREAM_SHIFT", "0"))):  # see tools/steady.p
         torch.zeros(8, device=dev)
     _dummies.append(_s)
 torch.cuda.synchronize()
-gen, critic = bench.build_models(dev)
-eng = Phase3Engine(gen, critic, bench.P3_DEFAULT)
-real, audio, slices, ready = synthetic_phase3_batch(64, 120, dev, seed=1, with_event=True)
+cfg = bench.PRESETS[os.environ.get("CONFIG", "c3")]
+gen, critic = bench.build_models(dev, cfg["frames"], cfg["enc_type"], cfg["ablated"])
+eng = Phase3Engine(gen, critic, bench.P3_DEFAULT, ablated=cfg["ablated"])
+real, audio, slices, ready = synthetic_phase3_batch(cfg["batch"], cfg["frames"], dev, seed=1, with_event=True)
 for _ in range(16): eng.train_step(real, audio, slices, inputs_ready=ready)
 from music2dance_amd import runner
 runner.settle_garbage_collector()  # (a generation-2 collection inside the timed bodies costs 60-80 ms)
@@ -43,6 +44,6 @@ end = ev()
 torch.cuda.synchronize()
 print("ms/body %.3f" % (base.elapsed_time(end) / N))
 if os.environ.get("BRIEF"):
-    marks = marks[10:24]
+    marks = marks[8:28]
 for name, s, e, grad in marks:
     print("%-14s %s %9.3f -> %9.3f  (%6.3f ms)" % (name, "grad" if grad else "    ", base.elapsed_time(s), base.elapsed_time(e), s.elapsed_time(e)))
