@@ -519,12 +519,18 @@ __device__ __forceinline__ bool gru_load_rows(__amdgpu_buffer_rsrc_t rs, const f
 __device__ __forceinline__ bool gru_spin_operands(bool use_i, __amdgpu_buffer_rsrc_t low_rs, const float* low, size_t low_off,
                                                   bool use_h, __amdgpu_buffer_rsrc_t own_rs, const float* own, size_t own_off,
                                                   bool rok, int H, int nblk, bool vec, int wave, int q, unsigned* error,
-                                                  unsigned limit, float (&ai)[GRU_FWD_MAXB][4], float (&ah)[GRU_FWD_MAXB][4]) {
+                                                  unsigned limit, float (&ai)[GRU_FWD_MAXB][4], float (&ah)[GRU_FWD_MAXB][4],
+                                                  unsigned& spin_acc) {
   bool need_i = use_i, need_h = use_h;
   for (unsigned spins = 0;; ++spins) {
     if (need_i) need_i = gru_load_rows(low_rs, low, low_off, rok, H, nblk, vec, wave, q, ai);
     if (need_h) need_h = gru_load_rows(own_rs, own, own_off, rok, H, nblk, vec, wave, q, ah);
-    if (!__builtin_amdgcn_ballot_w64(need_i || need_h)) return true;  // wave-uniform: every lane has its operands
+    if (!__builtin_amdgcn_ballot_w64(need_i || need_h)) {
+#ifdef GRU_COUNT_SPINS
+      spin_acc += spins;
+#endif
+      return true;  // wave-uniform: every lane has its operands
+    }
     if ((spins & 63u) == 63u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
     if (spins >= limit) {
       __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -575,23 +581,30 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
     if (use_i) { bir = a.b_ih[l][u]; biz = a.b_ih[l][H + u]; bin = a.b_ih[l][2 * H + u]; }
   }
 
+  unsigned spin_acc = 0;  // (GRU_COUNT_SPINS builds: repeated operand loads of this wave)
+  // layer 0: the input projection (written before the launch, (B, T, 3H): every step touches lines nobody has read
+  // yet - an HBM round trip) is fetched ONE STEP AHEAD, so the gate math never waits for it
+  float nir = bir, niz = biz, nin = bin;
+  if (owner && l == 0) {
+    const float* gi = a.gi0 + ((size_t)b * T) * 3 * H;
+    nir = gi[u]; niz = gi[H + u]; nin = gi[2 * H + u];
+  }
   for (int t = 0; t < T; ++t) {
     const bool use_h = t > 0;
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // layer 0: this step's input projection (written before the launch) is fetched under the waits
-    float gir = bir, giz = biz, gin = bin;
-    if (owner && l == 0) {
-      const float* gi = a.gi0 + ((size_t)b * T + t) * 3 * H;
-      gir = gi[u]; giz = gi[H + u]; gin = gi[2 * H + u];
+    float gir = nir, giz = niz, gin = nin;
+    if (owner && l == 0 && t + 1 < T) {
+      const float* gi = a.gi0 + ((size_t)b * T + t + 1) * 3 * H;
+      nir = gi[u]; niz = gi[H + u]; nin = gi[2 * H + u];
     }
     // ---- operands: step t of the layer below (usually there already) and step t-1 of every hidden tile of this
     //      layer (the critical dependency)
     float ai[GRU_FWD_MAXB][4], ah[GRU_FWD_MAXB][4];
     if (!gru_spin_operands(use_i, low_rs, a.out[use_i ? l - 1 : l], ((size_t)arow * T + t) * H, use_h, own_rs, a.out[l],
                            ((size_t)arow * T + (use_h ? t - 1 : 0)) * H, rok, H, nblk, vec, wave, q, pa.error,
-                           pa.spin_limit, ai, ah))
+                           pa.spin_limit, ai, ah, spin_acc))
       return;  // timeout or error elsewhere (waves that have left are not counted by the barriers)
     if (use_i) {
 #pragma unroll
@@ -664,6 +677,9 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
     }
     __syncthreads();  // `red` is free for the next step
   }
+#ifdef GRU_COUNT_SPINS
+  if (lane == 0) { atomicAdd(pa.error + 1, spin_acc); atomicAdd(pa.error + 2, (unsigned)T); }
+#endif
 }
 
 struct GruStackBwdArgs {
@@ -1030,6 +1046,13 @@ int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float*
 int m2d_gru_persist_error(void) {
   GruPersistState* ps = gru_persist_state_peek();
   if (!ps || !ps->error_host) return 0;
+#ifdef GRU_COUNT_SPINS
+  {
+    volatile unsigned* w = (volatile unsigned*)ps->error_host;
+    if (w[2]) fprintf(stderr, "[gru spins] %u retries over %u wave-steps = %.2f per step\n", w[1], w[2], (double)w[1] / w[2]);
+    w[1] = 0; w[2] = 0;
+  }
+#endif
   const unsigned e = *(volatile unsigned*)ps->error_host;
   if (e) *(volatile unsigned*)ps->error_host = 0u;
   return e ? 1 : 0;
