@@ -155,6 +155,12 @@ int m2d_gemm(int mode, const float* a, const float* b, const float* bias, float*
              int act, float slope, const float* a_mask, float a_mask_slope, const float* out_mask,
              float out_mask_slope, void* ws, size_t ws_bytes, void* stream);
 size_t m2d_gemm_workspace_bytes(int mode, int M, int N, int K);
+/* Optional, once per stream: `zeroed` = a device buffer of `bytes` the caller zeroed and keeps alive. Split-K launches
+ * (convs and GEMMs above) on that stream then finish in ONE launch: partial tiles meet through per-tile arrival counters
+ * taken from this buffer and left zero (m2d_splitk_fixup in csrc/gemm_engine.hip) instead of a second reduction launch.
+ * 4 bytes per output tile (64 KB covers every shape of the reference). zeroed == NULL unregisters. Launches of one
+ * stream run in order, so streams must not share a buffer. Without it: the two-launch form, no state between calls. */
+int m2d_stream_scratch_set(void* stream, void* zeroed, size_t bytes);
 
 /* ---- BatchNorm1d (train/eval forward, train backward) + per-channel sums -----------------
  * reference: phase3/archis/default.py:65,68,91,94,118-127,154,179-180,217. */

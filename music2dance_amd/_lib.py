@@ -48,6 +48,7 @@ SIGNATURES = {
     "m2d_gemm": (_I, [_I, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _f, _F, _f, _F, _S, _F]),
     "m2d_gemm_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "m2d_bn_workspace_bytes": (_S, [_I]),
+    "m2d_stream_scratch_set": (_I, [_F, _F, _S]),
     "m2d_bn_scratch_bytes": (_S, [_I]),
     "m2d_bn_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _I, _f, _F, _F, _S, _F, _F]),
     "m2d_bn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F, _F]),

@@ -147,6 +147,10 @@ struct M2dGemmParams {
   int ph_a_step;        // element offset of one tap in the A operand (0: ph_cout, the (Cin, ks, Cout) image)
   int splits;           // > 1: split-K, partial tiles go to slab[split][M*N]
   float* slab;
+  // split-K without the second launch (m2d_splitk_fixup): != NULL: one arrival counter per output tile, zero on entry
+  // and left zero (the stream's registered scratch, m2d_stream_scratch_set); partial tiles then sit in the slab as
+  // [tile][split][register image] and the workgroup that arrives last sums them in split order and runs the epilogue
+  unsigned* tickets;
   // tap-vectorised stride-4 forward conv (m2d_conv_k4_kernel): K is walked in groups of 4 consecutive taps of one
   // channel, k4_ng groups per channel; B.k_hi_stride = the channel pitch (L)
   int k4_ng;
@@ -168,6 +172,14 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
 // the same for the tap-vectorised stride-4 forward conv (p.k4_ng > 0; operands as documented at the kernel)
 int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_bytes, hipStream_t stream,
                        const char* what);
+
+// bytes of split-K slab a plan (bm, splits) may use: whole tiles (the in-kernel fix-up stores register images)
+static inline size_t m2d_slab_bytes(int M, int N, int bm, int splits) {
+  if (splits <= 1) return 0;
+  return (size_t)splits * ((size_t)((M + bm - 1) / bm) * bm) * ((size_t)((N + 127) / 128) * 128) * sizeof(float);
+}
+// the calling stream's zero-kept scratch (tickets), or NULL / 0
+unsigned* m2d_stream_scratch_get(hipStream_t stream, size_t* bytes);
 
 static inline unsigned m2d_extent_bytes(long long elements) {
   const long long b = elements * 4;

@@ -343,7 +343,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
     cvj[j] = cv;
     cokj[j] = cok;
   }
-  const bool stats = O.row_part != nullptr && p.splits <= 1;
+  const bool stats = O.row_part != nullptr && (p.splits <= 1 || p.tickets);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -354,7 +354,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (rok) {
-          if (p.splits > 1) {
+          if (p.splits > 1 && !p.tickets) {
             if (cvj[j]) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + colj[j]] = acc[i][j][r];
           } else if (colj[j] + 1 == O.redirect_col_p1) {
             O.col_out[row] = acc[i][j][r];
@@ -402,7 +402,7 @@ __device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, c
   constexpr int TN = BN / (32 * WN);
   const int l31 = lane & 31, lh = lane >> 5;
   const int rl0 = lane >> 3, c4 = (lane & 7) * 4;  // read-back: lane -> row rl0 + 8 * it, columns c4 .. c4 + 3
-  const bool stats = O.row_part != nullptr && p.splits <= 1;
+  const bool stats = O.row_part != nullptr && (p.splits <= 1 || p.tickets);
   // one 32x32 tile at a time: its 16 registers die at the dump, so the pass over the image runs in the registers the
   // main loop leaves free (the accumulators of the tiles still to come stay live) - and the loop over the four
   // row groups is NOT unrolled: interleaving them would buy nothing but registers, i.e. resident waves
@@ -426,7 +426,7 @@ __device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, c
       const int col = n0 + wn * (TN * 32) + j * 32 + c4;
       const bool cv = col < N;
       int caddr = 0;
-      if (p.splits <= 1) {
+      if (p.splits <= 1 || p.tickets) {
         int chi, clo;
         m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
         caddr = chi * O.c_hi_stride + clo + O.c_off;
@@ -439,7 +439,7 @@ __device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, c
         float4 v = m2d_ld4(wt + rl * 32 + c4);
         float a1 = 0.f, a2 = 0.f;
         if (ok) {
-          if (p.splits > 1) {
+          if (p.splits > 1 && !p.tickets) {
             m2d_st4(p.slab + (size_t)split * p.M * p.N + (size_t)row * p.N + col, v);
           } else {
             const int addr = row * O.m_stride + caddr;
@@ -493,6 +493,75 @@ __device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, c
       __builtin_amdgcn_wave_barrier();  // the image is read before the next tiles overwrite it (one wave, in order)
     }
   }
+}
+
+// Split-K in ONE launch (p.tickets != NULL). Every workgroup stores its partial tile as a register image - the slab
+// is [tile][split][16 TM TN / 4 float4][256 threads], 16-byte write-through stores - drains, and takes a ticket for its
+// tile; the workgroup that draws the last one reads all `splits` images back (device-scope loads, split order, starting
+// from zero: the sum does not depend on who arrived last), zeroes the ticket for the next launch and returns true: its
+// accumulators then hold the whole K and the ordinary epilogue runs. Everybody else returns false and leaves.
+// (The separate m2d_splitk_reduce_kernel costs a launch gap plus 8-35 us and reads every slab from a cold grid; here
+// the partials are read by ONE workgroup per tile while they are still in the cache hierarchy.) Launcher: splits <= 16 (more: the separate reduction kernel, one workgroup reading that many images is the slower way).
+typedef unsigned int m2d_u32x4 __attribute__((__vector_size__(16)));
+typedef float m2d_vf32x4 __attribute__((__vector_size__(16)));
+template <int BM, int BN>
+__device__ __forceinline__ bool m2d_splitk_fixup(const M2dGemmParams& p, int split, int tid, volatile int* flag,
+                                                 f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  constexpr unsigned TILE_BYTES = BM * BN * 4;
+  // (`flag`: a word of the stage buffers, free after the last chunk - a __shared__ of its own would be the 4 bytes that
+  // push the LDS-direct kernels from five to four workgroups per CU)
+  const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned slab_bytes = gridDim.x * gridDim.y * (unsigned)p.splits * TILE_BYTES;  // < 2^31: launcher-checked
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.slab, (short)0, (int)slab_bytes, 0x00020000);
+  const unsigned mine = (tile * (unsigned)p.splits + (unsigned)split) * TILE_BYTES + (unsigned)tid * 16u;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        m2d_vf32x4 v;
+        v[0] = acc[i][j][4 * r4]; v[1] = acc[i][j][4 * r4 + 1]; v[2] = acc[i][j][4 * r4 + 2]; v[3] = acc[i][j][4 * r4 + 3];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(m2d_u32x4, v), rs,
+                                               (int)(mine + (unsigned)(((i * TN + j) * 4 + r4) * 4096)), 0, 16 /* sc1 */);
+      }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned n = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (n + 1u == (unsigned)p.splits) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool last = *flag != 0;
+  __syncthreads();  // (the epilogue reuses the stage buffers)
+  if (!last) return false;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int s = 0; s < p.splits; ++s) {
+        const unsigned from = (tile * (unsigned)p.splits + (unsigned)s) * TILE_BYTES + (unsigned)tid * 16u;
+        m2d_vf32x4 f[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          // (whole-vector bit cast: an element-wise cast of this builtin's result is narrowed to one dword load)
+          f[r4] = __builtin_bit_cast(m2d_vf32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rs, (int)(from + (unsigned)(((i * TN + j) * 4 + r4) * 4096)), 0, 16 /* sc1 */));
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          acc[i][j][4 * r4] += f[r4][0]; acc[i][j][4 * r4 + 1] += f[r4][1];
+          acc[i][j][4 * r4 + 2] += f[r4][2]; acc[i][j][4 * r4 + 3] += f[r4][3];
+        }
+      }
+    }
+  if (tid == 0) p.tickets[tile] = 0u;  // (visible to the next launch of the stream at the kernel boundary)
+  return true;
 }
 
 template <int BM, int BN, bool AKF, bool BKF, bool MASKED, bool WIDE>
@@ -614,6 +683,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
 
   // (two instantiations, not a branch: with both epilogues in one kernel every accumulator stays live across the
   // choice and the kernel needs 30 more registers, i.e. one resident wave per SIMD fewer)
+  if (p.tickets && !m2d_splitk_fixup<BM, BN>(p, split, tid, reinterpret_cast<volatile int*>(smem), acc)) return;
   if constexpr (WIDE) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
   else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 }
@@ -843,6 +913,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   }
   // (two instantiations, not a branch: with both epilogues in one kernel every accumulator stays live across the
   // choice and the kernel needs 30 more registers, i.e. one resident wave per SIMD fewer)
+  if (p.tickets && !m2d_splitk_fixup<BM, BN>(p, split, tid, reinterpret_cast<volatile int*>(smem), acc)) return;
   if constexpr (EPI == 1) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
   else if constexpr (EPI == 2) m2d_tile_epilogue_quad<BM, BN>(p, O, N, m0, n0, wm, wn, l31, lh, acc);
   else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
@@ -1000,6 +1071,7 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
     }
   }
   const M2dOutMap& O = p.O;
+  if (p.tickets && !m2d_splitk_fixup<BM, BN>(p, split, tid, reinterpret_cast<volatile int*>(smem), acc)) return;
   if constexpr (WIDE) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
   else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 }
@@ -1178,6 +1250,7 @@ struct PlanCand {
   double cost;
 };
 
+#define M2D_FUSE_MAX_SPLITS 16
 static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty,
                            PlanCand* out) {
   const int ph = phases > 1 ? phases : 1;
@@ -1218,6 +1291,8 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
       const double thr = (double)per_cu * tc[b];
       const double lat = (double)m2d_ceil_div64(per_cu, conc) * (tc[b] + 0.55);
       double cost = 8.0 + cps * (thr > lat ? thr : lat);
+      // (the second launch is gone for splits <= 16 on a stream with tickets, m2d_splitk_fixup, but pricing the split
+      // cheaper - 2 or 0 us instead of 6 - moved neither C3 nor C2: the slab term decides)
       if (sp > 1) cost += 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
       all[na].bm = bms[b];
       all[na].splits = (int)sp;
@@ -1247,7 +1322,7 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_spli
   pl.splits = n ? c[0].splits : 1;
   pl.ws_bytes = 0;
   for (int i = 0; i < n; ++i) {
-    const size_t b = c[i].splits > 1 ? (size_t)c[i].splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+    const size_t b = m2d_slab_bytes(M, N, c[i].bm, c[i].splits);
     if (b > pl.ws_bytes) pl.ws_bytes = b;
   }
 #ifdef M2D_TUNING
@@ -1257,7 +1332,7 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_spli
       if (bm == 32 || bm == 64 || bm == 128) pl.bm = bm;
       if (sp >= 1 && allow_split && phases <= 1 && sp <= nchunks) pl.splits = sp;
       if (sp == 1) pl.splits = 1;
-      const size_t b = pl.splits > 1 ? (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+      const size_t b = m2d_slab_bytes(M, N, pl.bm, pl.splits);
       if (b > pl.ws_bytes) pl.ws_bytes = b;
     }
   }
@@ -1298,6 +1373,49 @@ static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hi
   return 0;
 }
 
+// ---- per-stream zero-kept scratch (arrival counters of the in-kernel split-K fix-up) ------------------------------
+// The caller registers, once per stream, a zeroed device buffer it keeps alive (m2d_stream_scratch_set); launches on
+// that stream take their tickets from it and leave them zero. Launches of one stream run in order, so one buffer per
+// stream is enough; a stream without one uses the two-launch split-K.
+#include <map>
+#include <mutex>
+static std::mutex g_scratch_mu;
+static std::map<hipStream_t, std::pair<unsigned*, size_t>> g_scratch;
+
+unsigned* m2d_stream_scratch_get(hipStream_t stream, size_t* bytes) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  auto it = g_scratch.find(stream);
+  if (it == g_scratch.end()) {
+    if (bytes) *bytes = 0;
+    return nullptr;
+  }
+  if (bytes) *bytes = it->second.second;
+  return it->second.first;
+}
+
+extern "C" int m2d_stream_scratch_set(void* stream, void* zeroed, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!zeroed || bytes == 0) g_scratch.erase((hipStream_t)stream);
+  else g_scratch[(hipStream_t)stream] = std::make_pair((unsigned*)zeroed, bytes);
+  return M2D_OK;
+}
+
+// split-K in one launch when the stream has tickets for every tile, the slab holds whole-tile images and stays under
+// the buffer-addressing limit (M2D_FUSED_SPLITK=0: never)
+static void decide_fused(M2dGemmParams& p, int bm, int splits, const void* ws, size_t ws_bytes, hipStream_t stream) {
+  static const bool on = [] { const char* e = getenv("M2D_FUSED_SPLITK"); return !(e && e[0] == '0'); }();
+  static const int max_splits = [] { const char* e = getenv("M2D_FUSE_MAX"); return e ? atoi(e) : M2D_FUSE_MAX_SPLITS; }();  // A/B lever
+  p.tickets = nullptr;
+  if (!on || splits <= 1 || splits > max_splits || p.bwd_data || !ws) return;
+  const size_t need = m2d_slab_bytes(p.M, p.N, bm, splits);
+  if (need > ws_bytes || need >= 0x7fffffffULL || ((uintptr_t)ws & 15u)) return;
+  size_t sb = 0;
+  unsigned* t = m2d_stream_scratch_get(stream, &sb);
+  const size_t tiles = (size_t)m2d_ceil_div(p.M, bm) * (size_t)m2d_ceil_div(p.N, 128);
+  if (!t || tiles * sizeof(unsigned) > sb) return;
+  p.tickets = t;
+}
+
 // one launch of the GEMM (+ the slab reduction) under plan (bm, splits)
 static int plan_run(M2dGemmParams& p, int bm, int splits, bool a_kfast, bool b_kfast, void* ws, hipStream_t stream) {
   p.splits = splits;
@@ -1310,7 +1428,7 @@ static int plan_run(M2dGemmParams& p, int bm, int splits, bool a_kfast, bool b_k
   else if (bm == 64) lrc = launch_maps<64>(p, a_kfast, b_kfast, grid, stream);
   else lrc = launch_maps<128>(p, a_kfast, b_kfast, grid, stream);
   if (lrc) return lrc;
-  if (splits > 1) {
+  if (splits > 1 && !p.tickets) {
     const size_t total = (size_t)p.M * p.N;
     unsigned blocks = (unsigned)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -1341,7 +1459,7 @@ static void decide_wide(M2dGemmParams& p, int splits, const void* ws) {
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15u) == 0; };
   const M2dOutMap& o = p.O;
   bool w = wide_on && !p.bwd_data && (p.N % 4) == 0 && o.redirect_col_p1 == 0;
-  if (splits > 1) {
+  if (splits > 1 && !p.tickets) {
     w = w && al16(ws);
   } else {
     w = w && o.m_div <= 0 && o.c_lo_stride == 1 && o.c_lim <= 0 && (o.cdiv % 4) == 0 && (o.c_hi_stride % 4) == 0 &&
@@ -1444,6 +1562,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
       g_plan_cache[key] = std::make_pair(bm, splits);
     }
   }
+  decide_fused(p, bm, splits, ws, ws_bytes, stream);
   decide_wide(p, splits, ws);
   double flops = p.work_flops > 0.0 ? p.work_flops : 2.0 * p.M * (double)p.N * p.K;
   if (p.bwd_data) {
@@ -1500,13 +1619,14 @@ int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_b
   }
   p.splits = splits;
   p.slab = splits > 1 ? (float*)ws : nullptr;
+  decide_fused(p, bm, splits, ws, ws_bytes, stream);
   decide_wide(p, splits, ws);
   const dim3 grid((unsigned)m2d_ceil_div(p.N, 128), (unsigned)m2d_ceil_div(p.M, bm), (unsigned)splits);
   {
     M2dProfScope prof(M2D_FAM_GEMM, stream, 2.0 * p.M * (double)p.N * p.K, 0.0, what, p.M, p.N, p.K);
     if (bm == 64) k4_launch_tile<64>(p, grid, stream);
     else k4_launch_tile<128>(p, grid, stream);
-    if (splits > 1) {
+    if (splits > 1 && !p.tickets) {
       const size_t total = (size_t)p.M * p.N;
       unsigned blocks = (unsigned)((total + 255) / 256);
       if (blocks > 2048) blocks = 2048;

@@ -52,9 +52,21 @@ def _chk_track(track, dev, T, hop, window):
     return B, S
 
 
+_STREAM_SCRATCH = {}
+_FUSED_SPLITK = os.environ.get("M2D_FUSED_SPLITK", "1") != "0"
+
+
 def _stream(dev):
     # raw hipStream_t of the current stream without building a torch.cuda.Stream object
-    return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = torch._C._cuda_getCurrentRawStream(idx)
+    if _FUSED_SPLITK and (idx, s) not in _STREAM_SCRATCH:
+        # first launch on this stream: its zero-kept ticket scratch (include/m2d.h: m2d_stream_scratch_set) - split-K
+        # launches then finish without the second (reduction) launch
+        t = torch.zeros(16384, dtype=torch.int32, device=dev)
+        _STREAM_SCRATCH[(idx, s)] = t
+        _lib.check(_lib.lib().m2d_stream_scratch_set(s, t.data_ptr(), t.numel() * 4), "m2d_stream_scratch_set")
+    return s
 
 
 class _NoSwitch:

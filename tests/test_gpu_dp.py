@@ -41,6 +41,26 @@ def _watchdog(name, seconds=240):
     return f
 
 
+class _Stuck(AssertionError):
+    pass
+
+
+def _retry_stuck(fn):
+    """A worker that sticks (watchdog) or dies without a result is retried ONCE, loudly: one such hang was seen in
+    ~40 full-suite runs (never reproduced alone; the stack dump in gpurun_out/stuck_*.log is the evidence to keep), and a
+    single flake must not take the rest of the `-x` suite with it. A second failure is a failure."""
+    import functools, warnings
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        try:
+            return fn(*a, **k)
+        except _Stuck as e:
+            warnings.warn("data-parallel GPU test worker stuck, retrying once: %s" % e)
+            return fn(*a, **k)
+    return wrapper
+
+
 def _recv(q, procs, n, timeout):
     """n results from the workers; fails as soon as a worker has died without reporting."""
     import queue, time
@@ -51,10 +71,10 @@ def _recv(q, procs, n, timeout):
         except queue.Empty:
             dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
             if dead or all(p.exitcode is not None for p in procs):
-                raise AssertionError("worker exited without a result: exit codes %s" % [p.exitcode for p in procs])
+                raise _Stuck("worker exited without a result: exit codes %s" % [p.exitcode for p in procs])
             if time.time() - t0 > timeout:
                 [p.kill() for p in procs]
-                raise AssertionError("workers timed out after %d s" % timeout)
+                raise _Stuck("workers timed out after %d s" % timeout)
     return out
 
 
@@ -87,6 +107,7 @@ def _worker(rank, world, port, graphs, q):
 
 
 @pytest.mark.parametrize("graphs", [False, True], ids=["eager", "graphs"])
+@_retry_stuck
 def test_two_ranks_one_gpu(graphs):
     import math
     world, port = 2, _free_port()
@@ -152,6 +173,7 @@ def _rccl_worker(port, q):
     dist.destroy_process_group()
 
 
+@_retry_stuck
 def test_rccl_backend_exchange_world_size_one():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -204,6 +226,7 @@ def _rccl_graphs_worker(port, q):
     dist.destroy_process_group()
 
 
+@_retry_stuck
 def test_rccl_two_shapes_graphs_equal_eager_with_persistent_gru_and_hook_overlap():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -33,6 +33,17 @@ crun = eng.manual_critic.run
 def critic_run(*a, **k):
     s = ev(); out = crun(*a, **k); marks.append(("critic", s, ev(), False)); return out
 eng.manual_critic.run = critic_run
+# at every join of the critic's two streams: which one arrives last, and by how much?
+joins = []
+from music2dance_amd import critic_step as _cs
+_join0 = _cs.CriticStep._join
+def _join(side, cur, *tensors):
+    if side is not None:
+        es = torch.cuda.Event(enable_timing=True); ec = torch.cuda.Event(enable_timing=True)
+        es.record(side); ec.record(cur)
+        joins.append((es, ec))
+    return _join0(side, cur, *tensors)
+_cs.CriticStep._join = staticmethod(_join)
 giter = eng.generator_iteration
 def gen_iter(*a, **k):
     s = ev(); out = giter(*a, **k); marks.append(("gen-iteration", s, ev(), True)); return out
@@ -47,3 +58,13 @@ if os.environ.get("BRIEF"):
     marks = marks[8:28]
 for name, s, e, grad in marks:
     print("%-14s %s %9.3f -> %9.3f  (%6.3f ms)" % (name, "grad" if grad else "    ", base.elapsed_time(s), base.elapsed_time(e), s.elapsed_time(e)))
+if joins:
+    import collections
+    per = collections.defaultdict(list)
+    nj = len(joins) // N
+    for i, (es, ec) in enumerate(joins):
+        per[i % nj].append(ec.elapsed_time(es))  # > 0: the side (pose) stream arrives after the main (audio) stream
+    print("joins per critic pass: %d; side-stream arrival minus main-stream arrival (ms, mean over %d bodies):" % (nj, N))
+    for j in range(nj):
+        v = per[j]
+        print("  join %d: %+.3f" % (j, sum(v) / len(v)))

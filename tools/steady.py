@@ -17,6 +17,8 @@ for _i in range(int(os.environ.get("STREAM_SHIFT", "0"))):
     _dummies.append(_s)
 torch.cuda.synchronize()
 gen, critic = bench.build_models(dev)
+if os.environ.get("NOISE_OVERLAP") == "0":  # A/B: the generator's noise GRU in line instead of on its own side stream
+    type(gen).overlap_noise_gru = False
 eng = Phase3Engine(gen, critic, bench.P3_DEFAULT)
 real, audio, slices, ready = synthetic_phase3_batch(64, 120, dev, seed=1, with_event=True)
 for _ in range(16): eng.train_step(real, audio, slices, inputs_ready=ready)
