@@ -767,3 +767,44 @@ def test_wgan_critic_loss_scalars():
     assert abs(out[2] - w) < 1e-6 and abs(out[1] - gp) < 1e-6 and abs(out[0] - (w + 10 * gp)) < 1e-5
     out = K().wgan_critic_loss(s.to(DEV), B, p0.to(DEV), None, 10.0).cpu().double()
     assert abs(out[1] - p0.double()) < 1e-7
+
+
+# ----------------------------------------------------------------------------------- split-K in one launch
+def test_split_k_in_one_launch_equals_the_two_launch_form():
+    """Round 3: with the stream's ticket scratch registered (include/m2d.h: m2d_stream_scratch_set; kernels.py does it
+    on a stream's first launch) a split-K plan finishes inside the GEMM launch; without it the C-ABI falls back to
+    GEMM + m2d_splitk_reduce_kernel. Same operands, both forms, against fp64: a weight gradient (K = B * Lout = 15 360,
+    a few tiles: always split) and a small-N forward."""
+    from music2dance_amd import _lib, kernels
+    k = K()
+    B, Cin, L, Cout, ks, s, p = 128, 128, 120, 128, 7, 1, 3
+    x = gen(B, Cin, L, seed=1).to(DEV)
+    dy = gen(B, Cout, L, seed=2).to(DEV)
+    w = (gen(Cout, Cin, ks, seed=3) / math.sqrt(Cin * ks)).to(DEV)
+    bias = gen(Cout, seed=4).to(DEV)
+    ref_w = torch.nn.grad.conv1d_weight(x.double().cpu(), w.shape, dy.double().cpu(), stride=s, padding=p)
+    ref_y = F.conv1d(x[:8].double().cpu(), w.double().cpu(), bias.double().cpu(), stride=s, padding=p)
+    stream = kernels._stream(torch.device(DEV))  # registers the scratch
+    key = (torch.device(DEV).index, stream)
+    assert key in kernels._STREAM_SCRATCH
+    k.prof_begin()
+    gw_fused = k.conv1d_bwd_weight(x, dy, ks, s, p)
+    y_fused = k.conv1d_fwd(x[:8].contiguous(), w, bias, s, p)
+    torch.cuda.synchronize()
+    k.prof_end()
+    # two-launch form: unregister, run, register again
+    t = kernels._STREAM_SCRATCH[key]
+    _lib.check(_lib.lib().m2d_stream_scratch_set(stream, 0, 0), "m2d_stream_scratch_set")
+    try:
+        gw_two = k.conv1d_bwd_weight(x, dy, ks, s, p)
+        y_two = k.conv1d_fwd(x[:8].contiguous(), w, bias, s, p)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(_lib.lib().m2d_stream_scratch_set(stream, t.data_ptr(), t.numel() * 4), "m2d_stream_scratch_set")
+    assert int(t.abs().sum().item()) == 0  # the tickets are left zero
+    assert rel_err(gw_fused, ref_w) <= 2e-5 and rel_err(gw_two, ref_w) <= 2e-5
+    assert rel_err(y_fused, ref_y) <= 2e-5 and rel_err(y_two, ref_y) <= 2e-5
+    assert rel_err(gw_fused, gw_two.double()) <= 2e-6
+    # and again on the registered stream: the tickets a launch left behind serve the next one
+    gw_again = k.conv1d_bwd_weight(x, dy, ks, s, p)
+    assert torch.equal(gw_again, gw_fused)
