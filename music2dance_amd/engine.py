@@ -177,6 +177,10 @@ class WganGpEngine:
 
     def flush(self):
         self._finish_critic_step()
+        # the persistent recurrent launches report a timeout through a host word that is only meaningful once the
+        # device has caught up: synchronise here (end of an epoch / before a checkpoint / end of the bench), not per step
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
         self._check_async()
 
     @staticmethod

@@ -464,6 +464,23 @@ def _all_reduce_sums(sums):
     return out
 
 
+_sync_counts = {}
+
+
+def _global_count(local_count, device):
+    """Elements per channel over ALL ranks. Reduced once per distinct local count (a host read, i.e. a device sync: not
+    something to do per layer and step) and cached: correct for equal shards and for a partial last batch that is
+    partial on every rank alike; ranks whose shard sizes vary independently of their own size are not supported."""
+    import torch.distributed as dist
+    key = (float(local_count), id(_sync_bn["group"]))
+    g = _sync_counts.get(key)
+    if g is None:
+        t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_sync_bn["group"])
+        g = _sync_counts[key] = float(t.item())
+    return g
+
+
 class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, eps, momentum, act, slope, sums):
@@ -480,9 +497,10 @@ class _BatchNormAct(Function):
             # batch statistics as raw sums: from the producing conv's epilogue when it supplied them
             if sums is None:
                 sums = K().bn_stats(x)
+            count = float(x.numel() // x.shape[1])
             if world > 1:
                 sums = _all_reduce_sums(sums)
-            count = float(world) * (x.numel() // x.shape[1])
+                count = _global_count(count, x.device)
             y, mean, invstd = K().bn_fwd_sums(x, sums, count, gamma, beta, running_mean, running_var, eps, momentum,
                                               act, slope, residual)
         else:
@@ -506,7 +524,7 @@ class _BatchNormAct(Function):
             local = K().bn_bwd_stats(gy, x, gamma, beta, mean, invstd, act, slope)
             glob = _all_reduce_sums(local)
             dx, dgamma, dbeta = K().bn_bwd_sums(gy, x, gamma, beta, mean, invstd, local, glob,
-                                                float(world) * (x.numel() // x.shape[1]), act, slope)
+                                                _global_count(x.numel() // x.shape[1], x.device), act, slope)
         else:
             dx, dgamma, dbeta = K().bn_bwd(gy, x, gamma, beta, mean, invstd, act, slope)
         return dx, dgamma, dbeta, None, None, (gy if has_res else None), None, None, None, None, None, None
