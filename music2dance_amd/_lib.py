@@ -96,6 +96,10 @@ def lib():
         raise M2dError(
             "libm2d_hip.so is not built (%s). Run `python -m music2dance_amd.build` "
             "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    # PyTorch first: its bundled HIP runtime must be the one this library binds to. Loaded the other way round the
+    # process holds two HIP runtimes (/opt/rocm's through this library, torch's own) and every launch through this
+    # library fails with "no ROCm-capable device is detected" (seen when build() and smoke() share a process).
+    import torch  # noqa: F401
     h = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(h, name)  # AttributeError here = header / library mismatch
