@@ -101,7 +101,9 @@ def cpu_baseline(sample_b=32, T=120, threads=None):
 
 
 PRESETS = {  # BASELINE.json configs[0..4] at their per-GPU shapes
-    "c1": dict(phase=1, batch=64, frames=1),     # phase1/configs/b1l10s128.yaml (BASELINE words it "CPU": GPU-only here)
+    # phase1/configs/b1l10s128.yaml (BASELINE words it "CPU": GPU-only here). Host-launch-bound when eager (2.8-3.2 ms
+    # per body for 0.75 ms of kernels): the preset replays the captured graphs (Phase1Engine.enable_graphs, 0.86 ms)
+    "c1": dict(phase=1, batch=64, frames=1, graphs="on"),
     "c2": dict(phase=2, batch=32, frames=120),   # phase2/configs/default.yaml at batch 32
     "c3": dict(enc_type="default", batch=64, frames=120, ablated=False),
     "c4": dict(enc_type="wavegan", batch=32, frames=120, ablated=False),  # global 256 on 8 GPUs

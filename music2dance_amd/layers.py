@@ -5,6 +5,8 @@ consumes the RNG identically (seeded-constructor parity) and
 state_dict keys / shapes are the reference's; only `forward` differs: it
 dispatches to the gfx950 kernels through ops.py and can fuse the following activation.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -163,6 +165,69 @@ class WindowView:
         return WindowView(torch.as_strided(x, (B, need), (S, 1), x.storage_offset()), T, hop, window)
 
 
+class DrawTape:
+    """The HOST random draws of a captured loop body (captured-graph mode of the small models, engine.Phase1Engine).
+    The reference draws noise, interpolation weights and dropout masks from the default CPU generator inside the loop;
+    a captured graph cannot. While a tape is installed (`draw_tape`) every `host_draw` hands out a STATIC device buffer
+    instead - the first pass records (kind, shape, p) in program order, later passes (the capture) get the same buffers
+    back in the same order - and `refill()` makes the same draws, in that order, on the host generator before each
+    replay and copies them into the buffers: the generator is consumed exactly as the eager path consumes it."""
+
+    def __init__(self):
+        self.entries = []  # (kind, shape, p, buffer)
+        self.cursor = 0
+
+    def rewind(self):
+        self.cursor = 0
+
+    def draw(self, kind, shape, p, device, dtype):
+        shape = tuple(shape)
+        if self.cursor < len(self.entries):
+            k, sh, pp, buf = self.entries[self.cursor]
+            if (k, sh, pp) != (kind, shape, p):
+                raise RuntimeError("DrawTape: the captured body drew %r where it had recorded %r" % ((kind, shape, p), (k, sh, pp)))
+        else:
+            buf = torch.zeros(shape, dtype=dtype, device=device)
+            self.entries.append((kind, shape, p, buf))
+        self.cursor += 1
+        return buf
+
+    def refill(self):
+        for kind, shape, p, buf in self.entries:
+            buf.copy_(to_device_async(_host_sample(kind, shape, p, buf.dtype), buf.device))
+
+
+_TAPE = None
+
+
+@contextlib.contextmanager
+def draw_tape(tape):
+    global _TAPE
+    prev, _TAPE = _TAPE, tape
+    try:
+        yield tape
+    finally:
+        _TAPE = prev
+
+
+def _host_sample(kind, shape, p, dtype):
+    if kind == "randn":
+        return torch.randn(*shape, dtype=dtype)
+    if kind == "rand":
+        return torch.rand(*shape, dtype=dtype)
+    if kind == "bernoulli":
+        return torch.empty(shape, dtype=dtype).bernoulli_(p)
+    raise ValueError(kind)
+
+
+def host_draw(kind, shape, device, p=0.0, dtype=torch.float32):
+    """A draw from the default HOST generator ("randn" | "rand" | "bernoulli" with probability p), moved to `device`
+    - or, under an installed DrawTape, the static buffer that stands for it."""
+    if _TAPE is not None:
+        return _TAPE.draw(kind, shape, float(p), torch.device(device), dtype)
+    return to_device_async(_host_sample(kind, tuple(shape), float(p), dtype), device)
+
+
 def lengths_tensor(lengths, T, device):
     """None when every sequence is full length (the training case), else an int32 tensor."""
     if lengths is None:
@@ -185,7 +250,7 @@ class Dropout(nn.Dropout):
         if not self.training or self.p == 0.0:
             return x
         if self.host_rng:
-            keep = to_device_async(torch.empty(x.shape, dtype=x.dtype).bernoulli_(1.0 - self.p), x.device)
+            keep = host_draw("bernoulli", x.shape, x.device, 1.0 - self.p, x.dtype)
         else:
             keep = torch.empty_like(x).bernoulli_(1.0 - self.p)
         return x * keep * (1.0 / (1.0 - self.p))

@@ -10,7 +10,7 @@ import torch
 import torch.autograd as autograd
 
 from . import ops
-from .layers import to_device_async
+from .layers import host_draw, to_device_async  # noqa: F401
 
 
 def gradient_penalty(critic, bsize, real, fake, audio=None, is_seq=False, is_cond=False, lp=False, device=None,
@@ -28,7 +28,7 @@ def gradient_penalty(critic, bsize, real, fake, audio=None, is_seq=False, is_con
     real2d = real.reshape(real.size(0), -1)
     fake2d = fake.reshape(fake.size(0), -1)
     if alpha is None:
-        alpha = to_device_async(torch.rand(bsize, 1), real2d.device)
+        alpha = host_draw("rand", (bsize, 1), real2d.device)
     interpol = ops.gp_interpolate(real2d, fake2d, alpha.view(-1))
     interpol = interpol.view(interpol.size(0), 69, -1) if is_seq else interpol.view(interpol.size(0), 23, 3)
     interpol.requires_grad_(True)

@@ -154,3 +154,37 @@ def test_phase2_captured_graphs_equal_eager():
     (o0, g0, s0), (o1, g1, s1) = sigs
     for a, b in zip(sum(o0, []) + s0, sum(o1, []) + s1):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (a, b)
+
+
+@pytest.mark.gpu
+def test_phase1_captured_graphs_equal_eager():
+    """Phase1Engine.enable_graphs() (round 3): every host draw of a loop body - generator noise, interpolation weights,
+    the dropout masks of both networks - goes through a DrawTape and is made again, in the same order on the same
+    generator, before each replay; six loop bodies (one generator iteration) then leave the same losses and parameters
+    as the eager engine (BASELINE configs[0] shapes)."""
+    from music2dance_amd.engine import Phase1Engine
+    from music2dance_amd.phase1.archis.residual import Discriminator as D1, Generator as G1
+    dev = torch.device("cuda:0")
+    cfg = {"lr_gen": 1e-4, "lr_critic": 1e-4, "n_critic_steps": 5, "gamma": 10, "latent_vector_size": 10}
+    real = torch.rand(64, 23, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    sigs = []
+    for graphs in (False, True):
+        torch.manual_seed(0)
+        gen = G1(10, 128, 69, 1).to(dev)
+        critic = D1(69, 128, 1).to(dev)
+        eng = Phase1Engine(gen, critic, cfg, data_parallel=False)
+        if graphs:
+            eng.enable_graphs()
+        torch.manual_seed(21)
+        outs = []
+        for _ in range(6):
+            out = eng.train_step(real)
+            outs.append([float(out[k]) for k in ("loss_critic", "gp", "w_dist")])
+        eng.flush()
+        torch.cuda.synchronize()
+        sigs.append((outs, float(out["loss_gen"]) if "loss_gen" in out else None,
+                     [p.detach().double().sum().item() for p in list(critic.parameters()) + list(gen.parameters())]))
+    (o0, g0, s0), (o1, g1, s1) = sigs
+    assert g0 is None and g1 is None or abs(g0 - g1) <= 2e-5 * max(1.0, abs(g0))
+    for a, b in zip(sum(o0, []) + s0, sum(o1, []) + s1):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (a, b)
