@@ -483,6 +483,11 @@ class Phase2Engine(WganGpEngine):
         self._finish_critic_step()
         self.optim_critic.zero_grad(set_to_none=True)  # after the deferred step used the old gradients
         self._join_generator_forward(fake_rows)
+        return self._critic_from_fake(real, fake_rows, alpha)
+
+    def _critic_from_fake(self, real, fake_rows, alpha):
+        B = real.size(0)
+        T = real.numel() // (B * self.output_size)
         if self.manual_critic is not None:
             if alpha is None:
                 alpha = to_device_async(torch.rand(B, 1), real.device)  # host draw, as losses.py:15
@@ -539,9 +544,28 @@ class Phase2Engine(WganGpEngine):
         self._finish_critic_step()
         g = self._graph_for(real)
         B, T = g["noise_c"].shape[0], g["noise_c"].shape[1]
+        dev = real.device
+        # the critic iteration's generator forward is a graph of its own, replayed on the generator stream one
+        # iteration ahead (as the eager engine pipelines it): a single replay queue would put its 0.5 ms of recurrent
+        # launches in line with the critic (2.64 ms per body against 2.2 eager)
+        self._always_ready(dev)
+
+        def forward():
+            g["noise_c"].copy_(self._noise(B, T, dev))  # host draw where the eager path makes it
+            g["fwd"].replay()
+            return g["fake_out"]
+
+        out_rows = self._generator_forward_nograd(forward, (), dev)
+        pend, self._fake_pending = self._fake_pending, None
+        main = torch.cuda.current_stream(dev)
         g["real"].copy_(real.reshape(g["real"].shape))
-        g["noise_c"].copy_(self._noise(B, T, real.device))
-        g["alpha"].copy_(to_device_async(torch.rand(B, 1), real.device))
+        g["alpha"].copy_(to_device_async(torch.rand(B, 1), dev))
+        if pend is not None:
+            main.wait_event(pend[1])
+        g["fake_in"].copy_(out_rows)
+        if pend is not None:
+            # the next forward may overwrite its output only after this copy
+            self._main_mark = main.record_event()
         Phase3Engine._bind_grads(self.critic, g["critic_grads"])
         g["critic"].replay()
         self._begin_critic_step()
@@ -568,12 +592,18 @@ class Phase2Engine(WganGpEngine):
         B = real.size(0)
         T = real.numel() // (B * self.output_size)
         g = {"real": torch.empty_like(real).copy_(real), "noise_c": torch.zeros(B, T, self.input_size, device=dev),
-             "noise_g": torch.zeros(B, T, self.input_size, device=dev), "alpha": torch.full((B, 1), 0.5, device=dev)}
+             "noise_g": torch.zeros(B, T, self.input_size, device=dev), "alpha": torch.full((B, 1), 0.5, device=dev),
+             "fake_in": torch.zeros(B * T, self.output_size, device=dev)}
         K = kernels.impl()
 
+        def fwd_body():
+            with K.weight_cache(), torch.no_grad():
+                return self.gen(g["noise_c"], [T] * B)
+
         def critic_body():
+            self.optim_critic.zero_grad(set_to_none=True)
             with K.weight_cache():
-                return self._critic_body(g["real"], g["noise_c"], g["alpha"])
+                return self._critic_from_fake(g["real"], g["fake_in"], g["alpha"])
 
         def gen_body():
             with K.weight_cache():
@@ -587,12 +617,20 @@ class Phase2Engine(WganGpEngine):
         with torch.cuda.stream(side), contextlib.ExitStack() as es:
             for q in quiet:
                 es.enter_context(q)
+            fwd_body()
             critic_body()
             gen_body()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.optim_critic.zero_grad(set_to_none=True)
         self.optim_gen.zero_grad(set_to_none=True)
+        # the forward graph replays on the generator stream WHILE the critic graph of the previous body runs: it gets
+        # a memory pool of its own (graphs that share a pool reuse each other's freed intermediates, which is only
+        # safe when they never overlap - sharing one here let the critic overwrite the recurrent layers' outputs
+        # under the running GRU kernel, which then spun on its hand-off sentinel until the timeout)
+        g["fwd"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["fwd"]):
+            g["fake_out"] = fwd_body()
         g["critic"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["critic"]):
             g["critic_out"] = critic_body()
