@@ -436,6 +436,25 @@ def main():
                 # launches that move >= 64 MB (smaller ones are launch-bound, listed under "small")
                 "hbm": hbm,
             }
+            if args.phase == 3:
+                # what the part sustains under fp32 MFMA load, measured here and now: the engine on a plain 4096^3 GEMM
+                # (no gather, no tails, a balanced grid). fp32 MFMA is power-limited on this part - matrix-pipe busy x
+                # clock is ~1.6 GHz for every large launch (profiles/*_pmc_shapes.json) - so this, not the nominal
+                # 157.3, is the ceiling a perfectly fed kernel reaches; `frac` above stays priced against the nominal peak
+                n = 4096
+                ga, gb = torch.randn(n, n, device=device), torch.randn(n, n, device=device)
+                K.gemm(1, ga, gb)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    K.gemm(1, ga, gb)
+                e1.record()
+                torch.cuda.synchronize()
+                plain = 10 * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+                out["roofline"]["plain_gemm_4096_tflops"] = round(plain, 1)
+                out["roofline"]["frac_of_plain_gemm"] = round(ach / plain, 4)
+                del ga, gb
             # the reference's own formulation executes REF_GFLOP_PER_SEQ_CYCLE per sequence consumed (SURVEY.md
             # 8(d), per workload); the engine skips work the reference discards, so this is an equivalent-work
             # rate over whole cycles, not a kernel rate
