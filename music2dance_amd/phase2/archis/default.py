@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...layers import GRU, BatchNorm1d, Conv1d, Linear, lengths_tensor
+from ...layers import GRU, BatchNorm1d, Conv1d, Linear, batched_bn_counters, lengths_tensor
 from ...utils import initialize_weights
 
 
@@ -100,9 +100,10 @@ class SequenceGenerator(nn.Module):
 
     def forward(self, x, lengths):
         ls = _check_sorted(lengths)
-        h = self.noise_gen(x, lengths_tensor(ls, x.size(1), x.device))
-        h = h[:, :max(ls)]
-        return self.decoder(h.reshape(-1, self.decoder.latent_size))
+        with batched_bn_counters(self):  # one fused add for the decoder's BatchNorm step counters
+            h = self.noise_gen(x, lengths_tensor(ls, x.size(1), x.device))
+            h = h[:, :max(ls)]
+            return self.decoder(h.reshape(-1, self.decoder.latent_size))
 
 
 class SequenceDiscriminator(nn.Module):
