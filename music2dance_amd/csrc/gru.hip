@@ -545,29 +545,39 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GruStackFwdArgs& a = pa.s;
   const int H = a.H, T = a.T;
-  float* wh = lds;                       // [H][48]: column g * 16 + c = gate g, unit u0 + c
-  float* wi = wh + (size_t)H * 48;       // [H][48] (layers >= 1)
-  float (*red)[4][256] = reinterpret_cast<float (*)[4][256]>(wi + (size_t)H * 48);
-  __shared__ int dead;
+  float (*red)[4][256] = reinterpret_cast<float (*)[4][256]>(lds);
   const int l = blockIdx.z, bt = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * 16, b0 = bt * 16;
   const bool use_i = l > 0;
-  if (tid == 0) dead = 0;
-  // weight slices -> LDS (once)
-  for (int e = tid; e < H * 48; e += 64 * NW) {
-    const int k = e / 48, c = e - k * 48;
-    const int g = c >> 4, u = u0 + (c & 15);
-    const size_t src = (size_t)k * 3 * H + (size_t)g * H + u;
-    wh[e] = u < H ? a.w_hh_t[l][src] : 0.f;
-    wi[e] = (use_i && u < H) ? a.w_ih_t[l][src] : 0.f;
-  }
-  __syncthreads();
   const int arow = b0 + (lane & 15);
   const bool rok = arow < a.B;
   const int nblk = (H + 15) / 16;
   const int q = lane >> 4;
   const bool vec = (H & 3) == 0;
+  // The weight slices live in REGISTERS for all T steps: a lane's MFMA B operands are W^T[k][gate g, unit u0 + (lane & 15)]
+  // for its 2 blocks x 4 k's x 3 gates - 24 floats per contraction, 48 with the input part. (Rounds 2-3 kept the slices
+  // in LDS, 92 KB at H = 240: three LDS reads in front of every MFMA triple on the step's critical path, and a footprint
+  // that kept the workgroup off any CU still holding two GEMM workgroups. LDS is now the 32 KB cross-wave sum only.)
+  float bwh[GRU_FWD_MAXB][4][3], bwi[GRU_FWD_MAXB][4][3];
+  {
+    const int ucol = u0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < GRU_FWD_MAXB; ++i) {
+      const int j = wave + NW * i;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int k = 16 * j + 4 * q + m;
+        const bool ok = j < nblk && k < H && ucol < H;
+        const size_t src = (size_t)(ok ? k : 0) * 3 * H + (ok ? ucol : 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          bwh[i][m][g] = ok ? a.w_hh_t[l][src + (size_t)g * H] : 0.f;
+          bwi[i][m][g] = (ok && use_i) ? a.w_ih_t[l][src + (size_t)g * H] : 0.f;
+        }
+      }
+    }
+  }
   const unsigned obytes = (unsigned)((size_t)a.B * T * H * sizeof(float));  // < 2^31: checked by the launcher
   const __amdgpu_buffer_rsrc_t own_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.out[l], (short)0, (int)obytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t low_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.out[use_i ? l - 1 : l], (short)0, (int)obytes, 0x00020000);
@@ -614,12 +624,9 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
           const int k0 = 16 * j + 4 * q;
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            const bool kok = k0 + m < H;
-            const float* wr = wi + (size_t)(kok ? k0 + m : 0) * 48 + (lane & 15);
-            const float b0v = kok ? wr[0] : 0.f, b1v = kok ? wr[16] : 0.f, b2v = kok ? wr[32] : 0.f;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], b0v, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], b1v, acc[1], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], b2v, acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], bwi[i][m][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], bwi[i][m][1], acc[1], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i][m], bwi[i][m][2], acc[3], 0, 0, 0);
           }
         }
       }
@@ -632,12 +639,9 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
           const int k0 = 16 * j + 4 * q;
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            const bool kok = k0 + m < H;
-            const float* wr = wh + (size_t)(kok ? k0 + m : 0) * 48 + (lane & 15);
-            const float b0v = kok ? wr[0] : 0.f, b1v = kok ? wr[16] : 0.f, b2v = kok ? wr[32] : 0.f;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], b0v, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], b1v, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], b2v, acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], bwh[i][m][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], bwh[i][m][1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][m], bwh[i][m][2], acc[2], 0, 0, 0);
           }
         }
       }
@@ -793,8 +797,9 @@ struct GruPersistBwdArgs {
 // the wave's (at most 6 at H = 240) blocks are issued before the first MFMA.
 #define GRU_BWD_MAXB 6  // blocks per wave: covers K = 3H <= 16 * 8 * 6 = 768 (H <= 256)
 template <int NW>
-__device__ __forceinline__ void gru_bwd_contract(const float* base, size_t row_off, bool rok, const float* wl, int K,
-                                                 int wave, int lane, bool vec, __amdgpu_buffer_rsrc_t rs, f32x4& acc) {
+__device__ __forceinline__ void gru_bwd_contract(const float* base, size_t row_off, bool rok,
+                                                 const float (&bw)[GRU_BWD_MAXB][4], int K, int wave, int lane, bool vec,
+                                                 __amdgpu_buffer_rsrc_t rs, f32x4& acc) {
   const int nblk = (K + 15) / 16;
   const int q = lane >> 4;
   float av[GRU_BWD_MAXB][4];
@@ -821,10 +826,7 @@ __device__ __forceinline__ void gru_bwd_contract(const float* base, size_t row_o
     if (j < nblk) {
       const int k0 = 16 * j + 4 * q;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const float bv = (k0 + m < K) ? wl[(size_t)(k0 + m) * 16 + (lane & 15)] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][m], bv, acc, 0, 0, 0);
-      }
+      for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][m], bw[i][m], acc, 0, 0, 0);
     }
   }
 }
@@ -839,21 +841,31 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
   const __amdgpu_buffer_rsrc_t gh_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dgh[blockIdx.z], (short)0, (int)gbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t gi_rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.dgi[(int)blockIdx.z + 1 < a.L ? blockIdx.z + 1 : blockIdx.z], (short)0, (int)gbytes, 0x00020000);
-  float* whh = lds;                        // [3H][16]: W_hh_l[k][u0 + c]
-  float* wih = whh + (size_t)K * 16;       // [3H][16]: W_ih_{l+1}[k][u0 + c]
-  float (*red)[256] = reinterpret_cast<float (*)[256]>(wih + (size_t)K * 16);
+  float (*red)[256] = reinterpret_cast<float (*)[256]>(lds);
   __shared__ int go;
   const int l = blockIdx.z, bt = blockIdx.y;
   const int nth = gridDim.x, nbt = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * 16, b0 = bt * 16;
   const bool has_up = (l + 1) < a.L;
-  for (int e = tid; e < K * 16; e += 64 * NW) {
-    const int k = e >> 4, u = u0 + (e & 15);
-    whh[e] = u < H ? a.w_hh[l][(size_t)k * H + u] : 0.f;
-    wih[e] = (has_up && u < H) ? a.w_ih[l + 1][(size_t)k * H + u] : 0.f;
+  // the weight slices (W_hh_l[k][u0 + c], W_ih_{l+1}[k][u0 + c]: a lane's MFMA B operands for its 6 blocks x 4 k's) live
+  // in registers for all T steps, as in the forward kernel: no LDS read in front of the MFMAs, LDS = the 8 KB sum
+  float bwhh[GRU_BWD_MAXB][4], bwih[GRU_BWD_MAXB][4];
+  {
+    const int ucol = u0 + (lane & 15);
+    const int nblk = (K + 15) / 16;
+#pragma unroll
+    for (int i = 0; i < GRU_BWD_MAXB; ++i) {
+      const int j = wave + NW * i;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int k = 16 * j + 4 * (lane >> 4) + m;
+        const bool ok = j < nblk && k < K && ucol < H;
+        bwhh[i][m] = ok ? a.w_hh[l][(size_t)k * H + ucol] : 0.f;
+        bwih[i][m] = (ok && has_up) ? a.w_ih[l + 1][(size_t)k * H + ucol] : 0.f;
+      }
+    }
   }
-  __syncthreads();
   const int arow = b0 + (lane & 15);
   const bool rok = arow < a.B;
   const int row = (tid & 255) >> 4, col = tid & 15;
@@ -882,7 +894,7 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
       if (tid == 0) go = gru_wait_ge(up_cnt, (unsigned)nth * (unsigned)(T - t), pa.error, pa.spin_limit) ? 1 : 0;
       __syncthreads();
       if (!go) return;
-      gru_bwd_contract<NW>(a.dgi[l + 1], ((size_t)arow * T + t) * K, rok, wih, K, wave, lane, vec, gi_rs, acc);
+      gru_bwd_contract<NW>(a.dgi[l + 1], ((size_t)arow * T + t) * K, rok, bwih, K, wave, lane, vec, gi_rs, acc);
     }
     // ---- next part: step t+1 of every hidden tile of this layer
     if (has_next) {
@@ -892,7 +904,7 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
         __syncthreads();
         if (!go) return;
       }
-      gru_bwd_contract<NW>(a.dgh[l], ((size_t)arow * T + (t + 1)) * K, rok, whh, K, wave, lane, vec, gh_rs, acc);
+      gru_bwd_contract<NW>(a.dgh[l], ((size_t)arow * T + (t + 1)) * K, rok, bwhh, K, wave, lane, vec, gh_rs, acc);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) red[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
@@ -969,8 +981,8 @@ static GruPersistState* gru_persist_state() {
   return ps.usable ? &ps : nullptr;
 }
 
-static size_t gru_persist_lds(int H) { return ((size_t)2 * H * 48 + (size_t)GRU_FWD_NW * 4 * 256) * sizeof(float); }
-static size_t gru_persist_bwd_lds(int H) { return ((size_t)2 * 3 * H * 16 + (size_t)GRU_BWD_NW * 256) * sizeof(float); }
+static size_t gru_persist_lds(int H) { (void)H; return (size_t)GRU_FWD_NW * 4 * 256 * sizeof(float); }  // the cross-wave sum only
+static size_t gru_persist_bwd_lds(int H) { (void)H; return (size_t)GRU_BWD_NW * 256 * sizeof(float); }  // the cross-wave sum only
 
 // every workgroup must be resident at once: one per CU (the LDS footprint allows no second one)
 static bool gru_persist_ok(dim3 grid, int H, int T, bool backward = false) {
