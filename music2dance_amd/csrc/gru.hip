@@ -984,17 +984,18 @@ static GruPersistState* gru_persist_state() {
 static size_t gru_persist_lds(int H) { (void)H; return (size_t)GRU_FWD_NW * 4 * 256 * sizeof(float); }  // the cross-wave sum only
 static size_t gru_persist_bwd_lds(int H) { (void)H; return (size_t)GRU_BWD_NW * 256 * sizeof(float); }  // the cross-wave sum only
 
-// every workgroup must be resident at once: one per CU (the LDS footprint allows no second one)
+// every workgroup must be resident at once. ONE per CU: a workgroup is 8 waves of 131-174 VGPRs (the weight slices
+// live in registers), i.e. two waves per SIMD, and a second workgroup's waves do not fit beside them - the LDS
+// footprint (32 KB / 8 KB) no longer says so by itself.
 static bool gru_persist_ok(dim3 grid, int H, int T, bool backward = false) {
   if (H > 256 || T < 4) return false;
   GruPersistState* ps = gru_persist_state();
   if (!ps) return false;
   const size_t lds = backward ? gru_persist_bwd_lds(H) : gru_persist_lds(H);
-  if (lds > 140 * 1024 || (int)lds > ps->max_lds) return false;
-  const int per_cu = lds > 0 ? (int)((size_t)ps->max_lds / lds) : 1;
+  if ((int)lds > ps->max_lds) return false;
   const long long blocks = (long long)grid.x * grid.y * grid.z;
   // leave a margin: other streams' kernels (the noise GRU) need a place to run too
-  return blocks <= (long long)ps->cus * (per_cu > 0 ? per_cu : 1) * 3 / 4;
+  return blocks <= (long long)ps->cus * 3 / 4;
 }
 
 extern "C" {
