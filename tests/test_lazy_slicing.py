@@ -48,3 +48,46 @@ def test_generator_reads_windows_in_place(enc):
     assert len(grads[0]) == len(grads[1])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_draw_tape_replays_the_eager_host_draws_in_order():
+    """layers.DrawTape (captured-graph mode of Phase1Engine): a body that draws noise, interpolation weights and a
+    dropout mask from the host generator gets static buffers while the tape is installed; refill() then consumes the
+    generator exactly as the eager body does - same values, same order - and a body that changes its draws is refused."""
+    import torch
+    from music2dance_amd import layers
+    dev = torch.device("cpu")
+
+    def body():
+        a = layers.host_draw("randn", (4, 3), dev)
+        b = layers.host_draw("rand", (4, 1), dev)
+        c = layers.host_draw("bernoulli", (4, 5), dev, p=0.5)
+        return a, b, c
+
+    torch.manual_seed(5)
+    eager = [t.clone() for t in body()] + [t.clone() for t in body()]  # two consecutive bodies
+    tape = layers.DrawTape()
+    with layers.draw_tape(tape):
+        bufs = body()            # records; the buffers hold zeros
+        tape.rewind()
+        again = body()           # the capture pass gets the same buffers back
+    assert all(x is y for x, y in zip(bufs, again)) and len(tape.entries) == 3
+    assert all(float(t.abs().sum()) == 0.0 for t in bufs)
+    torch.manual_seed(5)
+    tape.refill()
+    first = [t.clone() for t in bufs]
+    tape.refill()
+    second = [t.clone() for t in bufs]
+    for got, want in zip(first + second, eager):
+        assert torch.equal(got, want)
+    # outside the tape the draws are ordinary host draws again
+    torch.manual_seed(5)
+    assert torch.equal(layers.host_draw("randn", (4, 3), dev), eager[0])
+    # a body that draws something else than it recorded is an error, not a silent mismatch
+    tape.rewind()
+    with layers.draw_tape(tape):
+        try:
+            layers.host_draw("rand", (4, 3), dev)
+            raise AssertionError("expected a RuntimeError")
+        except RuntimeError:
+            pass

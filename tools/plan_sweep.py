@@ -22,6 +22,7 @@ CASES = [("temporal.k7 B32", 32, 128, 120, 128, 7, 1, 3), ("temporal.k7 B64", 64
          ("stick.conv1 B64", 64, 69, 120, 128, 25, 1, 12),
          ("audio_d.l2", B, 32, 19200, 64, 25, 4, 11), ("audio_d.l3", B, 64, 4800, 128, 25, 4, 11),
          ("audio_d.l4", B, 128, 1200, 256, 25, 4, 11), ("audio_d.l5", B, 256, 300, 512, 25, 4, 11),
+         ("wavegan.l4", 3840, 128, 43, 256, 25, 4, 0), ("wavegan.l3", 3840, 64, 193, 128, 25, 4, 0),
          ("enc.c1", N, 32, 64, 64, 4, 2, 1), ("enc.c2", N, 64, 32, 128, 4, 2, 1), ("enc.c3", N, 128, 16, 256, 4, 2, 1),
          ("enc.c5", N, 512, 4, 1024, 4, 2, 1), ("enc.c6", N, 1024, 2, 250, 2, 1, 0)]
 PLANS = [None, (128, 1), (64, 1), (32, 1), (128, 2), (64, 2), (32, 2), (128, 4), (64, 4), (32, 4), (128, 8), (64, 8), (128, 16), (64, 16), (128, 32), (64, 32), (128, 64), (64, 64)]
