@@ -1355,11 +1355,18 @@ static bool dl_enabled() {
   return on;
 }
 
+// THE gate of the LDS-direct kernel: TileMap::load_lds implements row-fast operands with the one-level row / k maps
+// only - no operand mask, no bias ("ones") row, no window views (rdiv2 / kdiv2). A new operand feature must be refused
+// here (or taught to load_lds) before it can reach m2d_gemm_dl_kernel.
+static inline bool dl_eligible(const M2dGemmParams& p, bool akf, bool bkf) {
+  return !akf && !bkf && !p.A.mask && !p.B.mask && !p.A.ones_row_p1 && !p.B.ones_row_p1 && p.A.rdiv2 <= 0 &&
+         p.B.rdiv2 <= 0 && p.A.kdiv2 <= 0 && p.B.kdiv2 <= 0;
+}
+
 template <int BM>
 static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hipStream_t stream) {
   {
-    if (!akf && !bkf && dl_enabled() && !p.A.mask && !p.B.mask && !p.A.ones_row_p1 && !p.B.ones_row_p1 &&
-        p.A.rdiv2 <= 0 && p.B.rdiv2 <= 0 && p.A.kdiv2 <= 0 && p.B.kdiv2 <= 0) {
+    if (dl_enabled() && dl_eligible(p, akf, bkf)) {
       if (p.O.wide) hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 1>), grid, dim3(256), 0, stream, p);
       else if (p.O.quad && p.splits <= 1) hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 2>), grid, dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 0>), grid, dim3(256), 0, stream, p);
