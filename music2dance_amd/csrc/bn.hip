@@ -316,11 +316,41 @@ struct BnApplyArgs {
   float slope;
 };
 
+// A thread owns ONE vector position of the (C, L) row and walks the batch: its channel(s) - one when L % 4 == 0, four
+// consecutive ones when L == 1 - and their parameters are fixed for the whole launch (registers), so the loop body is
+// load / FMA / store. (Rounds 1-2 walked a flat index: a 64-bit modulo and up to four divmods + sixteen parameter loads
+// per 16-byte vector - 4.5 TB/s. Rows shorter than 256 vectors put several rows in a block.)
 template <int VEC>
-__global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, size_t total_vec) {
-  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total_vec; v += (size_t)gridDim.x * 256) {
-    const size_t idx = v * VEC;
-    const int p = (int)(idx % (size_t)a.row_len);
+__global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, int B) {
+  const int rvl = a.row_len / VEC;  // vectors per row
+  const int tid = threadIdx.x;
+  int pv, r0, rstep;
+  if (rvl >= 256) {
+    pv = blockIdx.x * 256 + tid;
+    if (pv >= rvl) return;
+    r0 = blockIdx.y;
+    rstep = gridDim.y;
+  } else {
+    const int rpb = 256 / rvl;
+    pv = tid % rvl;
+    const int rib = tid / rvl;
+    if (rib >= rpb) return;
+    r0 = blockIdx.y * rpb + rib;
+    rstep = gridDim.y * rpb;
+  }
+  const int e0 = pv * VEC;
+  const bool percol = a.L == 1;  // the VEC elements are VEC consecutive channels (else one channel)
+  float g[VEC], bt[VEC], mu[VEC], is[VEC], sdz[VEC], sdzx[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = percol ? e0 + j : e0 / a.L;
+    g[j] = a.gamma[c]; bt[j] = a.beta[c]; mu[j] = a.mean[c]; is[j] = a.invstd[c];
+    sdz[j] = a.backward ? a.s_dz[c] : 0.f;
+    sdzx[j] = a.backward ? a.s_dzx[c] : 0.f;
+  }
+#pragma unroll 2
+  for (int r = r0; r < B; r += rstep) {
+    const size_t idx = (size_t)r * a.row_len + e0;
     float xv[VEC], dv[VEC], rv[VEC], ov[VEC];
     if constexpr (VEC == 4) {
       const float4 t = *reinterpret_cast<const float4*>(a.x + idx);
@@ -330,8 +360,8 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
         dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
       }
       if (a.residual) {
-        const float4 r = *reinterpret_cast<const float4*>(a.residual + idx);
-        rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
+        const float4 q = *reinterpret_cast<const float4*>(a.residual + idx);
+        rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
       }
     } else {
       xv[0] = a.x[idx];
@@ -340,12 +370,8 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      int c, l;
-      if (a.L == 1) c = p + j;
-      else bn_divmod(p + j, a.L, a.L_inv, c, l);
-      const float g = a.gamma[c], bt = a.beta[c], mu = a.mean[c], is = a.invstd[c];
-      const float xh = (xv[j] - mu) * is;
-      const float z = g * xh + bt;
+      const float xh = (xv[j] - mu[j]) * is[j];
+      const float z = g[j] * xh + bt[j];
       if (!a.backward) {
         float y = z;
         if (a.act == 1) y = z > 0.f ? z : 0.f;
@@ -355,7 +381,7 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
       } else {
         float dz = dv[j];
         if (a.act && !(z > 0.f)) dz = a.act == 1 ? 0.f : dz * a.slope;
-        ov[j] = g * is * (dz - a.s_dz[c] - xh * a.s_dzx[c]);
+        ov[j] = g[j] * is[j] * (dz - sdz[j] - xh * sdzx[j]);
       }
     }
     if constexpr (VEC == 4) {
@@ -367,14 +393,23 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
 }
 
 static int launch_apply(BnApplyArgs& a, int B, hipStream_t stream) {
-  const size_t total = (size_t)B * a.row_len;
   const bool vec4 = (a.row_len % 4 == 0) && (a.L == 1 || a.L % 4 == 0);
-  const size_t total_vec = vec4 ? total / 4 : total;
-  size_t blocks = (total_vec + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
-  if (vec4) hipLaunchKernelGGL(m2d_bn_apply_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a, total_vec);
-  else hipLaunchKernelGGL(m2d_bn_apply_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, total_vec);
+  const int rvl = vec4 ? a.row_len / 4 : a.row_len;
+  unsigned gx, gy;
+  if (rvl >= 256) {
+    gx = (unsigned)m2d_ceil_div(rvl, 256);
+    gy = 4096u / gx;
+    if (gy < 1) gy = 1;
+    if (gy > (unsigned)B) gy = (unsigned)B;
+  } else {
+    const int rpb = 256 / rvl;
+    gx = 1;
+    gy = (unsigned)m2d_ceil_div(B, rpb);
+    if (gy > 4096u) gy = 4096u;
+  }
+  if (gy > 65535u) gy = 65535u;
+  if (vec4) hipLaunchKernelGGL(m2d_bn_apply_kernel<4>, dim3(gx, gy), dim3(256), 0, stream, a, B);
+  else hipLaunchKernelGGL(m2d_bn_apply_kernel<1>, dim3(gx, gy), dim3(256), 0, stream, a, B);
   M2D_CHECK_LAUNCH("m2d_bn_apply_kernel");
   return M2D_OK;
 }
