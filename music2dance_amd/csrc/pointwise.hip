@@ -313,6 +313,37 @@ __global__ void __launch_bounds__(256) m2d_maxpool2_fwd_kernel(const float* x, f
   }
 }
 
+// L even: rows do not matter - y[i] = max(x[2i], x[2i+1]) over the flat tensor, four outputs (32 B in, 16 B out) per
+// thread and step, no index arithmetic (the row form above does a 64-bit division per output: 5.3 -> 6+ TB/s)
+__global__ void __launch_bounds__(256) m2d_maxpool2_fwd_flat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    size_t nvec) {
+#pragma unroll 2
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(x + 8 * v);
+    const float4 b = *reinterpret_cast<const float4*>(x + 8 * v + 4);
+    float4 o;
+    o.x = a.x > a.y ? a.x : a.y;
+    o.y = a.z > a.w ? a.z : a.w;
+    o.z = b.x > b.y ? b.x : b.y;
+    o.w = b.z > b.w ? b.z : b.w;
+    *reinterpret_cast<float4*>(y + 4 * v) = o;
+  }
+}
+
+// the same for the gradient: dx[2i], dx[2i+1] from (x[2i], x[2i+1], dy[i])
+__global__ void __launch_bounds__(256) m2d_maxpool2_bwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    float* __restrict__ dx, size_t nvec) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(x + 8 * v);
+    const float4 b = *reinterpret_cast<const float4*>(x + 8 * v + 4);
+    const float4 g = *reinterpret_cast<const float4*>(dy + 4 * v);
+    const bool f0 = a.x >= a.y || a.x != a.x, f1 = a.z >= a.w || a.z != a.z;
+    const bool f2 = b.x >= b.y || b.x != b.x, f3 = b.z >= b.w || b.z != b.z;
+    *reinterpret_cast<float4*>(dx + 8 * v) = make_float4(f0 ? g.x : 0.f, f0 ? 0.f : g.x, f1 ? g.y : 0.f, f1 ? 0.f : g.y);
+    *reinterpret_cast<float4*>(dx + 8 * v + 4) = make_float4(f2 ? g.z : 0.f, f2 ? 0.f : g.z, f3 ? g.w : 0.f, f3 ? 0.f : g.w);
+  }
+}
+
 // gradient goes to the arg-max (first element on ties, like torch); other positions 0
 __global__ void __launch_bounds__(256) m2d_maxpool2_bwd_kernel(const float* x, const float* dy, float* dx,
                                                                size_t rows, int L, int Lout) {
@@ -346,6 +377,59 @@ __global__ void __launch_bounds__(256) m2d_upsample2_fwd_kernel(const float* x, 
     const float w1 = src - (float)i0;
     const float w0 = 1.0f - w1;
     y[i] = w0 * x[r * L + i0] + w1 * x[r * L + i1];
+  }
+}
+
+// L % 4 == 0: a thread owns four input positions of a row (one 16-byte load + the two neighbours) and writes their
+// eight outputs (two 16-byte stores), walking the rows with a fixed position - no division per element. Same
+// expression per output as the kernel above (w0 * x[i0] + w1 * x[i1] with w in {1, 0.75, 0.25, 0}): same bits.
+__global__ void __launch_bounds__(256) m2d_upsample2_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    size_t rows, int L) {
+  const int rvl = L >> 2;  // vectors per row (<= 256: launcher-checked)
+  const int rpb = 256 / rvl;
+  const int pv = threadIdx.x % rvl, rib = threadIdx.x / rvl;
+  if (rib >= rpb) return;
+  const int p0 = 4 * pv;
+#pragma unroll 4
+  for (size_t r = (size_t)blockIdx.x * rpb + rib; r < rows; r += (size_t)gridDim.x * rpb) {
+    const float* xr = x + r * L;
+    const float4 c = *reinterpret_cast<const float4*>(xr + p0);
+    const float lft = p0 > 0 ? xr[p0 - 1] : 0.f;
+    const float rgt = p0 + 4 < L ? xr[p0 + 4] : c.w;  // i1 = min(i0 + 1, L - 1)
+    float o[8];
+    // even outputs j = 2p: p = 0 -> src clamps to 0: 1 * x[0] + 0 * x[min(1, L-1)]; p >= 1 -> 0.25 * x[p-1] + 0.75 * x[p]
+    o[0] = p0 > 0 ? 0.25f * lft + 0.75f * c.x : 1.0f * c.x + 0.0f * (L > 1 ? c.y : c.x);
+    o[2] = 0.25f * c.x + 0.75f * c.y;
+    o[4] = 0.25f * c.y + 0.75f * c.z;
+    o[6] = 0.25f * c.z + 0.75f * c.w;
+    // odd outputs j = 2p + 1: 0.75 * x[p] + 0.25 * x[min(p + 1, L - 1)]
+    o[1] = 0.75f * c.x + 0.25f * c.y;
+    o[3] = 0.75f * c.y + 0.25f * c.z;
+    o[5] = 0.75f * c.z + 0.25f * c.w;
+    o[7] = 0.75f * c.w + 0.25f * rgt;
+    float* yr = y + r * 2 * L + 2 * p0;
+    *reinterpret_cast<float4*>(yr) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(yr + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
+// any L <= 256: a thread owns ONE input position of a row (three scalar loads from the same lines) and writes its two
+// outputs as one 8-byte store, walking the rows with a fixed position. Same expressions: same bits.
+__global__ void __launch_bounds__(256) m2d_upsample2_fwd_row_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    size_t rows, int L) {
+  const int rpb = 256 / L;
+  const int p = threadIdx.x % L, rib = threadIdx.x / L;
+  if (rib >= rpb) return;
+#pragma unroll 4
+  for (size_t r = (size_t)blockIdx.x * rpb + rib; r < rows; r += (size_t)gridDim.x * rpb) {
+    const float* xr = x + r * L;
+    const float c = xr[p];
+    const float lft = p > 0 ? xr[p - 1] : 0.f;
+    const float rgt = p + 1 < L ? xr[p + 1] : c;
+    float2 o;
+    o.x = p > 0 ? 0.25f * lft + 0.75f * c : 1.0f * c + 0.0f * rgt;
+    o.y = 0.75f * c + 0.25f * rgt;
+    *reinterpret_cast<float2*>(y + r * 2 * L + 2 * p) = o;
   }
 }
 
@@ -560,7 +644,11 @@ int m2d_maxpool2_fwd(const float* x, float* y, size_t rows, int L, void* stream_
   const int Lout = L / 2;
   if (rows == 0 || Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_maxpool2_fwd: bad shape");
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 6.0 * rows * (double)L, "maxpool2_fwd");
-  hipLaunchKernelGGL(m2d_maxpool2_fwd_kernel, dim3(grid_for(rows * Lout, 4096)), dim3(256), 0, stream, x, y, rows, L, Lout);
+  if (L == 2 * Lout && (rows * Lout) % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0)
+    hipLaunchKernelGGL(m2d_maxpool2_fwd_flat_kernel, dim3(grid_for(rows * Lout / 4, 4096)), dim3(256), 0, stream, x, y,
+                       rows * Lout / 4);
+  else
+    hipLaunchKernelGGL(m2d_maxpool2_fwd_kernel, dim3(grid_for(rows * Lout, 4096)), dim3(256), 0, stream, x, y, rows, L, Lout);
   M2D_CHECK_LAUNCH("m2d_maxpool2_fwd");
   return M2D_OK;
 }
@@ -570,7 +658,11 @@ int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, in
   const int Lout = L / 2;
   if (rows == 0 || Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_maxpool2_bwd: bad shape");
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 10.0 * rows * (double)L, "maxpool2_bwd");
-  hipLaunchKernelGGL(m2d_maxpool2_bwd_kernel, dim3(grid_for(rows * L, 4096)), dim3(256), 0, stream, x, dy, dx, rows, L, Lout);
+  if (L == 2 * Lout && (rows * Lout) % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15u) == 0)
+    hipLaunchKernelGGL(m2d_maxpool2_bwd_flat_kernel, dim3(grid_for(rows * Lout / 4, 4096)), dim3(256), 0, stream, x, dy, dx,
+                       rows * Lout / 4);
+  else
+    hipLaunchKernelGGL(m2d_maxpool2_bwd_kernel, dim3(grid_for(rows * L, 4096)), dim3(256), 0, stream, x, dy, dx, rows, L, Lout);
   M2D_CHECK_LAUNCH("m2d_maxpool2_bwd");
   return M2D_OK;
 }
@@ -580,7 +672,17 @@ int m2d_upsample2_fwd(const float* x, float* y, size_t rows, int L, void* stream
   hipStream_t stream = (hipStream_t)stream_;
   if (rows == 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_fwd: bad shape");
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L, "upsample2_fwd");
-  hipLaunchKernelGGL(m2d_upsample2_fwd_kernel, dim3(grid_for(rows * 2 * L, 4096)), dim3(256), 0, stream, x, y, rows, L);
+  if ((L & 3) == 0 && L <= 1024 && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0) {
+    const size_t rpb = 256 / (L >> 2);
+    hipLaunchKernelGGL(m2d_upsample2_fwd_vec_kernel, dim3(grid_for((rows + rpb - 1) / rpb * 256, 4096)), dim3(256), 0, stream,
+                       x, y, rows, L);
+  } else if (L <= 256 && ((uintptr_t)y & 7u) == 0) {
+    const size_t rpb = 256 / L;
+    hipLaunchKernelGGL(m2d_upsample2_fwd_row_kernel, dim3(grid_for((rows + rpb - 1) / rpb * 256, 8192)), dim3(256), 0, stream,
+                       x, y, rows, L);
+  } else {
+    hipLaunchKernelGGL(m2d_upsample2_fwd_kernel, dim3(grid_for(rows * 2 * L, 4096)), dim3(256), 0, stream, x, y, rows, L);
+  }
   M2D_CHECK_LAUNCH("m2d_upsample2_fwd");
   return M2D_OK;
 }
