@@ -365,6 +365,17 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
         const float4 q = *reinterpret_cast<const float4*>(a.residual + idx);
         rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
       }
+    } else if constexpr (VEC == 2) {
+      const float2 t = *reinterpret_cast<const float2*>(a.x + idx);
+      xv[0] = t.x; xv[1] = t.y;
+      if (a.backward) {
+        const float2 d = *reinterpret_cast<const float2*>(a.dy + idx);
+        dv[0] = d.x; dv[1] = d.y;
+      }
+      if (a.residual) {
+        const float2 q = *reinterpret_cast<const float2*>(a.residual + idx);
+        rv[0] = q.x; rv[1] = q.y;
+      }
     } else {
       xv[0] = a.x[idx];
       if (a.backward) dv[0] = a.dy[idx];
@@ -388,6 +399,8 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
     }
     if constexpr (VEC == 4) {
       *reinterpret_cast<float4*>(a.out + idx) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    } else if constexpr (VEC == 2) {
+      *reinterpret_cast<float2*>(a.out + idx) = make_float2(ov[0], ov[1]);
     } else {
       a.out[idx] = ov[0];
     }
@@ -396,7 +409,8 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
 
 static int launch_apply(BnApplyArgs& a, int B, hipStream_t stream) {
   const bool vec4 = (a.row_len % 4 == 0) && (a.L == 1 || a.L % 4 == 0);
-  const int rvl = vec4 ? a.row_len / 4 : a.row_len;
+  const bool vec2 = !vec4 && (a.row_len % 2 == 0) && (a.L == 1 || a.L % 2 == 0);  // e.g. the WaveGAN encoder's L = 794
+  const int rvl = vec4 ? a.row_len / 4 : vec2 ? a.row_len / 2 : a.row_len;
   unsigned gx, gy;
   if (rvl >= 256) {
     gx = (unsigned)m2d_ceil_div(rvl, 256);
@@ -411,6 +425,7 @@ static int launch_apply(BnApplyArgs& a, int B, hipStream_t stream) {
   }
   if (gy > 65535u) gy = 65535u;
   if (vec4) hipLaunchKernelGGL(m2d_bn_apply_kernel<4>, dim3(gx, gy), dim3(256), 0, stream, a, B);
+  else if (vec2) hipLaunchKernelGGL(m2d_bn_apply_kernel<2>, dim3(gx, gy), dim3(256), 0, stream, a, B);
   else hipLaunchKernelGGL(m2d_bn_apply_kernel<1>, dim3(gx, gy), dim3(256), 0, stream, a, B);
   M2D_CHECK_LAUNCH("m2d_bn_apply_kernel");
   return M2D_OK;
