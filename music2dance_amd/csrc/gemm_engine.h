@@ -157,6 +157,9 @@ struct M2dGemmParams {
   // > 0: the algorithmic FLOPs of the launch when the walked K holds structural zeros (phantom taps): what the
   // profiler reports instead of 2 M N K
   double work_flops;
+  // workgroup -> tile map, set by the launcher (m2d_tile_of in gemm_engine.hip): 0 = tile id = workgroup id (N fastest),
+  // 1 = XCD-aware grouped order (M2D_TILE_MAP=0 restores 0)
+  int tile_map;
 };
 
 struct M2dGemmPlan {

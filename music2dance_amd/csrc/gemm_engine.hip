@@ -12,6 +12,33 @@ __device__ __forceinline__ void m2d_divmod(int n, int d, float inv, int& q, int&
   r -= adj * d;
 }
 
+// Workgroup -> tile map (p.tile_map). The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each
+// with an L2 of its own, so with tile = workgroup id (N fastest) the tiles resident on one XCD are ~96 different N
+// tiles of ONE M tile: every XCD streams its own copy of that A panel AND a disjoint eighth of B, and an M tile's B
+// panel is fetched again for the next M tile thousands of workgroups later. tile_map = 1: workgroups with equal
+// id % 8 (they share an XCD: a label, not the XCD's number) take a CONTIGUOUS range of a grouped tile order - groups of
+// up to 8 M tiles x all N tiles, M fastest - so the tiles an XCD holds at one time are all M tiles of a few neighbouring
+// N tiles (convs: every output-channel tile of the same positions reads the activation tile from that L2 once) or a
+// compact 8 x 12 patch of a large GEMM. A pure speed choice: any map is a bijection of the same tiles.
+__device__ __forceinline__ void m2d_tile_of(int tile_map, int& bx, int& by) {
+  bx = blockIdx.x;
+  by = blockIdx.y;
+  if (tile_map == 0) return;
+  const int nt = gridDim.x, mt = gridDim.y;
+  const int T = nt * mt, q = T >> 3, r = T & 7;
+  const int lin = by * nt + bx;
+  const int xcd = lin & 7, idx = lin >> 3;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int GM = 8;
+  const int per = GM * nt;
+  const int grp = id / per, rem = id - grp * per;
+  const int first = grp * GM;
+  const int gsz = mt - first < GM ? mt - first : GM;
+  const int nn = rem / gsz;
+  by = first + rem - nn * gsz;
+  bx = nn;
+}
+
 // Staging loads are raw buffer loads: an element that is padding, past a lo tail or past the
 // last row gets the byte offset M2D_OOB, which the hardware range check (num_records =
 // operand extent < 2^31) turns into 0.0f whatever scalar offset is added. No select on the
@@ -375,7 +402,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
           s2 += __shfl_xor(s2, off, 64);
         }
         if (l31 == 0 && rok) {
-          float* dst = O.row_part + ((size_t)(blockIdx.x * WN + wn) * p.M + row) * 2;
+          float* dst = O.row_part + ((size_t)((n0 / BN) * WN + wn) * p.M + row) * 2;
           dst[0] = s1;
           dst[1] = s2;
         }
@@ -483,7 +510,7 @@ __device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, c
             a2 += __shfl_xor(a2, off, 64);
           }
           if ((lane & 7) == 0 && row < p.M) {
-            float* dst = O.row_part + ((size_t)((blockIdx.x * WN + wn) * TN + j) * p.M + row) * 2;
+            float* dst = O.row_part + ((size_t)(((n0 / BN) * WN + wn) * TN + j) * p.M + row) * 2;
             dst[0] = a1;
             dst[1] = a2;
           }
@@ -589,6 +616,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   int N = p.N;
   int nhi = p.nhi;
   int split = blockIdx.z;
+  int bx, by;
+  m2d_tile_of(p.tile_map, bx, by);
   if (p.bwd_data) {
     // conv backward-data: output phase r of the stride-s lattice uses taps r, r+s, ...
     //   dx[n, ci, s*q + r - pad] = sum_{t, co} Wp[ci, r + s*t, co] * dy[n, co, q - t]
@@ -602,7 +631,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
     const int nq = top >= 0 ? (top / s - qmin + 1) : 0;
     if (nq <= 0) return;
     N = p.ph_batch * nq;
-    if ((int)(blockIdx.x * BN) >= N) return;
+    if ((int)(bx * BN) >= N) return;
     nhi = taps;
     A.r_off += r * (p.ph_a_step ? p.ph_a_step : p.ph_cout);
     B.nrows = N;
@@ -616,8 +645,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
     O.c_pos_off = O.c_off;
   }
 
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  const int m0 = by * BM;
+  const int n0 = bx * BN;
 
   TileMap<AKF, BM, MASKED> ta;
   TileMap<BKF, BN, MASKED> tb;
@@ -834,6 +863,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   int N = p.N;
   int nhi = p.nhi;
   int split = blockIdx.z;
+  int bx, by;
+  m2d_tile_of(p.tile_map, bx, by);
   if (p.bwd_data) {  // as in m2d_gemm_kernel
     const int r = blockIdx.z;
     const int s = p.phases;
@@ -844,7 +875,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
     const int nq = top >= 0 ? (top / s - qmin + 1) : 0;
     if (nq <= 0) return;
     N = p.ph_batch * nq;
-    if ((int)(blockIdx.x * BN) >= N) return;
+    if ((int)(bx * BN) >= N) return;
     nhi = taps;
     A.r_off += r * (p.ph_a_step ? p.ph_a_step : p.ph_cout);
     B.nrows = N;
@@ -857,8 +888,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
     O.c_off = s * qmin + r - p.ph_pad;
     O.c_pos_off = O.c_off;
   }
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  const int m0 = by * BM;
+  const int n0 = bx * BN;
   TileMap<false, BM, false> ta;
   TileMap<false, BN, false> tb;
   ta.prep_dl(A, m0, tid);
@@ -963,7 +994,9 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
   const M2dOperand& A = p.A;
   const M2dOperand& B = p.B;
   const int N = p.N;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int bx, by;
+  m2d_tile_of(p.tile_map, bx, by);
+  const int m0 = by * BM, n0 = bx * BN;
   const int split = blockIdx.z;
   const __amdgpu_buffer_rsrc_t ra = m2d_rsrc(A.base, A.nbytes);
   const __amdgpu_buffer_rsrc_t rb = m2d_rsrc(B.base, B.nbytes);
@@ -1423,9 +1456,16 @@ static void decide_fused(M2dGemmParams& p, int bm, int splits, const void* ws, s
   p.tickets = t;
 }
 
+// M2D_TILE_MAP=0: tile id = workgroup id (A/B lever)
+static int tile_map_default() {
+  static const int v = [] { const char* e = getenv("M2D_TILE_MAP"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
 // one launch of the GEMM (+ the slab reduction) under plan (bm, splits)
 static int plan_run(M2dGemmParams& p, int bm, int splits, bool a_kfast, bool b_kfast, void* ws, hipStream_t stream) {
   p.splits = splits;
+  p.tile_map = tile_map_default();
   p.slab = splits > 1 ? (float*)ws : nullptr;
   const int mt = m2d_ceil_div(p.M, bm);
   const long long nt = m2d_ceil_div(p.N, 128);
@@ -1625,6 +1665,7 @@ int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_b
     }
   }
   p.splits = splits;
+  p.tile_map = tile_map_default();
   p.slab = splits > 1 ? (float*)ws : nullptr;
   decide_fused(p, bm, splits, ws, ws_bytes, stream);
   decide_wide(p, splits, ws);

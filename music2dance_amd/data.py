@@ -10,8 +10,11 @@ What differs from the reference, on purpose:
     that already live in HBM - the sampling paths of phase2/train.py:192-193 and phase3/test.py:92-101;
   * wav files are read with scipy.io.wavfile (librosa is not a dependency): 16-bit / 32-bit PCM is scaled to
     [-1, 1) and multi-channel audio averaged, which is what `librosa.load(path, sr=None)` returns for them;
-  * `collate_fn(..., device=)` can place the padded batch on the device directly (default: host tensors, as the
-    reference returns them).
+  * the takes of a dataset are stored columnar (one array + offsets, `_Ragged`); `collate_fn(..., device=)` pads with
+    one masked gather, on the device when asked (default: host tensors, as the reference returns them), and
+    `SequenceDataset.sample_batch(indices, device=)` cuts a whole batch of windows out of the HBM-resident store;
+  * `SequenceDataset(crop_rng=)`: an explicit generator for the window starts (default: numpy's global one, as in the
+    reference); `make_loaders` returns no validation loader when the hold-out is empty.
 Nothing here is on the timed path; the kernels it calls are declared in include/m2d.h.
 """
 import json
@@ -157,139 +160,249 @@ def get_positions(sequence, length=120):
 
 
 # --------------------------------------------------------------------------------------- datasets
-class StickDataset(Dataset):
-    """Still poses (phase 1) and the fit of the MinMax scaler every phase shares (utils.py:15-45)."""
+# Storage is columnar: every take of a dataset lives in ONE array, takes back to back, with an offsets table - poses
+# (sum of frames, 23, 3) and audio (sum of samples,). `sequences` / `musics` hand out per-take views of those arrays
+# (the attribute contract of utils.py:48-125), a crop is an index range into them, and a whole batch of crops is one
+# gather - on the host, or on the device once `to_device()` has put the two arrays into HBM (a few hundred MB for the
+# real dataset against 288 GB: the dataset is resident, the loader moves indices).
+class _Ragged:
+    """Takes of different lengths stored back to back. Indexing gives a view; assigning a take re-packs."""
 
-    def __init__(self, name, resume=False, centering=True, normalize=None):
-        self.scaler = None
-        if resume:
-            self.skeletons = np.load(name) if isinstance(name, (str, bytes, os.PathLike)) else np.asarray(name)
+    def __init__(self, takes, dtype=None):
+        takes = [np.asarray(t) if dtype is None else np.asarray(t, dtype=dtype) for t in takes]
+        self._pack(takes)
+
+    def _pack(self, takes):
+        self.starts = np.zeros(len(takes) + 1, dtype=np.int64)
+        if takes:
+            np.cumsum([len(t) for t in takes], out=self.starts[1:])
+            self.flat = np.concatenate(takes, axis=0)
         else:
-            sticks = load_sticks(name)
-            self.skeletons = stickwise(sticks, "skeletons")
-            self.centers = stickwise(sticks, "center")
-            if not centering:
-                self.skeletons = self.skeletons + self.centers[:, np.newaxis]
-        if normalize == "minmax":
-            self.scaler = MinMaxScaler()
-            dshape = np.shape(self.skeletons)
-            flat = np.reshape(self.skeletons, (dshape[0], -1))
-            self.skeletons = np.reshape(self.scaler.fit_transform(flat), dshape)
+            self.flat = np.zeros((0,))
+        self._dev = None
 
     def __len__(self):
-        return len(self.skeletons)
+        return len(self.starts) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        return self.flat[self.starts[i]:self.starts[i + 1]]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __setitem__(self, i, take):
+        takes = list(self)
+        takes[int(i)] = np.asarray(take)
+        self._pack(takes)
+
+    def lengths(self):
+        return np.diff(self.starts)
+
+    def map_rows(self, fn):
+        """flat <- fn(flat) on all takes at once (row count unchanged)."""
+        out = fn(self.flat)
+        assert len(out) == len(self.flat)
+        self.flat, self._dev = out, None
+
+    def keep_heads(self, counts):
+        """Truncate take i to its first counts[i] rows."""
+        counts = np.minimum(np.asarray(counts, dtype=np.int64), self.lengths())
+        rows = np.concatenate([np.arange(s, s + c) for s, c in zip(self.starts[:-1], counts)]) if len(self) else []
+        self.flat = self.flat[rows]
+        self.starts = np.concatenate([[0], np.cumsum(counts)])
+        self._dev = None
+
+    def device(self, device, dtype=torch.float32):
+        if self._dev is None or self._dev.device != torch.device(device):
+            self._dev = torch.from_numpy(np.ascontiguousarray(self.flat)).to(device=device, dtype=dtype)
+        return self._dev
+
+
+def _flatten_features(a):
+    return a.reshape(len(a), -1)
+
+
+class StickDataset(Dataset):
+    """All still poses of the dataset, (N, 23, 3); optionally MinMax-scaled to [0, 1] - phase 1's samples, and the
+    scaler every phase shares. Interface of utils.py:15-45: `name` = dataset folder, or with resume=True an .npy
+    file / array of poses; centering=False adds the per-frame body centre back; attributes skeletons / centers / scaler."""
+
+    def __init__(self, name, resume=False, centering=True, normalize=None):
+        if resume:
+            poses = np.load(name) if isinstance(name, (str, bytes, os.PathLike)) else np.asarray(name)
+        else:
+            takes = load_sticks(name)
+            poses = stickwise(takes, "skeletons")
+            self.centers = stickwise(takes, "center")
+            if not centering:
+                poses = poses + self.centers[:, None, :]
+        self.scaler = None
+        if normalize == "minmax":
+            self.scaler = MinMaxScaler().fit(_flatten_features(poses))
+            poses = self.scaler.transform(_flatten_features(poses)).reshape(poses.shape)
+        self.skeletons = poses
+
+    def __len__(self):
+        return self.skeletons.shape[0]
 
     def __getitem__(self, idx):
-        return torch.from_numpy(self.skeletons[idx]).float()
+        return torch.as_tensor(self.skeletons[idx], dtype=torch.float32)
 
     def statistics(self):
-        return self.skeletons.mean(0), self.skeletons.std(0)
+        return self.skeletons.mean(axis=0), self.skeletons.std(axis=0)
 
     def export(self, path):
         np.save(path, self.skeletons)
 
 
 class SequenceDataset(Dataset):
-    """Pose sequences (+ audio tracks) with random fixed-length crops (utils.py:48-125). `name` is the dataset
-    folder, or with resume=True a dict {'sequences', 'labels', 'dirs'[, 'musics']}."""
+    """Pose takes (+ their audio tracks); an item is a random window of `seq_length` seconds (utils.py:48-125).
+    `name`: the dataset folder, or with resume=True a dict {'sequences', 'labels', 'dirs'[, 'musics']}.
+    `crop_rng` (extension): a numpy RandomState / Generator the window starts are drawn from; default = numpy's global
+    generator, which is what the reference draws from (utils.py:245-248), so seeded runs crop identically."""
 
-    def __init__(self, name, config, resume=False, scaler=None, dance_types=["W", "C", "R", "T"], withaudio=False):
-        self.scaler = None
-        self.aud_rate = config["audio_rate"]
-        self.vid_rate = config["video_rate"]
-        self.seq_length = config["seq_length"]
-        self.stick_length = int(config["seq_length"] * self.vid_rate)
-        self.audio_length = int(config["seq_length"] * self.aud_rate)
-        self.ratio = int(config["audio_rate"] / config["video_rate"])
-        self.feat_size = config["feat_size"]
+    def __init__(self, name, config, resume=False, scaler=None, dance_types=("W", "C", "R", "T"), withaudio=False,
+                 crop_rng=None):
+        self.aud_rate, self.vid_rate = config["audio_rate"], config["video_rate"]
+        self.seq_length, self.feat_size = config["seq_length"], config["feat_size"]
+        self.stick_length = int(self.seq_length * self.vid_rate)
+        self.audio_length = int(self.seq_length * self.aud_rate)
+        self.ratio = int(self.aud_rate / self.vid_rate)
         self.withaudio = withaudio
+        self.crop_rng = crop_rng
+        self.scaler = scaler
         if resume:
-            self.sequences = name["sequences"]
-            self.labels = name["labels"]
-            self.dirs = name["dirs"]
-            if withaudio:
-                self.musics = name["musics"]
+            poses, self.labels, self.dirs = name["sequences"], name["labels"], name["dirs"]
+            tracks = name["musics"] if withaudio else None
         else:
-            sticks, musics, labels, dirs = load_all(name, dance_types)
-            self.labels = one_hot_encode(labels)
-            self.dirs = dirs
-            self.musics = musics
-            self.sequences = [np.asarray(s["skeletons"]) for s in sticks]
-        if scaler is not None:
-            self.scaler = scaler
-            for i, seq in enumerate(self.sequences):
-                dshape = np.shape(seq)
-                flat = self.scaler.transform(np.reshape(seq, (seq.shape[0], -1)))
-                self.sequences[i] = np.reshape(flat, dshape)
+            takes, tracks, letters, self.dirs = load_all(name, list(dance_types))
+            self.labels = one_hot_encode(letters)
+            poses = [t["skeletons"] for t in takes]
+        self._poses = _Ragged(poses)
+        self._tracks = None if tracks is None else _Ragged(tracks)
+        if scaler is not None:  # one transform over every frame of every take
+            self._poses.map_rows(lambda f: scaler.transform(_flatten_features(f)).reshape(f.shape))
+
+    # the reference's attribute surface: per-take arrays (views of the columnar store)
+    @property
+    def sequences(self):
+        return self._poses
+
+    @property
+    def musics(self):
+        if self._tracks is None:
+            raise AttributeError("musics")
+        return self._tracks
+
+    @musics.setter
+    def musics(self, tracks):
+        self._tracks = tracks if isinstance(tracks, _Ragged) else _Ragged(tracks)
 
     def __len__(self):
-        return len(self.sequences)
+        return len(self._poses)
+
+    def _draw_start(self, idx):
+        span = int(self._poses.starts[idx + 1] - self._poses.starts[idx]) - self.stick_length
+        rng = self.crop_rng if self.crop_rng is not None else np.random
+        draw = getattr(rng, "integers", None) or rng.randint
+        return int(draw(0, span))
 
     def __getitem__(self, idx):
-        s, e = get_positions(self.sequences[idx], length=self.stick_length)
-        label = torch.from_numpy(np.asarray(self.labels[idx]))
+        idx = int(idx)
+        first = self._draw_start(idx)
+        item = [torch.from_numpy(self._poses[idx][first:first + self.stick_length])]
+        if self.withaudio:
+            a0 = first * self.ratio
+            item.append(torch.from_numpy(self._tracks[idx][a0:a0 + self.audio_length]).float())
+        return (*item, torch.as_tensor(np.asarray(self.labels[idx])), self.dirs[idx])
+
+    def sample_batch(self, indices, device=None):
+        """A whole batch of windows in one gather - from the HBM-resident store when `device` is given. Same draws, in
+        the order of `indices`, and same result as collate_fn([self[i] for i in indices], device=device) (all windows
+        have equal length, so the collate step's sort is the identity): (poses, lengths, [audio,] labels, dirs)."""
+        indices = [int(i) for i in indices]
+        firsts = np.asarray([self._draw_start(i) for i in indices], dtype=np.int64)
+        rows = self._poses.starts[indices] + firsts
+        where = device if device is not None else "cpu"
+        t = torch.arange(self.stick_length, device=where)
+        poses = self._poses.device(where)[torch.as_tensor(rows, device=where)[:, None] + t]
+        labels = torch.as_tensor(np.asarray([self.labels[i] for i in indices]), device=where)
+        dirs = tuple(self.dirs[i] for i in indices)
+        lengths = [self.stick_length] * len(indices)
         if not self.withaudio:
-            return torch.from_numpy(self.sequences[idx][s:e]), label, self.dirs[idx]
-        s_a = s * self.ratio
-        e_a = s_a + self.audio_length
-        return (torch.from_numpy(self.sequences[idx][s:e]), torch.from_numpy(self.musics[idx][s_a:e_a]).float(),
-                label, self.dirs[idx])
+            return poses, lengths, labels, dirs
+        cols = self._tracks.starts[indices] + firsts * self.ratio
+        s = torch.arange(self.audio_length, device=where)
+        audio = self._tracks.device(where)[torch.as_tensor(cols, device=where)[:, None] + s]
+        return poses, lengths, audio, labels, dirs
 
     def resample_audio(self, new_rate):
         from scipy.signal import resample
-        for i in range(len(self.musics)):
-            self.musics[i] = resample(self.musics[i], int(len(self.musics[i]) * new_rate / self.aud_rate))
-        self.aud_rate = new_rate
-        self.ratio = int(new_rate / self.vid_rate)
+        factor = new_rate / self.aud_rate
+        self._tracks = _Ragged([resample(t, int(len(t) * factor)) for t in self._tracks])
+        self.aud_rate, self.ratio = new_rate, int(new_rate / self.vid_rate)
         self.audio_length = int(self.seq_length * new_rate)
 
     def truncate(self):
-        """Cut audio and poses of every take to their common whole number of seconds (utils.py:109-116)."""
-        for i in range(len(self)):
-            al = int(len(self.musics[i]) / self.aud_rate)
-            sl = int(len(self.sequences[i]) / self.vid_rate)
-            mini = min(al, sl)
-            self.musics[i] = self.musics[i][:int(mini * self.aud_rate)]
-            self.sequences[i] = self.sequences[i][:int(mini * self.vid_rate)]
+        """Poses and audio of every take cut to the whole seconds both have (utils.py:109-116)."""
+        seconds = np.minimum((self._tracks.lengths() / self.aud_rate).astype(np.int64),
+                             (self._poses.lengths() / self.vid_rate).astype(np.int64))
+        self._tracks.keep_heads((seconds * self.aud_rate).astype(np.int64))
+        self._poses.keep_heads((seconds * self.vid_rate).astype(np.int64))
+
+    def subset(self, indices, withaudio=None):
+        """A dataset over the takes `indices` (same rates / crop source)."""
+        withaudio = self.withaudio if withaudio is None else withaudio
+        state = {"sequences": [self._poses[i] for i in indices], "labels": [self.labels[i] for i in indices],
+                 "dirs": [self.dirs[i] for i in indices]}
+        if withaudio:
+            state["musics"] = [self._tracks[i] for i in indices]
+        cfg = {"audio_rate": self.aud_rate, "video_rate": self.vid_rate, "seq_length": self.seq_length,
+               "feat_size": self.feat_size}
+        return SequenceDataset(state, cfg, resume=True, withaudio=withaudio, crop_rng=self.crop_rng)
 
     def export(self, pathfile):
         with open(pathfile, "wb") as f:
-            pickle.dump({"sequences": self.sequences, "labels": self.labels, "dirs": self.dirs}, f)
+            pickle.dump({"sequences": list(self._poses), "labels": self.labels, "dirs": self.dirs}, f)
 
 
 def collate_fn(batch, withaudio=True, device=None):
-    """utils.py:128-144: sort the samples by length (longest first), zero-pad the poses to (B, Tmax, 23, 3) fp32.
-    -> (padded_seqs, lengths, [musics,] labels, dirs). device: build / move the tensors there (extension)."""
-    batch.sort(key=lambda x: len(x[0]), reverse=True)
-    if withaudio:
-        sequences, musics, labels, dirs = zip(*batch)
-        musics = torch.stack(musics)
-    else:
-        sequences, labels, dirs = zip(*batch)
-    labels = torch.stack(labels)
-    lengths = [len(seq) for seq in sequences]
-    padded_seqs = torch.zeros(len(sequences), max(lengths), 23, 3)
-    for i, seq in enumerate(sequences):
-        padded_seqs[i, :lengths[i]] = seq[:lengths[i]]
-    if device is not None:
-        padded_seqs, labels = padded_seqs.to(device, non_blocking=True), labels.to(device, non_blocking=True)
-        if withaudio:
-            musics = musics.to(device, non_blocking=True)
-    if withaudio:
-        return padded_seqs, lengths, musics, labels, dirs
-    return padded_seqs, lengths, labels, dirs
+    """Ragged samples -> one zero-padded batch, longest sample first (what pack_padded_sequence wants; utils.py:128-144):
+    (poses (B, Tmax, 23, 3) fp32, lengths, [audio (B, S),] labels (B,), dirs). The padding is ONE masked gather over
+    the concatenated frames instead of a copy per sample; with `device` the frames are moved first and gather, mask
+    and the other tensors are made there."""
+    order = sorted(range(len(batch)), key=lambda i: -len(batch[i][0]))  # stable: ties keep their order, like list.sort
+    cols = list(zip(*(batch[i] for i in order)))
+    frames, dirs, labels = cols[0], cols[-1], torch.stack(cols[-2])
+    lengths = [len(f) for f in frames]
+    where = device if device is not None else frames[0].device
+    flat = torch.cat([f.reshape(len(f), -1) for f in frames]).to(device=where, dtype=torch.float32, non_blocking=True)
+    n = torch.as_tensor(lengths, device=where)
+    t = torch.arange(max(lengths), device=where)
+    inside = t[None, :] < n[:, None]                                      # (B, Tmax)
+    src = (torch.cumsum(n, 0) - n)[:, None] + torch.where(inside, t[None, :], torch.zeros_like(t)[None, :])
+    padded = (flat[src] * inside[..., None]).reshape(len(frames), len(t), *frames[0].shape[1:])
+    labels = labels.to(where, non_blocking=True)
+    if not withaudio:
+        return padded, lengths, labels, dirs
+    return padded, lengths, torch.stack(cols[1]).to(where, non_blocking=True), labels, dirs
 
 
 # --------------------------------------------------------------------------------------- split + samplers
 def split_indices(dataset_size, validation_split=.2, test_split=.5, random_seed=14):
-    """phase3/train.py:112-124: shuffle range(n) with numpy seed 14; the first floor(.2 n) indices are held out,
-    half of them (floor) for test. -> (train, val, test) index lists."""
-    indices = list(range(dataset_size))
-    vsplit = int(np.floor(validation_split * dataset_size))
-    tsplit = int(np.floor(test_split * vsplit))
+    """The seeded hold-out of phase3/train.py:112-124 -> (train, val, test) index lists: a permutation of range(n)
+    under numpy seed 14; its first floor(.2 n) entries are held out, the first floor(half) of those for test. Seeds
+    numpy's GLOBAL generator like the reference does (the crops drawn afterwards depend on that state)."""
     np.random.seed(random_seed)
-    np.random.shuffle(indices)
-    return indices[vsplit:], indices[tsplit:vsplit], indices[:tsplit]
+    perm = np.random.permutation(dataset_size).tolist()
+    held = int(validation_split * dataset_size)
+    test = int(test_split * held)
+    return perm[held:], perm[test:held], perm[:test]
 
 
 def class_balanced_weights(labels, indices):
@@ -302,28 +415,24 @@ def class_balanced_weights(labels, indices):
 
 
 def make_loaders(dataset, batch_size, withaudio=True, logdir=None):
-    """The train / validation loaders of phase3/train.py:112-162: seeded split, trainvaltest_samples.json,
-    class-balanced WeightedRandomSamplers, resume-datasets of the two subsets, validation served as one batch."""
+    """Train / validation loaders over the seeded split (phase3/train.py:112-162): trainvaltest_samples.json in
+    `logdir`, each subset drawn through a class-balanced WeightedRandomSampler, validation served as ONE batch.
+    A dataset too small to hold anything out (< 5 takes) gets no validation loader (None)."""
     from torch.utils.data import DataLoader, WeightedRandomSampler
-    train_idx, val_idx, test_idx = split_indices(len(dataset))
+    parts = dict(zip(("train", "val", "test"), split_indices(len(dataset))))
     if logdir is not None:
-        with open(logdir + "/trainvaltest_samples.json", "w+") as f:
-            json.dump({"train_samples": [dataset.dirs[i] for i in train_idx],
-                       "val_samples": [dataset.dirs[i] for i in val_idx],
-                       "test_samples": [dataset.dirs[i] for i in test_idx]}, f)
-    cfg = {"audio_rate": dataset.aud_rate, "video_rate": dataset.vid_rate, "seq_length": dataset.seq_length,
-           "feat_size": dataset.feat_size}
-    loaders = []
-    for idx, bs in ((train_idx, batch_size), (val_idx, len(val_idx))):
-        w = class_balanced_weights(dataset.labels, idx)
-        sub = {"sequences": [dataset.sequences[i] for i in idx], "labels": [dataset.labels[i] for i in idx],
-               "dirs": [dataset.dirs[i] for i in idx]}
-        if withaudio:
-            sub["musics"] = [dataset.musics[i] for i in idx]
-        ds = SequenceDataset(sub, cfg, resume=True, withaudio=withaudio)
-        loaders.append(DataLoader(ds, batch_size=max(bs, 1), sampler=WeightedRandomSampler(w, len(w)),
-                                  collate_fn=lambda b, wa=withaudio: collate_fn(b, withaudio=wa)))
-    return loaders[0], loaders[1], (train_idx, val_idx, test_idx)
+        with open(os.path.join(logdir, "trainvaltest_samples.json"), "w") as f:
+            json.dump({k + "_samples": [dataset.dirs[i] for i in v] for k, v in parts.items()}, f)
+
+    def loader(idx, per_batch):
+        if not idx:
+            return None
+        weights = class_balanced_weights(dataset.labels, idx)
+        return DataLoader(dataset.subset(idx, withaudio), batch_size=per_batch,
+                          sampler=WeightedRandomSampler(weights, len(weights)),
+                          collate_fn=lambda b: collate_fn(b, withaudio=withaudio))
+
+    return loader(parts["train"], batch_size), loader(parts["val"], len(parts["val"])), tuple(parts.values())
 
 
 # --------------------------------------------------------------------------------------- synthetic dataset folder

@@ -114,3 +114,32 @@ def test_label_encoding_split_and_sampler_weights_match_reference():
         assert tr == list(G["split%d_train" % n]) and va == list(G["split%d_val" % n]) and te == list(G["split%d_test" % n])
     tr = D.split_indices(61)[0]
     assert np.array_equal(D.class_balanced_weights(G["w61_labels"], tr), G["w61_train_weights"])
+
+
+def test_batched_window_gather_equals_itemwise_crops_and_small_datasets_have_no_validation_loader(tmp_path):
+    """Extensions of the rewritten dataset layer: sample_batch (one gather over the columnar store) returns what the
+    item-by-item path + collate_fn returns under the same draws; an explicit crop generator; < 5 takes -> no hold-out."""
+    from music2dance_amd import data as D
+    folder = D.write_synthetic_dataset(str(tmp_path / "ds"), n_takes=4, seconds=6, seed=5)
+    cfg = {"audio_rate": 16000, "video_rate": 25, "seq_length": 4.8, "feat_size": 0.2}
+    ds = D.SequenceDataset(folder, cfg, withaudio=True)
+    ds.truncate()
+    idx = [2, 0, 3, 3]
+    np.random.seed(7)
+    want = D.collate_fn([ds[i] for i in idx])
+    np.random.seed(7)
+    got = ds.sample_batch(idx)
+    assert torch.equal(got[0], want[0]) and got[1] == want[1] and torch.equal(got[2], want[2])
+    assert torch.equal(got[3], want[3]) and tuple(got[4]) == tuple(want[4])
+    # explicit generator: reproducible without touching numpy's global state
+    a = D.SequenceDataset(folder, cfg, withaudio=False, crop_rng=np.random.RandomState(3))
+    b = D.SequenceDataset(folder, cfg, withaudio=False, crop_rng=np.random.RandomState(3))
+    state = np.random.get_state()[1].copy()
+    assert all(torch.equal(a[i][0], b[i][0]) for i in (1, 1, 0))
+    assert np.array_equal(state, np.random.get_state()[1])
+    # per-take assignment re-packs the store
+    first = np.array(ds.sequences[1])
+    ds.sequences[1] = first[:150]
+    assert len(ds.sequences[1]) == 150 and np.array_equal(ds.sequences[1], first[:150]) and len(ds.sequences[2]) > 0
+    train_loader, val_loader, (tr, va, te) = D.make_loaders(ds, batch_size=2, logdir=None)
+    assert val_loader is None and va == [] and len(tr) == 4 and next(iter(train_loader))[0].shape[0] == 2
