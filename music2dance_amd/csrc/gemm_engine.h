@@ -83,7 +83,7 @@ struct M2dOutMap {
   const float* residual;
   float* sum_out;
   int mask_last;
-  // set by the launcher when the tile can leave as 16-byte rows (m2d_tile_epilogue_wide): unit column stride, every
+  // set by the launcher when the tile can leave as 16-byte rows (m2d_tile_epilogue, WIDE): unit column stride, every
   // pitch / offset / column count a multiple of 4, 16-byte aligned pointers, no window / redirect column
   int wide;
   // set by the caller (sub-pixel backward-data at stride 4): rows 4 c .. 4 c + 3 of one column are four consecutive

@@ -213,7 +213,11 @@ struct TileMap {
     const int row0 = BR >= 64 ? (__builtin_amdgcn_readfirstlane(tid) & (BR - 1) & ~63) : 0;
     float* dst = img + kb0 * LD + row0;
     if constexpr (UNIFORM) {
+#ifdef M2D_X_NO_WINDOW  // experiment: no window test in uniform chunks
+      const unsigned voff = full;
+#else
       const unsigned voff = ((unsigned)(posr + P) < lim_eff) ? full : M2D_OOB;
+#endif
 #pragma unroll
       for (int i = 0; i < NE; ++i) m2d_bload_lds(rs, dst + (KS * i) * LD, voff, i * ls4);
     } else {
@@ -344,100 +348,124 @@ __device__ __forceinline__ void m2d_chunk_mma(const TileMap<AKF, BM, MASKED>& ta
   }
 }
 
+// Accumulator start values: the bias (per row or per column) instead of zero - the MFMA chain then carries it and the
+// epilogue has no bias lookup at all (bias[row] was a global load on every row's dependency chain there). Not under the
+// two-launch split-K (its reduction kernel adds the bias); with the in-kernel fix-up only split 0 starts from the bias
+// (the last arriver sums every split's image, split 0's included, from zero).
+template <int BM, int BN>
+__device__ __forceinline__ void m2d_acc_init(const M2dGemmParams& p, const M2dOutMap& O, int N, int split, int m0, int n0, int wm,
+                                             int wn, int l31, int lh,
+                                             f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  const bool with_bias = O.bias_mode != 0 && (p.splits <= 1 || (p.tickets && split == 0));
+  if (!with_bias) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    return;
+  }
+  if (O.bias_mode == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float b = row < p.M ? O.bias[row] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j][r] = b;
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+      const float b = col < N ? O.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+    }
+  }
+}
+
 // Tile epilogue shared by the staging variants. C/D layout of the 32x32 MFMA: col = lane & 31,
 //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-template <int BM, int BN>
+// Every 32x32 accumulator tile goes through a wave-private 4 KB LDS image [row][32 columns] (the stage buffers are free
+// after the last chunk) and is written out by a rolled loop over the image:
+//   WIDE  (launcher-checked: unit column stride, pitches / offsets / N multiples of 4, no window / redirect / row map):
+//         a lane takes 4 consecutive columns of one row - 16-byte stores, 8 rows x 128 B per instruction;
+//   else  a lane takes one element - column = lane & 31, two rows per step - through the full output map (column
+//         divmod, window, sub-pixel row map, redirect column).
+// Round 4 rewrite. Phase stamps (tools/phase_stamps.py, -DM2D_STAMP builds) showed a workgroup spending 10-55 us in its
+// epilogue - a tenth of a 300-600 us conv launch. Cause: a global load (bias[row], the output mask, the residual) in
+// front of every store. `s_waitcnt vmcnt` counts loads AND stores on this part, in issue order, so waiting for item
+// q's load also waits for item q - 1's store to be acknowledged: 16-64 store round trips (1-3 us each under load) in
+// series per wave. Now NO load sits between two stores: the bias rides in the accumulators (m2d_acc_init), the output
+// mask of a whole band is fetched in one burst right after the dump and kept as ONE BIT per element (the multiplier is
+// 1 or mask_slope), and the pass over the image only reads LDS and stores. (The residual, rare, is still looked up in
+// the pass - inside its own uniform branch, so that launches without one carry no wait.)
+__device__ __forceinline__ float4 m2d_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void m2d_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+typedef unsigned int m2d_u32x4 __attribute__((__vector_size__(16)));
+typedef float m2d_vf32x4 __attribute__((__vector_size__(16)));
+__device__ __forceinline__ void m2d_bstore1(__amdgpu_buffer_rsrc_t r, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void m2d_bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
+  m2d_vf32x4 w;
+  w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(m2d_u32x4, w), r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ float4 m2d_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const m2d_vf32x4 w = __builtin_bit_cast(m2d_vf32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+  return make_float4(w[0], w[1], w[2], w[3]);
+}
+
+// All global accesses of the pass are raw buffer operations with a 32-bit byte offset (the launcher checks that the
+// output map stays below 2 GiB): one address register per access, and an element that must not be touched simply gets
+// the offset M2D_OOB - the range check drops the store / returns 0.0 - instead of a branch around the instruction.
+template <int BM, int BN, bool WIDE>
 __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const M2dOutMap& O, int N, int split, int m0,
-                                                  int n0, int wm, int wn, int l31, int lh,
+                                                  int n0, int wm, int wn, int lane, float* wl,
                                                   f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
   constexpr int WM = BM >= 64 ? 2 : 1;
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (32 * WM);
   constexpr int TN = BN / (32 * WN);
-  int caddr[TN], colj[TN], posj[TN];
-  bool cvj[TN], cokj[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (TN * 32) + j * 32 + l31;
-    const bool cv = col < N;
-    int chi, clo;
-    m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
-    caddr[j] = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
-    bool cok = cv;
-    posj[j] = clo * O.c_pos_mul + O.c_pos_off;
-    if (O.c_lim > 0 && O.m_div <= 0) cok = cok && ((unsigned)posj[j] < (unsigned)O.c_lim);
-    colj[j] = col;
-    cvj[j] = cv;
-    cokj[j] = cok;
-  }
-  const bool stats = O.row_part != nullptr && (p.splits <= 1 || p.tickets);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const bool rok = row < p.M;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (rok) {
-          if (p.splits > 1 && !p.tickets) {
-            if (cvj[j]) p.slab[(size_t)split * p.M * p.N + (size_t)row * p.N + colj[j]] = acc[i][j][r];
-          } else if (colj[j] + 1 == O.redirect_col_p1) {
-            O.col_out[row] = acc[i][j][r];
-          } else if (cokj[j] && (O.m_div <= 0 || (unsigned)(posj[j] + (row % O.m_div) * O.m_pos_mul) < (unsigned)O.c_lim)) {
-            const int addr = (O.m_div > 0 ? (row / O.m_div) * O.m_stride + (row % O.m_div) * O.m_lo_stride
-                                          : row * O.m_stride) + caddr[j];
-            const float v = m2d_epilogue(O, acc[i][j][r], row, colj[j], addr);
-            O.out[addr] = v;
-            s1 += v;
-            s2 += v * v;
-          }
-        }
-      }
-      if (stats) {  // wave-uniform: sum over the 32 lanes (columns) that share this row, one atomic pair per row
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          s1 += __shfl_xor(s1, off, 64);
-          s2 += __shfl_xor(s2, off, 64);
-        }
-        if (l31 == 0 && rok) {
-          float* dst = O.row_part + ((size_t)((n0 / BN) * WN + wn) * p.M + row) * 2;
-          dst[0] = s1;
-          dst[1] = s2;
-        }
-      }
-    }
-  }
-}
-
-// Wide tile epilogue: every 32x32 accumulator tile goes through a wave-private 4 KB LDS image (the stage buffers are
-// free after the last chunk) and leaves as 16-byte rows - 8 rows x 128 bytes per store instruction instead of 2 rows
-// x 128 bytes as dwords: a quarter of the store (and mask / residual load) instructions. Bias, activation, mask,
-// residual, second output and the row statistics are applied on the way out, in the same order as m2d_epilogue.
-// Requires O.wide (launcher-checked): unit column stride, all pitches / offsets / N multiples of 4, no column window.
-__device__ __forceinline__ float4 m2d_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void m2d_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-
-template <int BM, int BN>
-__device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, const M2dOutMap& O, int N, int split,
-                                                       int m0, int n0, int wm, int wn, int lane, float* wl,
-                                                       f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
-  constexpr int WM = BM >= 64 ? 2 : 1;
-  constexpr int WN = 4 / WM;
-  constexpr int TM = BM / (32 * WM);
-  constexpr int TN = BN / (32 * WN);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int rl0 = lane >> 3, c4 = (lane & 7) * 4;  // read-back: lane -> row rl0 + 8 * it, columns c4 .. c4 + 3
-  const bool stats = O.row_part != nullptr && (p.splits <= 1 || p.tickets);
-  // one 32x32 tile at a time: its 16 registers die at the dump, so the pass over the image runs in the registers the
-  // main loop leaves free (the accumulators of the tiles still to come stay live) - and the loop over the four
-  // row groups is NOT unrolled: interleaving them would buy nothing but registers, i.e. resident waves
-  // BM = 128: both tiles of a 32-row band are dumped together (2 x 4 KB per wave = the whole 32 KB of stage buffers),
-  // so 32 accumulator registers die at once and the pass fits under the main loop's 89 registers (five waves per SIMD)
-  constexpr int NT = (BM == 128) ? TN : 1;
+  // two-launch split-K: the raw partial tile goes to this split's slab [M][N] - the same pass under a plain map
+  const bool slab = p.splits > 1 && !p.tickets;
+  const bool stats = O.row_part != nullptr && !slab;
+  const bool has_mask = O.mask != nullptr && !slab, has_res = O.residual != nullptr && !slab;
+  const bool two_out = O.sum_out != nullptr && !slab;
+  const int act = slab ? 0 : O.act;
+  const float ms = O.mask_slope;
+  const int m_stride = slab ? p.N : O.m_stride;
+  const int m_div = slab ? 0 : O.m_div;
+  const int c_lim = slab ? 0 : O.c_lim;
+  const int redirect = slab ? 0 : O.redirect_col_p1;
+  const float* out_base = slab ? p.slab + (size_t)split * p.M * p.N : O.out;
+  // (descriptors are built where they are used: four of them held across the pass spill scalar registers)
+#define M2D_RS(ptr) m2d_rsrc((ptr), 0x7ffffffcu)
+  // BM = 128: both tiles of a 32-row band are dumped together (2 x 4 KB per wave = the whole 32 KB of stage buffers)
+  // (only the 16-byte pass needs the second tile's registers; the one-element pass takes a tile at a time)
+  constexpr int NT = (BM == 128 && WIDE) ? TN : 1;
+  // WIDE: lane -> row rl0 + 8 it, columns c4 .. c4 + 3 (it = 0..3); else: lane -> row 2 it + lh, column l31 (it = 0..15)
+  const int rl0 = lane >> 3, c4 = (lane & 7) * 4;
+  constexpr int PER_TILE = WIDE ? 4 : 16;
+  constexpr int ITEMS = NT * PER_TILE;           // per band
+  // items whose mask is fetched in one burst (one bit each fits 32 bits); 128-row tiles: 8 - sixteen loads in flight
+  // beside 48 live accumulators would cost the LDS-direct kernel its fifth wave per SIMD
+  constexpr int GROUP = WIDE ? ITEMS : (BM == 128 ? 8 : 16);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int rowb = m0 + wm * (TM * 32) + i * 32;
 #pragma unroll
     for (int j0 = 0; j0 < TN; j0 += NT) {
 #pragma unroll
@@ -446,80 +474,234 @@ __device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, c
         for (int r = 0; r < 16; ++r) wl[jj * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[i][j0 + jj][r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-      for (int jj = 0; jj < NT; ++jj) {
-      const int j = j0 + jj;
-      const float* wt = wl + jj * 1024;
-      const int col = n0 + wn * (TN * 32) + j * 32 + c4;
-      const bool cv = col < N;
-      int caddr = 0;
-      if (p.splits <= 1 || p.tickets) {
-        int chi, clo;
-        m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
-        caddr = chi * O.c_hi_stride + clo + O.c_off;
-      }
-#pragma unroll 1
-      for (int it = 0; it < 4; ++it) {
-        const int rl = rl0 + 8 * it;
-        const int row = m0 + wm * (TM * 32) + i * 32 + rl;
-        const bool ok = row < p.M && cv;
-        float4 v = m2d_ld4(wt + rl * 32 + c4);
-        float a1 = 0.f, a2 = 0.f;
-        if (ok) {
-          if (p.splits > 1 && !p.tickets) {
-            m2d_st4(p.slab + (size_t)split * p.M * p.N + (size_t)row * p.N + col, v);
-          } else {
-            const int addr = row * O.m_stride + caddr;
-            if (O.bias_mode == 1) {
-              const float b = O.bias[row];
-              v.x += b; v.y += b; v.z += b; v.w += b;
-            } else if (O.bias_mode == 2) {
-              const float4 b = m2d_ld4(O.bias + col);
-              v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-            }
-            if (O.act == 1) {
-              v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-            } else if (O.act == 2) {
-              v.x = v.x > 0.f ? v.x : v.x * O.slope; v.y = v.y > 0.f ? v.y : v.y * O.slope;
-              v.z = v.z > 0.f ? v.z : v.z * O.slope; v.w = v.w > 0.f ? v.w : v.w * O.slope;
-            }
-            if (O.residual && O.mask_last) {
-              const float4 q = m2d_ld4(O.residual + addr);
-              v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
-            if (O.mask) {
-              const float4 m = m2d_ld4(O.mask + addr);
-              v.x *= m.x > 0.f ? 1.f : O.mask_slope; v.y *= m.y > 0.f ? 1.f : O.mask_slope;
-              v.z *= m.z > 0.f ? 1.f : O.mask_slope; v.w *= m.w > 0.f ? 1.f : O.mask_slope;
-            }
-            if (O.residual && !O.mask_last) {
-              const float4 q = m2d_ld4(O.residual + addr);
-              const float4 sum = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
-              if (O.sum_out) m2d_st4(O.sum_out + addr, sum);
-              else v = sum;
-            }
-            m2d_st4(O.out + addr, v);
-            a1 = (v.x + v.y) + (v.z + v.w);
-            a2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-          }
-        }
-        if (stats) {  // this tile's 32 columns of the row: the 8 lanes that share it; one partial per (row, 32-column tile)
+      __builtin_amdgcn_sched_barrier(0);  // (nothing of the pass above the dump: its registers are the ones the dump frees)
+      // per-tile column state of this lane (NT <= 2 tiles: picked by select)
+      int caddr_t[NT], pos_t[NT];
+      bool cok_t[NT], red_t[NT];
 #pragma unroll
-          for (int off = 4; off > 0; off >>= 1) {
-            a1 += __shfl_xor(a1, off, 64);
-            a2 += __shfl_xor(a2, off, 64);
+      for (int jj = 0; jj < NT; ++jj) {
+        const int col = n0 + wn * (TN * 32) + (j0 + jj) * 32 + (WIDE ? c4 : l31);
+        const bool cv = col < N;
+        if (slab) {
+          caddr_t[jj] = col;
+          pos_t[jj] = 0;
+        } else {
+          int chi, clo;
+          m2d_divmod(cv ? col : 0, O.cdiv, O.cdiv_inv, chi, clo);
+          caddr_t[jj] = chi * O.c_hi_stride + clo * (WIDE ? 1 : O.c_lo_stride) + O.c_off;
+          pos_t[jj] = clo * O.c_pos_mul + O.c_pos_off;
+        }
+        red_t[jj] = !WIDE && cv && (col + 1 == redirect);
+        bool cok = cv;
+        if (!WIDE && c_lim > 0 && m_div <= 0) cok = cok && ((unsigned)pos_t[jj] < (unsigned)c_lim);
+        cok_t[jj] = cok;
+      }
+      // ---- fast pass: no residual, plain row map (and, one element per lane: no statistics, no redirect column in
+      // this tile). A dozen instructions per element, no branch: the general pass below spends ~150 on its uniform
+      // feature tests, and a lane has 64 elements (20 us per workgroup on a plain GEMM tile, measured).
+      //   activation: max(x, 0) + s min(x, 0) with s = 1 / 0 / slope (none / ReLU / leaky) - equal to the selects up to
+      //   the sign of a zero; mask: one bit per element, fetched in one burst per tile
+      {
+        const float act_s = act == 0 ? 1.f : (act == 1 ? 0.f : O.slope);
+        bool fast = !has_res && m_div <= 0;
+        if constexpr (!WIDE) fast = fast && !stats && __ballot(red_t[0]) == 0ull;
+        if (fast) {
+          const __amdgpu_buffer_rsrc_t rso = m2d_rsrc(out_base, 0x7ffffffcu);
+#pragma unroll
+          for (int jj = 0; jj < NT; ++jj) {
+            constexpr int NI = PER_TILE;  // items of one tile: rows r0 + RS it
+            constexpr int RS = WIDE ? 8 : 2;
+            const int r0 = WIDE ? rl0 : lh;
+            const unsigned step = (unsigned)(RS * m_stride) << 2;
+            const unsigned v0 = cok_t[jj] ? (unsigned)((rowb + r0) * m_stride + caddr_t[jj]) << 2 : M2D_OOB;
+            const int nrow = p.M - rowb - r0;  // item `it` is inside the matrix iff RS it < nrow
+            unsigned keep = 0xffffffffu;
+            if (has_mask) {
+              const __amdgpu_buffer_rsrc_t rsm = m2d_rsrc(O.mask, 0x7ffffffcu);
+              keep = 0u;
+              if constexpr (WIDE) {
+                float4 mraw[NI];
+#pragma unroll
+                for (int it = 0; it < NI; ++it)
+                  mraw[it] = m2d_bload4(rsm, (RS * it < nrow && v0 != M2D_OOB) ? v0 + (unsigned)it * step : M2D_OOB);
+#pragma unroll
+                for (int it = 0; it < NI; ++it)
+                  keep |= ((mraw[it].x > 0.f ? 1u : 0u) | (mraw[it].y > 0.f ? 2u : 0u) | (mraw[it].z > 0.f ? 4u : 0u) | (mraw[it].w > 0.f ? 8u : 0u)) << (4 * it);
+              } else {
+                float mraw[NI];
+#pragma unroll
+                for (int it = 0; it < NI; ++it)
+                  mraw[it] = m2d_bload(rsm, (RS * it < nrow && v0 != M2D_OOB) ? v0 + (unsigned)it * step : M2D_OOB, 0);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) keep |= (mraw[it] > 0.f ? 1u : 0u) << it;
+              }
+            }
+            const float* img = wl + jj * 1024 + r0 * 32 + (WIDE ? c4 : l31);
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+              const bool ok = RS * it < nrow && v0 != M2D_OOB;
+              const unsigned voff = ok ? v0 + (unsigned)it * step : M2D_OOB;
+              if constexpr (WIDE) {
+                float4 x = m2d_ld4(img + it * (RS * 32));
+                const unsigned kb = keep >> (4 * it);
+                x.x = (fmaxf(x.x, 0.f) + act_s * fminf(x.x, 0.f)) * ((kb & 1u) ? 1.f : ms);
+                x.y = (fmaxf(x.y, 0.f) + act_s * fminf(x.y, 0.f)) * ((kb & 2u) ? 1.f : ms);
+                x.z = (fmaxf(x.z, 0.f) + act_s * fminf(x.z, 0.f)) * ((kb & 4u) ? 1.f : ms);
+                x.w = (fmaxf(x.w, 0.f) + act_s * fminf(x.w, 0.f)) * ((kb & 8u) ? 1.f : ms);
+                m2d_bstore4(rso, voff, x);
+                if (stats) {  // this tile's 32 columns of the row: the 8 lanes that share it
+                  float a1 = ok ? (x.x + x.y) + (x.z + x.w) : 0.f;
+                  float a2 = ok ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : 0.f;
+#pragma unroll
+                  for (int off = 4; off > 0; off >>= 1) {
+                    a1 += __shfl_xor(a1, off, 64);
+                    a2 += __shfl_xor(a2, off, 64);
+                  }
+                  if ((lane & 7) == 0 && RS * it < nrow) {
+                    float* dst = O.row_part + ((size_t)(((n0 / BN) * WN + wn) * TN + j0 + jj) * p.M + rowb + r0 + RS * it) * 2;
+                    dst[0] = a1;
+                    dst[1] = a2;
+                  }
+                }
+              } else {
+                float x = img[it * (RS * 32)];
+                x = (fmaxf(x, 0.f) + act_s * fminf(x, 0.f)) * (((keep >> it) & 1u) ? 1.f : ms);
+                m2d_bstore1(rso, voff, x);
+              }
+            }
           }
-          if ((lane & 7) == 0 && row < p.M) {
-            float* dst = O.row_part + ((size_t)(((n0 / BN) * WN + wn) * TN + j) * p.M + row) * 2;
-            dst[0] = a1;
-            dst[1] = a2;
-          }
+          __builtin_amdgcn_wave_barrier();
+          continue;
         }
       }
+      // ---- general pass
+      // item q of the dumped tiles -> (tile jj, image row, output row, byte offset of the element or M2D_OOB)
+      auto locate = [&](int q, int& jj, int& rl, int& row, unsigned& voff) {
+        jj = NT > 1 ? q / PER_TILE : 0;
+        const int it = q - jj * PER_TILE;
+        rl = WIDE ? rl0 + 8 * it : 2 * it + lh;
+        row = rowb + rl;
+        const int caddr = NT > 1 && jj ? caddr_t[NT - 1] : caddr_t[0];
+        bool ok = row < p.M && (NT > 1 && jj ? cok_t[NT - 1] : cok_t[0]) && !(NT > 1 && jj ? red_t[NT - 1] : red_t[0]);
+        int addr;
+        if (!WIDE && m_div > 0) {  // sub-pixel row map (the quad epilogue's fall-back)
+          int mhi, mlo;
+          m2d_divmod(row, m_div, 1.f / (float)m_div, mhi, mlo);
+          const int pos = NT > 1 && jj ? pos_t[NT - 1] : pos_t[0];
+          if (c_lim > 0) ok = ok && ((unsigned)(pos + mlo * O.m_pos_mul) < (unsigned)c_lim);
+          addr = mhi * m_stride + mlo * O.m_lo_stride + caddr;
+        } else {
+          addr = row * m_stride + caddr;
+        }
+        voff = ok ? (unsigned)addr << 2 : M2D_OOB;
+      };
+#pragma unroll 1
+      for (int q0 = 0; q0 < ITEMS; q0 += GROUP) {
+        // the group's output mask in ONE burst - no load between two stores of the group - kept as one bit per element
+        unsigned keep = 0xffffffffu;
+        if (has_mask) {
+          keep = 0u;
+          if constexpr (WIDE) {
+            float4 mraw[GROUP];
+#pragma unroll
+            for (int q = 0; q < GROUP; ++q) {
+              int jj, rl, row;
+              unsigned voff;
+              locate(q0 + q, jj, rl, row, voff);
+              mraw[q] = m2d_bload4(M2D_RS(O.mask), voff);
+            }
+#pragma unroll
+            for (int q = 0; q < GROUP; ++q)
+              keep |= ((mraw[q].x > 0.f ? 1u : 0u) | (mraw[q].y > 0.f ? 2u : 0u) | (mraw[q].z > 0.f ? 4u : 0u) | (mraw[q].w > 0.f ? 8u : 0u)) << (4 * q);
+          } else {
+            float mraw[GROUP];
+#pragma unroll
+            for (int q = 0; q < GROUP; ++q) {
+              int jj, rl, row;
+              unsigned voff;
+              locate(q0 + q, jj, rl, row, voff);
+              mraw[q] = m2d_bload(M2D_RS(O.mask), voff, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < GROUP; ++q) keep |= (mraw[q] > 0.f ? 1u : 0u) << q;
+          }
+        }
+#pragma unroll 2
+        for (int qq = 0; qq < GROUP; ++qq) {
+          int jj, rl, row;
+          unsigned voff;
+          locate(q0 + qq, jj, rl, row, voff);
+          const bool ok = voff != M2D_OOB;
+          float a1 = 0.f, a2 = 0.f;
+          if constexpr (WIDE) {
+            float4 x = m2d_ld4(wl + jj * 1024 + rl * 32 + c4);
+            if (act == 1) {
+              x.x = x.x > 0.f ? x.x : 0.f; x.y = x.y > 0.f ? x.y : 0.f; x.z = x.z > 0.f ? x.z : 0.f; x.w = x.w > 0.f ? x.w : 0.f;
+            } else if (act == 2) {
+              x.x = x.x > 0.f ? x.x : x.x * O.slope; x.y = x.y > 0.f ? x.y : x.y * O.slope;
+              x.z = x.z > 0.f ? x.z : x.z * O.slope; x.w = x.w > 0.f ? x.w : x.w * O.slope;
+            }
+            if (has_res && O.mask_last) {  // (a load and its use inside ONE uniform branch: launches without a residual carry no wait)
+              const float4 r4 = m2d_bload4(M2D_RS(O.residual), voff);
+              x.x += r4.x; x.y += r4.y; x.z += r4.z; x.w += r4.w;
+            }
+            const unsigned kb = keep >> (4 * qq);
+            x.x *= (kb & 1u) ? 1.f : ms; x.y *= (kb & 2u) ? 1.f : ms; x.z *= (kb & 4u) ? 1.f : ms; x.w *= (kb & 8u) ? 1.f : ms;
+            if (has_res && !O.mask_last) {
+              const float4 r4 = m2d_bload4(M2D_RS(O.residual), voff);
+              const float4 sum = make_float4(x.x + r4.x, x.y + r4.y, x.z + r4.z, x.w + r4.w);
+              if (two_out) m2d_bstore4(M2D_RS(O.sum_out), voff, sum);
+              else x = sum;
+            }
+            m2d_bstore4(M2D_RS(out_base), voff, x);
+            if (stats) {  // this tile's 32 columns of the row: the 8 lanes that share it; one partial per (row, 32-column tile)
+              a1 = ok ? (x.x + x.y) + (x.z + x.w) : 0.f;
+              a2 = ok ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : 0.f;
+#pragma unroll
+              for (int off = 4; off > 0; off >>= 1) {
+                a1 += __shfl_xor(a1, off, 64);
+                a2 += __shfl_xor(a2, off, 64);
+              }
+              if ((lane & 7) == 0 && row < p.M) {
+                float* dst = O.row_part + ((size_t)(((n0 / BN) * WN + wn) * TN + j0 + jj) * p.M + row) * 2;
+                dst[0] = a1;
+                dst[1] = a2;
+              }
+            }
+          } else {
+            float x = wl[jj * 1024 + rl * 32 + l31];
+            if (redirect && (NT > 1 && jj ? red_t[NT - 1] : red_t[0]) && row < p.M) O.col_out[row] = x;  // raw: a bias gradient
+            if (act == 1) x = x > 0.f ? x : 0.f;
+            else if (act == 2) x = x > 0.f ? x : x * O.slope;
+            if (has_res && O.mask_last) x += m2d_bload(M2D_RS(O.residual), voff, 0);
+            x *= ((keep >> qq) & 1u) ? 1.f : ms;
+            if (has_res && !O.mask_last) {
+              const float sum = x + m2d_bload(M2D_RS(O.residual), voff, 0);
+              if (two_out) m2d_bstore1(M2D_RS(O.sum_out), voff, sum);
+              else x = sum;
+            }
+            m2d_bstore1(M2D_RS(out_base), voff, x);
+            if (stats) {  // the 32 lanes (columns) that share this row; one partial per (row, 32-column tile)
+              a1 = ok ? x : 0.f;
+              a2 = ok ? x * x : 0.f;
+#pragma unroll
+              for (int off = 16; off > 0; off >>= 1) {
+                a1 += __shfl_xor(a1, off, 64);
+                a2 += __shfl_xor(a2, off, 64);
+              }
+              if (l31 == 0 && row < p.M) {
+                float* dst = O.row_part + ((size_t)(((n0 / BN) * WN + wn) * TN + j0 + jj) * p.M + row) * 2;
+                dst[0] = a1;
+                dst[1] = a2;
+              }
+            }
+          }
+        }
       }
       __builtin_amdgcn_wave_barrier();  // the image is read before the next tiles overwrite it (one wave, in order)
     }
   }
+#undef M2D_RS
 }
 
 // Split-K in ONE launch (p.tickets != NULL). Every workgroup stores its partial tile as a register image - the slab
@@ -529,8 +711,6 @@ __device__ __forceinline__ void m2d_tile_epilogue_wide(const M2dGemmParams& p, c
 // accumulators then hold the whole K and the ordinary epilogue runs. Everybody else returns false and leaves.
 // (The separate m2d_splitk_reduce_kernel costs a launch gap plus 8-35 us and reads every slab from a cold grid; here
 // the partials are read by ONE workgroup per tile while they are still in the cache hierarchy.) Launcher: splits <= 16 (more: the separate reduction kernel, one workgroup reading that many images is the slower way).
-typedef unsigned int m2d_u32x4 __attribute__((__vector_size__(16)));
-typedef float m2d_vf32x4 __attribute__((__vector_size__(16)));
 template <int BM, int BN>
 __device__ __forceinline__ bool m2d_splitk_fixup(const M2dGemmParams& p, int split, int tid, volatile int* flag,
                                                  f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
@@ -591,6 +771,26 @@ __device__ __forceinline__ bool m2d_splitk_fixup(const M2dGemmParams& p, int spl
   return true;
 }
 
+#ifdef M2D_STAMP  // diagnostic builds only (tools/probes/gemm_ceiling.hip): where does a workgroup of the LDS-direct kernel spend its time?
+__device__ unsigned long long m2d_stamp_buf[8192 * 4];
+#define M2D_STAMP_AT(i)                                                                                      \
+  do {                                                                                                       \
+    if (threadIdx.x == 0)                                                                                    \
+      m2d_stamp_buf[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 8192 * 4 + (i)] =     \
+          __builtin_amdgcn_s_memrealtime();                                                                  \
+  } while (0)
+extern "C" int m2d_debug_stamps_reset(void) {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(m2d_stamp_buf)) != hipSuccess) return -2;
+  return hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -2;
+}
+extern "C" int m2d_debug_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(m2d_stamp_buf), (size_t)n * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#else
+#define M2D_STAMP_AT(i) do { } while (0)
+#endif
+
 template <int BM, int BN, bool AKF, bool BKF, bool MASKED, bool WIDE>
 __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p) {
   constexpr int LDA = BM + M2D_LDPAD;
@@ -609,6 +809,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   const int wn = wave / WM;
   const int l31 = lane & 31;
   const int lh = lane >> 5;
+  M2D_STAMP_AT(0);
 
   M2dOperand A = p.A;
   M2dOperand B = p.B;
@@ -662,12 +863,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
   if (!B.mask) B.mask_slope = 1.f;
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  m2d_acc_init<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
 
   const int cph = (p.kdiv + M2D_BK - 1) / M2D_BK;  // chunks per hi
   const int nchunks = nhi * cph;
@@ -690,6 +886,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
     tb.template store<LDB>(B, smem + M2D_BK * LDA, tid);
     cc.next();
     __syncthreads();
+    M2D_STAMP_AT(1);
     for (int c = c0; c < c1; ++c) {
       const int cur = (c - c0) & 1;
       // Stage chunk c + 1 (cursor cc) while chunk c is multiplied: its buffer loads are issued
@@ -712,10 +909,15 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
 
   // (two instantiations, not a branch: with both epilogues in one kernel every accumulator stays live across the
   // choice and the kernel needs 30 more registers, i.e. one resident wave per SIMD fewer)
+  M2D_STAMP_AT(2);
   if (p.tickets && !m2d_splitk_fixup<BM, BN>(p, split, tid, reinterpret_cast<volatile int*>(smem), acc)) return;
-  if constexpr (WIDE) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
-  else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+  m2d_tile_epilogue<BM, BN, WIDE>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+#ifdef M2D_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  M2D_STAMP_AT(3);
 }
+
 
 // ---- LDS-direct staging variant ------------------------------------------------------------------------------------
 // Both operands row-fast and unmasked (conv forward / backward-data over the K-major weight image, plain NN GEMMs):
@@ -856,6 +1058,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   const int wn = wave / WM;
   const int l31 = lane & 31;
   const int lh = lane >> 5;
+  M2D_STAMP_AT(0);
 
   M2dOperand A = p.A;
   M2dOperand B = p.B;
@@ -898,12 +1101,16 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   const __amdgpu_buffer_rsrc_t rb = m2d_rsrc(B.base, B.nbytes);
 
   f32x16 acc[TM][TN];
+  if constexpr (EPI == 2) {  // (the quad epilogue adds its bias itself)
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  } else {
+    m2d_acc_init<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+  }
 
   const int cph = (p.kdiv + M2D_BK - 1) / M2D_BK;
   const int nchunks = nhi * cph;
@@ -924,11 +1131,18 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
     cc.next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    M2D_STAMP_AT(1);
     for (int c = c0; c < c1; ++c) {
       const int cur = (c - c0) & 1;
       // chunk c + 1 streams into the other stage (every wave left it at the barrier that ended chunk c - 1) while
       // chunk c is multiplied; the chunk after the last one loads zeros or the next split's data, harmlessly
       float* nxt = smem + (cur ^ 1) * STAGE;
+#ifdef M2D_X_UNIFORM_ONLY  // experiment: the loop without its general path (valid for plain GEMMs with K % 16 == 0)
+      {
+        ta.template load_lds<true, BM>(A, ra, cc.hi, cc.lo0, cc.kdiv, nxt, tid);
+        tb.template load_lds<true, BN>(B, rb, cc.hi, cc.lo0, cc.kdiv, nxt + M2D_BK * BM, tid);
+      }
+#else
       if (cc.uniform()) {
         ta.template load_lds<true, BM>(A, ra, cc.hi, cc.lo0, cc.kdiv, nxt, tid);
         tb.template load_lds<true, BN>(B, rb, cc.hi, cc.lo0, cc.kdiv, nxt + M2D_BK * BM, tid);
@@ -936,18 +1150,27 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
         ta.template load_lds<false, BM>(A, ra, cc.hi, cc.lo0, cc.extent(), nxt, tid);
         tb.template load_lds<false, BN>(B, rb, cc.hi, cc.lo0, cc.extent(), nxt + M2D_BK * BM, tid);
       }
+#endif
       m2d_chunk_mma_dl<BM, BN>(smem + cur * STAGE, wm, wn, l31, lh, acc);
+#ifdef M2D_X_SIMPLE_CURSOR  // experiment: plain GEMM cursor (nhi = 1)
+      cc.lo0 += M2D_BK;
+#else
       cc.next();
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   }
   // (two instantiations, not a branch: with both epilogues in one kernel every accumulator stays live across the
   // choice and the kernel needs 30 more registers, i.e. one resident wave per SIMD fewer)
+  M2D_STAMP_AT(2);
   if (p.tickets && !m2d_splitk_fixup<BM, BN>(p, split, tid, reinterpret_cast<volatile int*>(smem), acc)) return;
-  if constexpr (EPI == 1) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
-  else if constexpr (EPI == 2) m2d_tile_epilogue_quad<BM, BN>(p, O, N, m0, n0, wm, wn, l31, lh, acc);
-  else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+  if constexpr (EPI == 2) m2d_tile_epilogue_quad<BM, BN>(p, O, N, m0, n0, wm, wn, l31, lh, acc);
+  else m2d_tile_epilogue<BM, BN, EPI == 1>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+#ifdef M2D_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  M2D_STAMP_AT(3);
 }
 
 // LDS byte address of a pointer into a __shared__ array, and a 16-byte LDS read the compiler does not see as a memory
@@ -991,6 +1214,7 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
   const int l31 = lane & 31, lh = lane >> 5;
+  M2D_STAMP_AT(0);
   const M2dOperand& A = p.A;
   const M2dOperand& B = p.B;
   const int N = p.N;
@@ -1018,12 +1242,7 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
     posb[h] = rv ? lo * B.r_pos_mul + B.r_pos_off : M2D_BAD;
   }
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  m2d_acc_init<BM, BN>(p, p.O, N, split, m0, n0, wm, wn, l31, lh, acc);
 
   const int ng = p.k4_ng;
   const int nkg = p.nhi * ng;                      // nhi = Cin
@@ -1060,6 +1279,7 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
     stage(smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    M2D_STAMP_AT(1);
     for (int c = c0; c < c1; ++c) {
       const int cur = (c - c0) & 1;
       stage(smem + (cur ^ 1) * STAGE);  // chunk c + 1 (past the end: zeros or the next split's data, harmless)
@@ -1104,9 +1324,13 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
     }
   }
   const M2dOutMap& O = p.O;
+  M2D_STAMP_AT(2);
   if (p.tickets && !m2d_splitk_fixup<BM, BN>(p, split, tid, reinterpret_cast<volatile int*>(smem), acc)) return;
-  if constexpr (WIDE) m2d_tile_epilogue_wide<BM, BN>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
-  else m2d_tile_epilogue<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+  m2d_tile_epilogue<BM, BN, WIDE>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+#ifdef M2D_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  M2D_STAMP_AT(3);
 }
 
 // Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue. Eight
@@ -1500,7 +1724,7 @@ static bool autotune_enabled() {
   return on == 1;
 }
 
-// 16-byte epilogue rows (m2d_tile_epilogue_wide) when the output map allows it (M2D_WIDE_EPILOGUE=0: never)
+// 16-byte epilogue rows (m2d_tile_epilogue, WIDE) when the output map allows it (M2D_WIDE_EPILOGUE=0: never)
 static void decide_wide(M2dGemmParams& p, int splits, const void* ws) {
   static const bool wide_on = [] { const char* e = getenv("M2D_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15u) == 0; };
@@ -1530,6 +1754,16 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
   if (!((a_kfast && !b_kfast) || (!a_kfast && !b_kfast) || (a_kfast && b_kfast)))
     M2D_FAIL(M2D_ERR_ARG, "%s: unsupported operand map combination", what);
   if (p.phases < 1) p.phases = 1;
+  {
+    // the epilogue addresses out / mask / residual / sum_out with 32-bit byte offsets: the map must stay below 2 GiB
+    const M2dOutMap& o = p.O;
+    const long long row_off = o.m_div > 0 ? (long long)((p.M - 1) / o.m_div) * o.m_stride + (long long)(o.m_div - 1) * o.m_lo_stride
+                                          : (long long)(p.M - 1) * o.m_stride;
+    const long long col_off = p.bwd_data ? (long long)(p.ph_batch - 1) * o.c_hi_stride + p.ph_L
+                                         : (long long)((p.N - 1) / (o.cdiv > 0 ? o.cdiv : 1)) * o.c_hi_stride +
+                                               (long long)((o.cdiv > 0 ? o.cdiv : 1) - 1) * o.c_lo_stride + o.c_off;
+    if ((row_off + col_off + 4) * 4 >= 0x7ffffff0LL) M2D_FAIL(M2D_ERR_RANGE, "%s: output larger than 2 GiB", what);
+  }
   // bwd_data: the widest phase has ceil(ks / phases) taps
   const int nhi_max = p.bwd_data ? (p.ph_ks + p.phases - 1) / p.phases : p.nhi;
   const int nchunks = m2d_chunks(nhi_max, p.kdiv);
@@ -1630,7 +1864,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
     if (p.O.row_part) {
       if (!p.O.row_sums) M2D_FAIL(M2D_ERR_ARG, "%s: row statistics without a destination", what);
       // partials per row: one per wave column of every N tile; the 16-byte epilogue writes one per 32-column tile
-      const int wn = p.O.wide ? 4 : (bm >= 64 ? 2 : 4);
+      const int wn = 4;  // one per 32-column tile
       const int rc = m2d_rowsums_reduce(p.O.row_part, m2d_ceil_div(p.N, 128) * wn, p.M, p.O.row_sums,
                                         m2d_rowstats_scratch(p.O.row_part, p.M, p.N), stream);
       if (rc) return rc;
@@ -1683,7 +1917,7 @@ int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_b
     M2D_CHECK_LAUNCH(what);
     if (p.O.row_part) {
       if (!p.O.row_sums) M2D_FAIL(M2D_ERR_ARG, "%s: row statistics without a destination", what);
-      const int wn = p.O.wide ? 4 : 2;
+      const int wn = 4;  // one per 32-column tile
       const int rc = m2d_rowsums_reduce(p.O.row_part, m2d_ceil_div(p.N, 128) * wn, p.M, p.O.row_sums,
                                         m2d_rowstats_scratch(p.O.row_part, p.M, p.N), stream);
       if (rc) return rc;

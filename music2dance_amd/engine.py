@@ -37,6 +37,19 @@ class _Freeze:
             p.requires_grad_(True)
 
 
+def _capture(graph, body, dev, keep, pool=None):
+    """Capture body() into `graph` on a capture stream of its own, with kernel scratch (split-K arrival counters,
+    BatchNorm accumulators) that belongs to this graph alone: captured launches bake the scratch address in, and graphs
+    that replay concurrently (the phase-2 generator forward under the previous body's critic pass) must not count
+    arrivals in each other's words - torch's default is ONE capture stream for every graph, hence one scratch.
+    `keep`: a list that outlives the graph; stream and scratch are parked there."""
+    cap = torch.cuda.Stream(device=dev)
+    scratch = kernels.private_scratch(dev)
+    keep.append((cap, scratch))
+    with scratch, torch.cuda.graph(graph, pool=pool, stream=cap):
+        return body()
+
+
 class WganGpEngine:
     """Common machinery: optimisers, n_critic gating, data-parallel gradient exchange (the critic's
     optimiser step is taken at the start of the next iteration, once its all-reduce has landed),
@@ -403,15 +416,14 @@ class Phase3Engine(WganGpEngine):
         torch.cuda.synchronize(dev)
         self.optim_critic.zero_grad(set_to_none=True)
         self.optim_gen.zero_grad(set_to_none=True)
+        g["keep"] = []
         g["critic"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["critic"]):
-            g["critic_out"] = critic_body()
+        g["critic_out"] = _capture(g["critic"], critic_body, dev, g["keep"])
         # the gradient tensors live in this graph's private pool: a graph captured later for another
         # shape allocates its own, so each replay re-binds p.grad to the set it writes
         g["critic_grads"] = [p.grad for p in self.critic.parameters()]
         g["gen"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["gen"], pool=g["critic"].pool()):
-            g["gen_out"] = gen_body()
+        g["gen_out"] = _capture(g["gen"], gen_body, dev, g["keep"], pool=g["critic"].pool())
         g["gen_grads"] = [p.grad for p in self.gen.parameters()]
         with torch.no_grad():
             for m, bufs in zip(mods, saved):
@@ -628,16 +640,14 @@ class Phase2Engine(WganGpEngine):
         # a memory pool of its own (graphs that share a pool reuse each other's freed intermediates, which is only
         # safe when they never overlap - sharing one here let the critic overwrite the recurrent layers' outputs
         # under the running GRU kernel, which then spun on its hand-off sentinel until the timeout)
+        g["keep"] = []
         g["fwd"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["fwd"]):
-            g["fake_out"] = fwd_body()
+        g["fake_out"] = _capture(g["fwd"], fwd_body, dev, g["keep"])
         g["critic"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["critic"]):
-            g["critic_out"] = critic_body()
+        g["critic_out"] = _capture(g["critic"], critic_body, dev, g["keep"])
         g["critic_grads"] = [p.grad for p in self.critic.parameters()]
         g["gen"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["gen"], pool=g["critic"].pool()):
-            g["gen_out"] = gen_body()
+        g["gen_out"] = _capture(g["gen"], gen_body, dev, g["keep"], pool=g["critic"].pool())
         g["gen_grads"] = [p.grad for p in self.gen.parameters()]
         with torch.no_grad():
             for m, bufs in zip(mods, saved):
@@ -772,13 +782,12 @@ class Phase1Engine(WganGpEngine):
         torch.cuda.synchronize(dev)
         self.optim_critic.zero_grad(set_to_none=True)
         self.optim_gen.zero_grad(set_to_none=True)
+        g["keep"] = []
         g["critic"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["critic"]):
-            g["critic_out"] = critic_body()
+        g["critic_out"] = _capture(g["critic"], critic_body, dev, g["keep"])
         g["critic_grads"] = [p.grad for p in self.critic.parameters()]
         g["gen"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["gen"], pool=g["critic"].pool()):
-            g["gen_out"] = gen_body()
+        g["gen_out"] = _capture(g["gen"], gen_body, dev, g["keep"], pool=g["critic"].pool())
         g["gen_grads"] = [p.grad for p in self.gen.parameters()]
         with torch.no_grad():
             for m, bufs in zip(mods, saved):

@@ -54,16 +54,26 @@ def _chk_track(track, dev, T, hop, window):
 
 _STREAM_SCRATCH = {}
 _FUSED_SPLITK = os.environ.get("M2D_FUSED_SPLITK", "1") != "0"
+_TICKET_WORDS = 16384   # 4 bytes per output tile of a split-K launch (include/m2d.h: 64 KB covers every shape)
+_BN_MAX_C = 4096        # widest channel / feature count a reducing call may have (the reference's widest: 1024)
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 def _stream(dev):
     # raw hipStream_t of the current stream without building a torch.cuda.Stream object
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     s = torch._C._cuda_getCurrentRawStream(idx)
-    if _FUSED_SPLITK and (idx, s) not in _STREAM_SCRATCH:
+    if _PRIVATE is not None:
+        _PRIVATE.adopt((idx, s))
+    elif _FUSED_SPLITK and (idx, s) not in _STREAM_SCRATCH and not _capturing():
         # first launch on this stream: its zero-kept ticket scratch (include/m2d.h: m2d_stream_scratch_set) - split-K
-        # launches then finish without the second (reduction) launch
-        t = torch.zeros(16384, dtype=torch.int32, device=dev)
+        # launches then finish without the second (reduction) launch. Never created inside a capture (it would live in
+        # that graph's private pool behind a captured memset): a capture without `private_scratch` keeps the
+        # two-launch split-K, which needs no state.
+        t = torch.zeros(_TICKET_WORDS, dtype=torch.int32, device=dev)
         _STREAM_SCRATCH[(idx, s)] = t
         _lib.check(_lib.lib().m2d_stream_scratch_set(s, t.data_ptr(), t.numel() * 4), "m2d_stream_scratch_set")
     return s
@@ -112,12 +122,89 @@ _BN_SCRATCH = {}
 
 def _bn_scratch(dev, C):
     """The zero-kept accumulator scratch of the reducing BatchNorm / channel-sum calls (include/m2d.h:
-    m2d_bn_scratch_bytes): one per (device, stream), zeroed once here and left zeroed by every call."""
-    key = (dev.index, _stream(dev))
+    m2d_bn_scratch_bytes): one per (device, stream), of FIXED size (captured graphs keep its address: it is never
+    re-allocated), zeroed once here and left zeroed by every call. None inside a capture that has not been given one
+    (`private_scratch`): the call then takes the stateless three-launch form."""
+    if C > _BN_MAX_C:
+        raise _lib.M2dError("reducing call over %d channels: the per-stream scratch holds %d" % (C, _BN_MAX_C))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
     t = _BN_SCRATCH.get(key)
-    if t is None or t.numel() * 8 < 16 * C + 64:
-        t = _BN_SCRATCH[key] = torch.zeros((2 * max(C, 1024) + 8,), dtype=torch.float64, device=dev)
+    if t is None:
+        if _capturing() or _PRIVATE is not None:
+            return None
+        t = _BN_SCRATCH[key] = torch.zeros((2 * _BN_MAX_C + 8,), dtype=torch.float64, device=dev)
     return t
+
+
+_PRIVATE = None   # the private_scratch scope being captured under, if any
+
+
+class private_scratch:
+    """Scope for CAPTURING a graph: launches made inside it - on the capture stream and on every stream forked from it -
+    take their zero-kept scratch (split-K tickets, BatchNorm / channel-sum accumulators) from buffers owned by this
+    object instead of the streams' own. A captured launch bakes the scratch ADDRESS in; two graphs captured on one
+    stream (torch captures every graph on the same class-level stream by default) would otherwise share it, and
+    replaying them concurrently - the phase-2 generator-forward graph runs on the generator stream under the critic
+    graph of the previous body - has both sets of kernels counting arrivals in the same words. Keep the object alive
+    as long as the graph. Everything is allocated in __init__, i.e. outside the capture: `nstreams` sets (the capture
+    stream + the side streams the modules fork); a further stream gets none and its calls take the stateless forms."""
+
+    def __init__(self, dev, nstreams=4):
+        self.dev = dev
+        self.free = [(torch.zeros(_TICKET_WORDS, dtype=torch.int32, device=dev) if _FUSED_SPLITK else None,
+                      torch.zeros((2 * _BN_MAX_C + 8,), dtype=torch.float64, device=dev)) for _ in range(nstreams)]
+        self.by_stream = {}
+        self.saved = {}
+
+    @staticmethod
+    def _register(raw, t):
+        if t is None:
+            _lib.check(_lib.lib().m2d_stream_scratch_set(raw, None, 0), "m2d_stream_scratch_set")
+        else:
+            _lib.check(_lib.lib().m2d_stream_scratch_set(raw, t.data_ptr(), t.numel() * 4), "m2d_stream_scratch_set")
+
+    def adopt(self, key):
+        """First launch on stream `key` = (device index, raw stream) inside the scope: give it one of the sets."""
+        if key in self.by_stream:
+            return
+        pair = self.free.pop() if self.free else (None, None)
+        self.by_stream[key] = pair
+        self.saved[key] = (_STREAM_SCRATCH.get(key), _BN_SCRATCH.get(key))
+        for table, t in ((_STREAM_SCRATCH, pair[0]), (_BN_SCRATCH, pair[1])):
+            if t is None:
+                table.pop(key, None)
+            else:
+                table[key] = t
+        if _FUSED_SPLITK:
+            self._register(key[1], pair[0])
+
+    def __enter__(self):
+        global _PRIVATE
+        self._outer, _PRIVATE = _PRIVATE, self
+        return self
+
+    def __exit__(self, *exc):
+        global _PRIVATE
+        _PRIVATE = self._outer
+        for key, (old_t, old_b) in self.saved.items():
+            for table, t in ((_STREAM_SCRATCH, old_t), (_BN_SCRATCH, old_b)):
+                if t is None:
+                    table.pop(key, None)
+                else:
+                    table[key] = t
+            if _FUSED_SPLITK:
+                self._register(key[1], old_t)
+        self.saved = {}
+        return False
+
+
+def reset_scratch():
+    """Re-zero every zero-kept scratch buffer of the streams' own (not the graphs' private ones). A launch that was
+    aborted mid-way (device fault, a persistent kernel's timeout) can leave arrival counters or accumulators non-zero,
+    which would silently corrupt every later reducing / split-K call on that stream: callers that detect such an
+    error call this AFTER synchronising the device."""
+    for t in list(_STREAM_SCRATCH.values()) + list(_BN_SCRATCH.values()):
+        t.zero_()
 
 
 def conv_out_len(L, ks, stride, pad):

@@ -19,7 +19,7 @@ for g in sorted(glob.glob(root + '/g*')):
             dur[int(r['Dispatch_Id'])] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 out = []
 for k, v in rows.items():
-    if 'm2d' not in v["kernel"]:
+    if not any(t in v["kernel"] for t in ('m2d', 'k_dl', 'k_guide')):  # (k_*: the kernels of tools/probes/gemm_ceiling.hip)
         continue
     e = {"dispatch": k, "kernel": v["kernel"], "workgroups": v["grid"] // 256, "us": round(dur.get(k, 0.0), 1)}
     gui = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0

@@ -16,6 +16,7 @@
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_ceiling.bin gemm_ceiling.hip -L../../music2dance_amd/lib
 //          -lm2d_hip -Wl,-rpath,'$ORIGIN/../../music2dance_amd/lib'
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -69,9 +70,15 @@ __device__ __forceinline__ void stamp(const Args& a, int which) {
     if (threadIdx.x == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
       const unsigned long long r = __builtin_amdgcn_s_memrealtime();
-      a.stamps[(size_t)blockIdx.x * 4 + which * 2] = t;
-      a.stamps[(size_t)blockIdx.x * 4 + which * 2 + 1] = r;
+      a.stamps[(size_t)blockIdx.x * 8 + which * 2] = t;
+      a.stamps[(size_t)blockIdx.x * 8 + which * 2 + 1] = r;
     }
+  }
+}
+template <bool STAMP>
+__device__ __forceinline__ void stamp_rt(const Args& a, int slot) {   // realtime only: kernel entry (4), after the stores (5)
+  if constexpr (STAMP) {
+    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -152,6 +159,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) k_dl(const Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WGM, wn = wave / WGM;
   const int l31 = lane & 31, lh = lane >> 5;
+  stamp_rt<STAMP>(a, 4);
   int m0, n0;
   tile_of(a, BM, BN, m0, n0);
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, (short)0, (int)((size_t)a.M * a.K * 4), 0x00020000);
@@ -265,6 +273,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) k_dl(const Args a) {
         *reinterpret_cast<fvb*>(a.C + (size_t)row * a.N + n0 + wn * (TN * 32) + TN * l31) = v;
       }
   }
+  if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp_rt<STAMP>(a, 5);
 }
 
 
@@ -401,6 +411,7 @@ struct Variant {
   void (*launch)(const Args&, bool stamped, hipStream_t);
   int bm, bn, map;
   bool engine;
+  int (*stamps)(unsigned long long*, int) = nullptr;
 };
 
 template <int BM, int BN, int WGM, int WGN, int BK, int DMA, int FRAG, int MINW = 1, bool PIN = false>
@@ -427,6 +438,16 @@ static void launch_engine(const Args& a, bool, hipStream_t s) {
   if (rc) { fprintf(stderr, "m2d_gemm failed: %d\n", rc); exit(1); }
 }
 
+// experiment builds of the engine (M2D_PROBE_LIBS = colon-separated paths of other libm2d_hip builds): m2d_gemm of each
+typedef int (*gemm_fn)(int, const float*, const float*, const float*, float*, int, int, int, int, float, const float*, float,
+                       const float*, float, void*, size_t, void*);
+static gemm_fn g_xfn[4];
+template <int I>
+static void launch_engine_x(const Args& a, bool, hipStream_t s) {
+  const int rc = g_xfn[I](2, a.A, a.B, nullptr, a.C, a.M, a.N, a.K, 0, 0.f, nullptr, 0.f, nullptr, 0.f, g_ws, g_ws_bytes, (void*)s);
+  if (rc) { fprintf(stderr, "m2d_gemm (variant %d) failed: %d\n", I, rc); exit(1); }
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
   const int rounds = argc > 4 ? atoi(argv[4]) : 7;
@@ -443,10 +464,28 @@ int main(int argc, char** argv) {
   if (g_ws_bytes) hipMalloc(&g_ws, g_ws_bytes);
   unsigned long long* dStamps;
   const size_t max_wg = (size_t)(M / 64) * (N / 64);
-  hipMalloc(&dStamps, max_wg * 4 * sizeof(unsigned long long));
+  hipMalloc(&dStamps, max_wg * 8 * sizeof(unsigned long long));
 
   std::vector<Variant> v;
   v.push_back({"engine m2d_gemm(mode 2)", launch_engine, 128, 128, 0, true});
+  if (const char* libs = getenv("M2D_PROBE_LIBS")) {
+    std::string all(libs);
+    size_t pos = 0;
+    int n = 0;
+    void (*lx[4])(const Args&, bool, hipStream_t) = {launch_engine_x<0>, launch_engine_x<1>, launch_engine_x<2>, launch_engine_x<3>};
+    while (pos <= all.size() && n < 4) {
+      const size_t e = all.find(':', pos);
+      const std::string path = all.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+      pos = e == std::string::npos ? all.size() + 1 : e + 1;
+      if (path.empty()) continue;
+      void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+      if (!h) { fprintf(stderr, "dlopen %s: %s\n", path.c_str(), dlerror()); return 1; }
+      g_xfn[n] = (gemm_fn)dlsym(h, "m2d_gemm");
+      v.push_back({"engine build " + path.substr(path.rfind('/') + 1), lx[n], 128, 128, 0, true});
+      v.back().stamps = (int (*)(unsigned long long*, int))dlsym(h, "m2d_debug_stamps");
+      ++n;
+    }
+  }
   v.push_back({"guide 128x128x32 reg-staged, no pipelining", launch_guide, 128, 128, 0, false});
   const int set = argc > 5 ? atoi(argv[5]) : 1;
   if (set == 0) {
@@ -461,6 +500,9 @@ int main(int argc, char** argv) {
       v.push_back({"dl 256x256x16 4x2 dma16 frag1 (8 waves)" + ms, launch_dl<256, 256, 4, 2, 16, 16, 1>, 256, 256, map, false});
       v.push_back({"dl 256x256x16 2x2 dma16 frag1 (4 waves)" + ms, launch_dl<256, 256, 2, 2, 16, 16, 1>, 256, 256, map, false});
     }
+  } else if (set == 2) {
+    v.push_back({"dl 128x128x16 dma4 frag0 minw2 + pinned", launch_dl<128, 128, 2, 2, 16, 4, 0, 2, true>, 128, 128, 0, false});
+    v.push_back({"dl 128x128x16 dma16 frag1 minw2", launch_dl<128, 128, 2, 2, 16, 16, 1, 2>, 128, 128, 0, false});
   } else {
     // set 1: what separates the engine's LDS-direct kernel (same tile, same DMA count) from the plain dl kernel?
     v.push_back({"dl 128x128x16 dma4 frag0 (AGPR acc)", launch_dl<128, 128, 2, 2, 16, 4, 0>, 128, 128, 0, false});
@@ -524,25 +566,59 @@ int main(int argc, char** argv) {
     const float mn = t[i].front(), med = t[i][t[i].size() / 2];
     printf("%-56s %9.1f %9.1f %9.1f\n", v[i].name.c_str(), mn * 1e3, med * 1e3, flop / (med * 1e-3) / 1e12);
   }
+  // phase stamps of the engine's LDS-direct kernel (M2D_STAMP builds among M2D_PROBE_LIBS export m2d_debug_stamps):
+  // per workgroup s_memrealtime (100 MHz) at kernel entry, loop entry, loop exit, after the epilogue's stores
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (!v[i].engine || !v[i].stamps) continue;
+    a.C = dC; a.map = 0;
+    for (int q = 0; q < 20; ++q) v[i].launch(a, false, 0);
+    hipDeviceSynchronize();
+    const int wg = (M / 128) * (N / 128);
+    std::vector<unsigned long long> st(wg * 4);
+    if (v[i].stamps(st.data(), wg)) { printf("stamps: copy failed\n"); continue; }
+    unsigned long long t0 = ~0ull, t3 = 0;
+    for (int w = 0; w < wg; ++w) { t0 = std::min(t0, st[w * 4]); t3 = std::max(t3, st[w * 4 + 3]); }
+    std::vector<double> start, pro, loop, epi;
+    for (int w = 0; w < wg; ++w) {
+      start.push_back((st[w * 4] - t0) * 0.01); pro.push_back((st[w * 4 + 1] - st[w * 4]) * 0.01);
+      loop.push_back((st[w * 4 + 2] - st[w * 4 + 1]) * 0.01); epi.push_back((st[w * 4 + 3] - st[w * 4 + 2]) * 0.01);
+    }
+    auto q3 = [](std::vector<double> x) { std::sort(x.begin(), x.end()); char b[96]; snprintf(b, 96, "min %.1f med %.1f max %.1f", x.front(), x[x.size() / 2], x.back()); return std::string(b); };
+    printf("\n%s: kernel span %.1f us over %d workgroups\n  start offset us: %s\n  prologue us: %s\n  loop us: %s\n  epilogue us: %s\n", v[i].name.c_str(),
+           (t3 - t0) * 0.01, wg, q3(start).c_str(), q3(pro).c_str(), q3(loop).c_str(), q3(epi).c_str());
+  }
   // in-kernel clock: >= 2 s of back-to-back launches of the variant, then one stamped launch
   printf("\n%-56s %9s\n", "variant", "clock GHz (median over workgroups, stamped build)");
-  std::vector<unsigned long long> hs(max_wg * 4);
+  std::vector<unsigned long long> hs(max_wg * 8);
   for (size_t i = 0; i < v.size(); ++i) {
     if (v[i].engine) continue;
     a.C = dC; a.map = v[i].map;
     const int n = (int)(2.0e3 / t[i][t[i].size() / 2]) + 1;
     for (int q = 0; q < n; ++q) v[i].launch(a, false, 0);
+    hipMemsetAsync(dStamps, 0, max_wg * 8 * sizeof(unsigned long long), 0);
     v[i].launch(a, true, 0);
     hipDeviceSynchronize();
     const size_t wg = (size_t)(M / v[i].bm) * (N / v[i].bn);
-    hipMemcpy(hs.data(), dStamps, wg * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    hipMemcpy(hs.data(), dStamps, wg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     std::vector<double> ghz;
     for (size_t w = 0; w < wg; ++w) {
-      const double dt = (double)(hs[w * 4 + 2] - hs[w * 4]), dr = (double)(hs[w * 4 + 3] - hs[w * 4 + 1]);
+      const double dt = (double)(hs[w * 8 + 2] - hs[w * 8]), dr = (double)(hs[w * 8 + 3] - hs[w * 8 + 1]);
       if (dr > 0) ghz.push_back(dt / dr * 0.1);
     }
     std::sort(ghz.begin(), ghz.end());
-    printf("%-56s %9.3f\n", v[i].name.c_str(), ghz.empty() ? 0.0 : ghz[ghz.size() / 2]);
+    printf("%-56s %9.3f", v[i].name.c_str(), ghz.empty() ? 0.0 : ghz[ghz.size() / 2]);
+    if (hs[5]) {   // phase stamps (k_dl): entry, loop entry, loop exit, after the stores
+      unsigned long long t0 = ~0ull, t3 = 0;
+      for (size_t w = 0; w < wg; ++w) { t0 = std::min(t0, hs[w * 8 + 4]); t3 = std::max(t3, hs[w * 8 + 5]); }
+      std::vector<double> start, pro, loop, epi;
+      for (size_t w = 0; w < wg; ++w) {
+        start.push_back((hs[w * 8 + 4] - t0) * 0.01); pro.push_back((hs[w * 8 + 1] - hs[w * 8 + 4]) * 0.01);
+        loop.push_back((hs[w * 8 + 3] - hs[w * 8 + 1]) * 0.01); epi.push_back((hs[w * 8 + 5] - hs[w * 8 + 3]) * 0.01);
+      }
+      auto q3 = [](std::vector<double> x) { std::sort(x.begin(), x.end()); char b[96]; snprintf(b, 96, "%.1f/%.1f/%.1f", x.front(), x[x.size() / 2], x.back()); return std::string(b); };
+      printf("   span %.1f us; min/med/max us: start %s, prologue %s, loop %s, epilogue %s", (t3 - t0) * 0.01, q3(start).c_str(), q3(pro).c_str(), q3(loop).c_str(), q3(epi).c_str());
+    }
+    printf("\n");
   }
   return 0;
 }
