@@ -22,3 +22,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Worst errors the parity tests recorded (tests call `note(key, value)` of their module's WORST dict): printed
+    with every run so that the driver's record shows how far inside its bounds each case landed."""
+    rows = []
+    for name, mod in list(sys.modules.items()):
+        if name.startswith("tests.") or name.startswith("test_"):
+            w = getattr(mod, "WORST", None)
+            if isinstance(w, dict):
+                rows += sorted(w.items())
+    if rows:
+        terminalreporter.section("worst errors recorded by the parity tests")
+        for key, val in rows:
+            terminalreporter.write_line("%.3e  %s" % (val, key))

@@ -108,10 +108,25 @@ def test_phase2_critic(dev, lp):
     _compare(critic, real, fake_rows, alpha, None, 10.0, lp, 2e-4 if dev.type == "cuda" else 1e-5)
 
 
-def test_tanh_heads_keep_the_autograd_path():
-    critic = p3.AblatedSequenceDiscriminator(69, 8, 6, 20, activ="tanh", device="cpu")
-    assert not CriticStep.supports(critic)
+def test_tanh_heads_are_supported():
+    assert CriticStep.supports(p3.AblatedSequenceDiscriminator(69, 8, 6, 20, activ="tanh", device="cpu"))
     assert CriticStep.supports(p3.AblatedSequenceDiscriminator(69, 8, 6, 20, activ="relu", device="cpu"))
+
+
+def test_phase3_two_branch_critic_with_tanh_heads(dev):
+    """`activ: tanh` (phase3/configs/tanh.yaml): the penalty's double backward through tanh - the tangent times
+    (1 - e^2) plus the tanh'' cotangent chain on the 4B-row layout - against autograd through ops.tanh."""
+    torch.manual_seed(0)
+    critic = p3.SequenceDiscriminator(69, 16, 12, 120, init_ker=25, activ="tanh", device="cpu").to(dev)
+    real, fake_rows, alpha, audio = _inputs(2, 120, dev)
+    _compare(critic, real, fake_rows, alpha, audio, 10.0, False, 2e-4 if dev.type == "cuda" else 1e-5)
+
+
+def test_phase3_ablated_critic_with_tanh_head(dev):
+    torch.manual_seed(1)
+    critic = p3.AblatedSequenceDiscriminator(69, 16, 12, 40, init_ker=25, activ="tanh", device="cpu").to(dev)
+    real, fake_rows, alpha, _ = _inputs(3, 40, dev, audio=False)
+    _compare(critic, real, fake_rows, alpha, None, 10.0, False, 2e-4 if dev.type == "cuda" else 1e-5)
 
 
 @pytest.mark.gpu
@@ -124,6 +139,19 @@ def test_full_size_batch_64_matches_autograd():
     with kernels.impl().weight_cache():
         worst = _compare(critic, real, fake_rows, alpha, audio, 10.0, False, 1e-3, flips=True)
     print("manual vs autograd at B=64: worst element error relative to the tensor's largest: %.2e" % worst)
+
+
+@pytest.mark.gpu
+def test_full_size_batch_64_tanh_critic_matches_autograd():
+    """The tanh critic at BASELINE configs[2]'s size (B = 64, 120 frames)."""
+    import bench
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    critic = p3.SequenceDiscriminator(69, 128, 100, 120, init_ker=25, activ="tanh", device="cpu").to(dev)
+    real, fake_rows, alpha, audio = _inputs(64, 120, dev, seed=9)
+    with kernels.impl().weight_cache():
+        worst = _compare(critic, real, fake_rows, alpha, audio, 10.0, False, 1e-3, flips=True)
+    print("tanh critic, manual vs autograd at B=64: worst element error relative to the tensor's largest: %.2e" % worst)
 
 
 @pytest.mark.gpu

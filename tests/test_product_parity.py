@@ -77,10 +77,20 @@ def grad_norms(module):
                      for _, p in module.named_parameters()])
 
 
-def norms_close(got, want, rtol=2e-3):
+WORST = {}   # per test: the worst errors seen (printed in the terminal summary by tests/conftest.py)
+
+
+def note(key, value):
+    WORST[key] = max(WORST.get(key, 0.0), float(value))
+
+
+def norms_close(got, want, rtol=2e-3, what="gradient norms"):
     assert np.array_equal(np.isnan(got), np.isnan(want)), "set of parameters without gradient differs"
     m = ~np.isnan(want)
-    np.testing.assert_allclose(got[m], want[m], rtol=rtol, atol=1e-6 * np.nanmax(want))
+    atol = 1e-6 * np.nanmax(want)
+    rel = np.abs(got[m] - want[m]) / np.maximum(np.abs(want[m]), atol / rtol)
+    note(os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + " " + what + " (worst relative error)", rel.max())
+    np.testing.assert_allclose(got[m], want[m], rtol=rtol, atol=atol)
 
 
 # Biases that feed a BatchNorm directly have an exactly-zero gradient; what the kernels produce for
@@ -302,7 +312,13 @@ def test_p3(dev, case):
     gen.zero_grad()
     err_gen.backward()
     close(l1, fx["err_l1"], 2e-5), close(err_gen, fx["err_gen"])
-    norms_close(grad_norms(gen), fx["gen_grad_norms"])
+    # The U-Net generator at fixture size (2 x T windows) is a chain of max-pools and ReLUs over a handful of samples: a
+    # pre-activation or a pair of pooled neighbours within fp32 rounding of each other lands on the other side in a
+    # different (equally valid) summation order, and ONE such flip moves a layer's gradient norm by 1e-3 .. 4e-3.
+    # Observed over builds of the same arithmetic (epilogue forms, staging variants): 6e-4, 7.5e-4, 1.0e-3, 1.45e-3,
+    # 3.8e-3 - discrete outcomes, not a drift. Hence 5e-3 here (the bound of the full-size generator check) and 2e-3
+    # for the encoders without pooling.
+    norms_close(grad_norms(gen), fx["gen_grad_norms"], rtol=5e-3 if enc == "unet" else 2e-3, what="generator gradient norms")
 
 
 @pytest.mark.parametrize("case", [("default", "id", False), ("wavegan", "id", False), ("unet", "id", True)],
