@@ -469,15 +469,22 @@ _sync_counts = {}
 
 def _global_count(local_count, device):
     """Elements per channel over ALL ranks. Reduced once per distinct local count (a host read, i.e. a device sync: not
-    something to do per layer and step) and cached: correct for equal shards and for a partial last batch that is
-    partial on every rank alike; ranks whose shard sizes vary independently of their own size are not supported."""
+    something to do per layer and step) and cached - which is only sound when every rank sees the same sequence of
+    local counts (a rank with a cached value skips the collective another rank would wait in for ever). So EQUAL shards
+    are required and checked: the first reduction of a count must return count x world size, else this raises on every
+    rank at once (use drop_last / equal per-rank batches with synchronised BatchNorm)."""
     import torch.distributed as dist
     key = (float(local_count), id(_sync_bn["group"]))
     g = _sync_counts.get(key)
     if g is None:
         t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_sync_bn["group"])
-        g = _sync_counts[key] = float(t.item())
+        g = float(t.item())
+        world = dist.get_world_size(_sync_bn["group"])
+        if abs(g - float(local_count) * world) > 0.5:
+            raise RuntimeError("synchronised BatchNorm needs equal shards on every rank: this rank has %d elements per "
+                               "channel, all %d ranks together %d" % (int(local_count), world, int(g)))
+        _sync_counts[key] = g
     return g
 
 

@@ -206,6 +206,26 @@ def case_p2(R):
         out["trace_" + k] = np.array(v)
     out["gen_final_sum"] = P.sd_checksums(gen.state_dict())
     out["critic_final_sum"] = P.sd_checksums(critic.state_dict())
+    # and a SHORT trace at the config's own learning rate (phase2/configs/default.yaml: 5e-4), three critic iterations:
+    # the run the reference actually makes, compared before the divergence described above sets in
+    load_filled(gen, 3000); load_filled(critic, 4000)
+    opt_d = torch.optim.Adam(critic.parameters(), lr=5e-4)
+    torch.manual_seed(8)
+    tr = {"loss_critic": [], "gp": [], "w_dist": []}
+    for it in range(3):
+        opt_d.zero_grad()
+        nz = torch.randn(B, T, 50)
+        fake = gen(nz, [T] * B).view(B, T, 69).permute(0, 2, 1).contiguous()
+        gp = R["losses"].gradient_penalty(critic, B, real_c, fake, is_seq=True, lp=True)
+        err_real = critic(real_c).mean(); err_fake = critic(fake.detach()).mean()
+        err_critic = err_fake - err_real + 10 * gp
+        tr["loss_critic"].append(err_critic.item()); tr["gp"].append(gp.item())
+        tr["w_dist"].append((err_fake - err_real).item())
+        err_critic.backward(retain_graph=True)
+        opt_d.step()
+    for k, v in tr.items():
+        out["trace5e4_" + k] = np.array(v)
+    out["critic_final_sum_5e4"] = P.sd_checksums(critic.state_dict())
     save("p2", **out)
 
 
@@ -438,6 +458,10 @@ def case_data(R):
 def main():
     torch.set_num_threads(8)
     R = import_reference()
+    if len(sys.argv) > 1:   # regenerate single cases: python make_golden.py p2 ...
+        for name in sys.argv[1:]:
+            {"init": case_init, "data": case_data, "p1": case_p1, "p2": case_p2}[name](R)
+        return
     case_init(R)
     case_data(R)
     case_p1(R)

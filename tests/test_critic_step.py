@@ -185,6 +185,44 @@ def test_phase2_captured_graphs_equal_eager():
 
 
 @pytest.mark.gpu
+def test_phase2_graph_replays_without_host_syncs_equal_eager():
+    """48 loop bodies with NO host read between them: the generator-forward graph of body i + 1 then really runs on the
+    generator stream underneath the critic graph of body i (a float() per step, as in the test above, serialises the two
+    streams). Both graphs count split-K arrivals and BatchNorm / channel sums in zero-kept scratch; captured on torch's
+    one capture stream they shared it (round-3 advice: wrong sums, scratch left dirty) - each graph now owns its scratch
+    (kernels.private_scratch). Compared with the eager engine under the same host draws, at lr 5e-5 (phase 2 at its
+    config's 5e-4 amplifies rounding, see test_product_parity.py)."""
+    from music2dance_amd.engine import Phase2Engine
+    dev = torch.device("cuda:0")
+    cfg = {"lr_gen": 5e-5, "lr_critic": 5e-5, "n_critic_steps": 8, "gamma": 10, "eta": 50, "input_vector_size": 50}
+    real = torch.rand(8, 120, 69, generator=torch.Generator().manual_seed(4)).to(dev)
+    ready = torch.cuda.current_stream(dev).record_event()
+    sigs = []
+    for graphs in (False, True):
+        torch.manual_seed(0)
+        gen = p2.SequenceGenerator(50, 50, 256, 69, 2, 3, dev)
+        critic = p2.SequenceDiscriminator(69, 128, 120, 25, 3, dev)
+        eng = Phase2Engine(gen, critic, cfg, data_parallel=False)
+        if graphs:
+            eng.enable_graphs()
+        torch.manual_seed(21)
+        outs = []
+        for _ in range(48):
+            out = eng.train_step(real, inputs_ready=ready)
+            outs.append(torch.stack([out[k].detach().clone() for k in ("loss_critic", "gp", "w_dist")]))
+        eng.flush()
+        torch.cuda.synchronize()
+        sigs.append((torch.stack(outs).double().cpu(),
+                     [p.detach().double().sum().item() for p in list(critic.parameters()) + list(gen.parameters())]))
+    (o0, s0), (o1, s1) = sigs
+    assert torch.isfinite(o1).all()
+    worst = ((o0 - o1).abs() / o0.abs().clamp_min(1.0)).max().item()
+    assert worst <= 1e-3, "losses over 48 bodies: graphs vs eager differ by %.3e" % worst
+    for a, b in zip(s0, s1):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(a)), (a, b)
+
+
+@pytest.mark.gpu
 def test_phase1_captured_graphs_equal_eager():
     """Phase1Engine.enable_graphs() (round 3): every host draw of a loop body - generator noise, interpolation weights,
     the dropout masks of both networks - goes through a DrawTape and is made again, in the same order on the same

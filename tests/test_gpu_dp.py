@@ -42,23 +42,10 @@ def _watchdog(name, seconds=240):
 
 
 class _Stuck(AssertionError):
-    pass
-
-
-def _retry_stuck(fn):
-    """A worker that sticks (watchdog) or dies without a result is retried ONCE, loudly: one such hang was seen in
-    ~40 full-suite runs (never reproduced alone; the stack dump in gpurun_out/stuck_*.log is the evidence to keep), and a
-    single flake must not take the rest of the `-x` suite with it. A second failure is a failure."""
-    import functools, warnings
-
-    @functools.wraps(fn)
-    def wrapper(*a, **k):
-        try:
-            return fn(*a, **k)
-        except _Stuck as e:
-            warnings.warn("data-parallel GPU test worker stuck, retrying once: %s" % e)
-            return fn(*a, **k)
-    return wrapper
+    """A worker stuck (watchdog) or died without a result. NOT retried (round-3 advice): this code hands data between
+    workgroups with spin loops, zero-kept counters and completion-ordered streams, so an unexplained hang is a finding,
+    not a flake - the run fails and gpurun_out/stuck_*.log holds every thread's stack. Levers for the post-mortem:
+    M2D_FUSED_SPLITK=0, M2D_PERSISTENT_GRU=0, M2D_MANUAL_CRITIC=0."""
 
 
 def _recv(q, procs, n, timeout):
@@ -107,7 +94,6 @@ def _worker(rank, world, port, graphs, q):
 
 
 @pytest.mark.parametrize("graphs", [False, True], ids=["eager", "graphs"])
-@_retry_stuck
 def test_two_ranks_one_gpu(graphs):
     import math
     world, port = 2, _free_port()
@@ -173,7 +159,6 @@ def _rccl_worker(port, q):
     dist.destroy_process_group()
 
 
-@_retry_stuck
 def test_rccl_backend_exchange_world_size_one():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -226,7 +211,6 @@ def _rccl_graphs_worker(port, q):
     dist.destroy_process_group()
 
 
-@_retry_stuck
 def test_rccl_two_shapes_graphs_equal_eager_with_persistent_gru_and_hook_overlap():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

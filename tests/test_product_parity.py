@@ -256,6 +256,33 @@ def test_p2_trace(dev):
     sums_close(critic.state_dict(), fx["critic_final_sum"], adam_lr=lr, adam_steps=8)
 
 
+def test_p2_trace_at_the_config_learning_rate(dev):
+    """Three critic iterations at phase2/configs/default.yaml's own lr 5e-4 (the 8-step trace above runs at 5e-5, off
+    the LP kink's blow-up): the run the reference makes, through the engine's hand-scheduled LP critic iteration.
+    Step 1 is bound like every single evaluation (1e-4); the closed-form critic then amplifies fp32 rounding (the
+    reference against its own fp64 run: 4e-3 by step 3), so steps 2 and 3 get 2e-3 and 1e-2 relative."""
+    fx = load("p2")
+    gen = fill(p2.SequenceGenerator(50, 50, 256, 69, 2, 3, "cpu"), fx, "gen", 3000).to(dev)
+    critic = fill(p2.SequenceDiscriminator(69, 128, 120, 25, 3, "cpu"), fx, "critic", 4000).to(dev)
+    real = P.poses(2, 120, seed=32).to(dev)
+    cfg = {"lr_gen": 5e-4, "lr_critic": 5e-4, "n_critic_steps": 8, "gamma": 10, "eta": 50, "input_vector_size": 50}
+    eng = Phase2Engine(gen, critic, cfg)
+    torch.manual_seed(8)
+    tr = {"loss_critic": [], "gp": [], "w_dist": []}
+    for _ in range(3):
+        out = eng.train_step(real)
+        for k in tr:
+            tr[k].append(out[k].item())
+    eng.flush()
+    for k in tr:
+        want = fx["trace5e4_" + k]
+        for step, rtol in enumerate((1e-4, 2e-3, 1e-2)):
+            err = abs(tr[k][step] - want[step]) / max(1.0, abs(want[step]))
+            note("test_p2_trace_at_the_config_learning_rate[%s] step %d %s (relative error)" % (dev.type, step + 1, k), err)
+            assert err <= rtol, (k, step, tr[k][step], want[step])
+    sums_close(critic.state_dict(), fx["critic_final_sum_5e4"], adam_lr=5e-4, adam_steps=3)
+
+
 # ------------------------------------------------------------------------------ phase 3
 P3_CASES = [("default", "id", False, 120, 2), ("default", "tanh", False, 120, 2), ("default", "relu", True, 120, 2),
             ("wavegan", "id", False, 120, 2), ("wavegan", "tanh", True, 120, 2), ("unet", "id", False, 120, 2),
