@@ -258,6 +258,31 @@ int m2d_jerk_mean_fwd(const float* x, float* out, int B, int C, int T, long sb, 
 int m2d_affine_cols(const float* x, const float* scale, const float* shift, float* y, size_t rows, int cols,
                     void* stream);
 
+/* ---- optimizer step (phase3/train.py:102-103,214,238; phase2/train.py:86-87; phase1/train_wgan-gp.py:60-61) ----
+ * torch.optim.Adam(params, lr) with its defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay, no amsgrad) over
+ * MANY tensors in one launch (per 48 tensors), optionally writing a conv weight's two K-major packed images
+ * (m2d_conv1d_pack_weights) in the same pass - the critic's weights change every loop body, and their images with them:
+ *   m = m + (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g;
+ *   p = p - (lr / bias_corr1) m / (sqrt(v) / bias_corr2_sqrt + eps)
+ * with bias_corr1 = 1 - beta1^step, bias_corr2_sqrt = sqrt(1 - beta2^step) computed by the caller (the arithmetic of
+ * torch's fused implementation). `items`: HOST array of n records; tensors whose gradient is absent are simply not
+ * listed (torch skips them). pack_fwd / pack_bwd (either may be NULL) only for 3-D conv weights
+ * (cout, cin, ks). `skip` (optional): device float; when it is non-zero at execution time the whole step is a no-op -
+ * the hook by which a failed launch upstream (a persistent recurrent kernel that timed out) voids the update on
+ * the device, without a host round trip. */
+typedef struct M2dAdamItem {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  long long numel;
+  float* pack_fwd;   /* (cin, ks, cout) image or NULL */
+  float* pack_bwd;   /* (cout, ks, cin) image or NULL */
+  int cout, cin, ks, reserved;
+} M2dAdamItem;
+int m2d_adam_multi(const M2dAdamItem* items, int n, float lr, float beta1, float beta2, float eps, float bias_corr1,
+                   float bias_corr2_sqrt, const float* skip, void* stream);
+
 /* ---- U-Net encoder resampling (phase3/archis/default.py:235-245) --------------------------- */
 int m2d_maxpool2_fwd(const float* x, float* y, size_t rows, int L, void* stream);
 int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, int L, void* stream);

@@ -17,6 +17,13 @@ _L = _c.c_long
 LIB_PATH = os.environ.get("M2D_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
                                                       "libm2d_hip.so")
 
+class AdamItem(_c.Structure):
+    """struct M2dAdamItem of include/m2d.h (one tensor of a multi-tensor Adam step)"""
+    _fields_ = [("param", _c.c_void_p), ("grad", _c.c_void_p), ("exp_avg", _c.c_void_p), ("exp_avg_sq", _c.c_void_p),
+                ("numel", _c.c_longlong), ("pack_fwd", _c.c_void_p), ("pack_bwd", _c.c_void_p),
+                ("cout", _I), ("cin", _I), ("ks", _I), ("reserved", _I)]
+
+
 # name -> (restype, argtypes); mirrors include/m2d.h line by line
 SIGNATURES = {
     "m2d_last_error": (_c.c_char_p, []),
@@ -74,6 +81,7 @@ SIGNATURES = {
     "m2d_tv_mean_bwd": (_I, [_F, _F, _F, _I, _I, _I, _L, _L, _L, _F]),
     "m2d_jerk_mean_fwd": (_I, [_F, _F, _I, _I, _I, _L, _L, _L, _F, _S, _F]),
     "m2d_affine_cols": (_I, [_F, _F, _F, _F, _S, _I, _F]),
+    "m2d_adam_multi": (_I, [_F, _I, _f, _f, _f, _f, _f, _f, _F, _F]),
     "m2d_maxpool2_fwd": (_I, [_F, _F, _S, _I, _F]),
     "m2d_maxpool2_bwd": (_I, [_F, _F, _F, _S, _I, _F]),
     "m2d_upsample2_fwd": (_I, [_F, _F, _S, _I, _F]),

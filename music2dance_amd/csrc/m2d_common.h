@@ -47,5 +47,17 @@ struct M2dProfScope {
   ~M2dProfScope();
 };
 
+// one tensor of a multi-tensor Adam step: struct M2dAdamItem of include/m2d.h (kept identical)
+typedef struct M2dAdamItem {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  long long numel;
+  float* pack_fwd;
+  float* pack_bwd;
+  int cout, cin, ks, reserved;
+} M2dAdamItem;
+
 static inline int m2d_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long m2d_ceil_div64(long long a, long long b) { return (a + b - 1) / b; }

@@ -217,6 +217,49 @@ __global__ void __launch_bounds__(256) m2d_affine_cols_kernel(const float* x, co
   }
 }
 
+// ---------------------------------------------------------------- multi-tensor Adam (+ packed conv-weight images)
+// One launch steps up to M2D_ADAM_BATCH tensors (their records travel in the kernel arguments, like torch's
+// multi_tensor_apply): a workgroup owns 2 048 consecutive elements of one tensor; 28 algorithmic bytes per element
+// (read p, g, m, v; write p, m, v) + 8 per element of a conv weight whose packed images are refreshed on the way.
+#define M2D_ADAM_BATCH 48
+#define M2D_ADAM_CHUNK 2048
+struct M2dAdamBatch {
+  M2dAdamItem it[M2D_ADAM_BATCH];
+  int first_block[M2D_ADAM_BATCH + 1];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) m2d_adam_multi_kernel(const M2dAdamBatch b, float lr_over_bc1, float beta1, float beta2,
+                                                             float eps, float bc2_sqrt, const float* skip) {
+  if (skip && *skip != 0.f) return;
+  int k = 0;
+  while (k + 1 < b.n && (int)blockIdx.x >= b.first_block[k + 1]) ++k;   // wave-uniform
+  const M2dAdamItem& t = b.it[k];
+  const long long base = (long long)((int)blockIdx.x - b.first_block[k]) * M2D_ADAM_CHUNK;
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+#pragma unroll
+  for (int e = 0; e < M2D_ADAM_CHUNK / 256; ++e) {
+    const long long i = base + e * 256 + threadIdx.x;
+    if (i >= t.numel) break;
+    const float g = t.grad[i];
+    float m = t.exp_avg[i], v = t.exp_avg_sq[i], p = t.param[i];
+    m = m + omb1 * (g - m);
+    v = beta2 * v + omb2 * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - lr_over_bc1 * (m / denom);
+    t.exp_avg[i] = m;
+    t.exp_avg_sq[i] = v;
+    t.param[i] = p;
+    if (t.pack_fwd || t.pack_bwd) {  // (co, ci, kk) -> (ci, kk, co) and (co, kk, ci)
+      const int kk = (int)(i % t.ks);
+      const long long r = i / t.ks;
+      const int ci = (int)(r % t.cin), co = (int)(r / t.cin);
+      if (t.pack_fwd) t.pack_fwd[((long long)ci * t.ks + kk) * t.cout + co] = p;
+      if (t.pack_bwd) t.pack_bwd[((long long)co * t.ks + kk) * t.cin + ci] = p;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- tanh heads (`activ: tanh`)
 // The 'tanh' switch of the encoders / critics (phase3/archis/default.py:75-76,102-103,134-135,309-310,339-340) on
 // the (N, code) head tensors, with the two derivatives the gradient penalty's double backward needs:
@@ -586,6 +629,42 @@ int m2d_affine_cols(const float* x, const float* scale, const float* shift, floa
   hipLaunchKernelGGL(m2d_affine_cols_kernel, dim3(grid_for(rows * (size_t)cols)), dim3(256), 0, stream, x, scale,
                      shift, y, rows, cols);
   M2D_CHECK_LAUNCH("m2d_affine_cols");
+  return M2D_OK;
+}
+
+// torch.optim.Adam's step over many tensors (see include/m2d.h); `items` is a HOST array
+int m2d_adam_multi(const M2dAdamItem* items, int n, float lr, float beta1, float beta2, float eps, float bias_corr1,
+                   float bias_corr2_sqrt, const float* skip, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || (n > 0 && !items) || !(bias_corr1 > 0.f) || !(bias_corr2_sqrt > 0.f))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_adam_multi: bad arguments");
+  double bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const M2dAdamItem& t = items[i];
+    if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq || t.numel < 0)
+      M2D_FAIL(M2D_ERR_ARG, "m2d_adam_multi: item %d has a NULL tensor", i);
+    if ((t.pack_fwd || t.pack_bwd) && (t.cout <= 0 || t.cin <= 0 || t.ks <= 0 || (long long)t.cout * t.cin * t.ks != t.numel))
+      M2D_FAIL(M2D_ERR_ARG, "m2d_adam_multi: item %d: packed images need the (cout, cin, ks) of the weight", i);
+    bytes += 28.0 * (double)t.numel + 4.0 * (double)t.numel * ((t.pack_fwd ? 1 : 0) + (t.pack_bwd ? 1 : 0));
+  }
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, bytes, "adam_multi");
+  for (int i0 = 0; i0 < n;) {
+    M2dAdamBatch b;
+    b.n = 0;
+    int blocks = 0;
+    for (; i0 < n && b.n < M2D_ADAM_BATCH; ++i0) {
+      if (items[i0].numel == 0) continue;
+      b.it[b.n] = items[i0];
+      b.first_block[b.n] = blocks;
+      blocks += (int)((items[i0].numel + M2D_ADAM_CHUNK - 1) / M2D_ADAM_CHUNK);
+      ++b.n;
+    }
+    b.first_block[b.n] = blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(m2d_adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b, lr / bias_corr1, beta1, beta2,
+                       eps, bias_corr2_sqrt, skip);
+    M2D_CHECK_LAUNCH("m2d_adam_multi");
+  }
   return M2D_OK;
 }
 

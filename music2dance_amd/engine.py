@@ -62,13 +62,21 @@ class WganGpEngine:
         self.sync_bn = bool(sync_bn) and ops.set_sync_batchnorm(True)
         self.n_critic_steps = int(n_critic_steps)
         dev = next(critic.parameters()).device
-        kw = {}
-        if fused_adam is None:
-            fused_adam = dev.type == "cuda"
-        if fused_adam:
-            kw["fused"] = True
-        self.optim_critic = optim.Adam(critic.parameters(), lr=lr_critic, **kw)
-        self.optim_gen = optim.Adam(gen.parameters(), lr=lr_gen, **kw)
+        # torch.optim.Adam objects (param_groups, state_dict, schedulers) whose step is ONE multi-tensor HIP launch that
+        # also rewrites the packed images of the conv weights it changes (optim.py; M2D_ADAM=torch: torch's own fused /
+        # foreach implementation - the A/B lever; `fused_adam` then keeps its round-1 meaning)
+        if os.environ.get("M2D_ADAM", "m2d") == "torch":
+            kw = {}
+            if fused_adam is None:
+                fused_adam = dev.type == "cuda"
+            if fused_adam:
+                kw["fused"] = True
+            self.optim_critic = optim.Adam(critic.parameters(), lr=lr_critic, **kw)
+            self.optim_gen = optim.Adam(gen.parameters(), lr=lr_gen, **kw)
+        else:
+            from .optim import Adam as M2dAdam
+            self.optim_critic = M2dAdam(critic.parameters(), lr=lr_critic)
+            self.optim_gen = M2dAdam(gen.parameters(), lr=lr_gen)
         # an optimizer step only invalidates the packed conv-weight images of ITS parameters (the generator's
         # stay valid through the critic iterations of a cycle)
         self._keep_packs = os.environ.get("M2D_KEEP_PACKS", "1") != "0"

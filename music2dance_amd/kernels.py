@@ -248,11 +248,14 @@ class HipKernels:
         if tensors is None:
             self._packed.clear()
         else:
+            kept = getattr(self, "_adam_kept", ())   # (w_fwd, w_bwd) images adam_multi has just rewritten stay
             for w in tensors:
-                self._packed.pop(id(w), None)
+                if id(w) not in kept:
+                    self._packed.pop(id(w), None)
                 self._packed.pop((id(w), "T"), None)
                 for key in [k for k in self._packed if isinstance(k, tuple) and k[0] == id(w)]:
                     self._packed.pop(key, None)
+            self._adam_kept = ()
 
     def packed_weights(self, w):
         """(w_fwd (Cin, ks, Cout), w_bwd (Cout, ks, Cin)): the K-major images of a conv weight the forward / backward-data
@@ -261,7 +264,7 @@ class HipKernels:
         key = id(w)
         if self._cache_depth > 0:
             ent = self._packed.get(key)
-            if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == stream:
+            if ent is not None and ent[0]() is w and ent[1] == w._version and (ent[2] is None or ent[2] == stream):
                 return ent[3], ent[4]
         Cout, Cin, ks = w.shape
         wf = torch.empty((Cin, ks, Cout), dtype=torch.float32, device=w.device)
@@ -563,6 +566,38 @@ class HipKernels:
             rc = _lib.lib().m2d_tanh_bwd_bwd(_ptr(g), _ptr(gy), _ptr(y), _ptr(out), y.numel(), _stream(dev))
         _lib.check(rc, "m2d_tanh_bwd_bwd")
         return out
+
+    def adam_multi(self, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step, skip=None, repack=True):
+        """One torch.optim.Adam step (defaults: no weight decay, no amsgrad) over the listed tensors in one launch per 48
+        (include/m2d.h: m2d_adam_multi). repack: conv weights (3-D, >= 16 input channels) that have live packed images in
+        the weight cache get those images rewritten in the same pass - the cache entries stay valid across the step
+        (the engines call invalidate_packed() for everything else). skip: optional device float (non-zero = no-op)."""
+        if not params:
+            return
+        dev = _chk(*params, *grads, *exp_avgs, *exp_avg_sqs, skip)
+        items = (_lib.AdamItem * len(params))()
+        stream = _stream(dev)
+        keep = []
+        for it, p, g, m, v in zip(items, params, grads, exp_avgs, exp_avg_sqs):
+            assert p.numel() == g.numel() == m.numel() == v.numel()
+            it.param, it.grad, it.exp_avg, it.exp_avg_sq, it.numel = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+            ent = self._packed.get(id(p)) if (repack and p.dim() == 3) else None
+            if ent is not None and ent[0]() is p:
+                # written on THIS stream; consumers on other streams fork behind it (side.wait_stream(main) in the
+                # modules), so the refreshed entry is marked valid for every stream (None)
+                wf, wb = ent[3], ent[4]
+                it.pack_fwd, it.pack_bwd = wf.data_ptr(), wb.data_ptr()
+                it.cout, it.cin, it.ks = p.shape
+                keep.append((id(p), (ent[0], p._version, None, wf, wb)))
+        bc1 = 1.0 - beta1 ** step
+        bc2s = (1.0 - beta2 ** step) ** 0.5
+        with _on(dev):
+            rc = _lib.lib().m2d_adam_multi(ctypes.addressof(items), len(params), lr, beta1, beta2, eps, bc1, bc2s,
+                                           _ptr(skip), stream)
+        _lib.check(rc, "m2d_adam_multi")
+        for key, ent in keep:
+            self._packed[key] = ent
+        self._adam_kept = {k for k, _ in keep}
 
     def transposed(self, w):
         """w.t().contiguous() of a 2-D weight (the GRU kernels read W^T), kept like the packed conv images: built

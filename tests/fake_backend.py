@@ -35,6 +35,18 @@ class FakeKernels:
     def invalidate_packed(self, tensors=None):
         pass
 
+    def adam_multi(self, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step, skip=None, repack=True):
+        """m2d_adam_multi in torch ops (same arithmetic, element-wise)"""
+        if skip is not None and float(skip) != 0.0:
+            return
+        bc1 = 1.0 - beta1 ** step
+        bc2s = (1.0 - beta2 ** step) ** 0.5
+        with torch.no_grad():
+            for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+                m.add_((g - m) * (1.0 - beta1))
+                v.mul_(beta2).add_(g * g * (1.0 - beta2))
+                p.sub_((m / (v.sqrt() / bc2s + eps)) * (lr / bc1))
+
     @staticmethod
     def _into(out, val):
         if out is None:
