@@ -221,6 +221,16 @@ int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float*
                       const float* const* w_hh_t, const float* const* b_hh, float* const* out, float* const* saved,
                       const int* lengths, int B, int T, int H, int L, unsigned* counters, void* stream);
 int m2d_gru_persist_error(void);
+/* Recovery from such a timeout without leaving the process: m2d_gru_persist_peek() reads the word without clearing it,
+ * m2d_async_fault_word() is its device-visible address (or NULL) - passed to m2d_adam_multi as `skip`, every optimizer
+ * step queued behind the failed recurrence voids itself on the device; the host then synchronises, clears the word
+ * (m2d_gru_persist_error) and carries on with the per-step launches (engine.py). m2d_gru_persist_raise(): test hook. */
+int m2d_gru_persist_peek(void);
+void* m2d_async_fault_word(void);
+int m2d_gru_persist_raise(void);
+/* dst[0] (device float) = 1.0 when the word is raised, else 0.0: what a data-parallel gradient exchange adds to its last
+ * bucket so that every rank skips the optimizer steps one rank has to skip (dp.GradExchange.fault_flag). */
+int m2d_fault_fetch(float* dst, void* stream);
 int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* const* saved,
                       const float* const* w_hh, const float* const* w_ih, float* const* dgi, float* const* dgh,
                       float* const* dh_buf, const int* lengths, int B, int T, int H, int L, unsigned* counters,
@@ -267,7 +277,7 @@ int m2d_affine_cols(const float* x, const float* scale, const float* shift, floa
  * with bias_corr1 = 1 - beta1^step, bias_corr2_sqrt = sqrt(1 - beta2^step) computed by the caller (the arithmetic of
  * torch's fused implementation). `items`: HOST array of n records; tensors whose gradient is absent are simply not
  * listed (torch skips them). pack_fwd / pack_bwd (either may be NULL) only for 3-D conv weights
- * (cout, cin, ks). `skip` (optional): device float; when it is non-zero at execution time the whole step is a no-op -
+ * (cout, cin, ks). `skip` (optional): device-visible 32-bit word; when any of its bits is set at execution time the whole step is a no-op -
  * the hook by which a failed launch upstream (a persistent recurrent kernel that timed out) voids the update on
  * the device, without a host round trip. */
 typedef struct M2dAdamItem {

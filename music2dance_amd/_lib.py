@@ -69,6 +69,10 @@ SIGNATURES = {
     "m2d_gru_stack_counters": (_I, [_I, _I]),
     "m2d_gru_stack_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F, _F]),
     "m2d_gru_persist_error": (_I, []),
+    "m2d_gru_persist_peek": (_I, []),
+    "m2d_async_fault_word": (_c.c_void_p, []),
+    "m2d_gru_persist_raise": (_I, []),
+    "m2d_fault_fetch": (_I, [_F, _F]),
     "m2d_gru_stack_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _F, _F]),
     "m2d_gp_interpolate": (_I, [_F, _F, _F, _F, _I, _I, _F]),
     "m2d_gp_penalty_workspace_bytes": (_S, [_I]),

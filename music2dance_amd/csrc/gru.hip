@@ -1071,6 +1071,42 @@ int m2d_gru_persist_error(void) {
   return e ? 1 : 0;
 }
 
+// The same word without clearing it (recovery protocol, engine.py: peek -> device synchronise, so that every queued
+// optimizer step has seen the word and skipped itself -> m2d_gru_persist_error() to clear -> go on with step launches)
+int m2d_gru_persist_peek(void) {
+  GruPersistState* ps = gru_persist_state_peek();
+  if (!ps || !ps->error_host) return 0;
+  return *(volatile unsigned*)ps->error_host ? 1 : 0;
+}
+
+// Device-visible address of that word (mapped pinned host memory), or NULL when the persistent form is not in use:
+// what m2d_adam_multi takes as `skip` - an optimizer step queued behind a recurrence that gave up voids itself.
+void* m2d_async_fault_word(void) {
+  GruPersistState* ps = gru_persist_state();
+  return ps ? (void*)ps->error_dev : nullptr;
+}
+
+// dst[0] = 1.0f when the word is raised, else 0.0f (on `stream`): the form in which a data-parallel gradient exchange
+// carries this rank's state to its peers - one more float in the last bucket, MAX-like after the sum / average.
+__global__ void m2d_fault_fetch_kernel(const unsigned* word, float* dst) {
+  dst[0] = (word && __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) ? 1.f : 0.f;
+}
+int m2d_fault_fetch(float* dst, void* stream) {
+  if (!dst) M2D_FAIL(M2D_ERR_ARG, "m2d_fault_fetch: NULL destination");
+  GruPersistState* ps = gru_persist_state();
+  hipLaunchKernelGGL(m2d_fault_fetch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ps ? ps->error_dev : nullptr, dst);
+  M2D_CHECK_LAUNCH("m2d_fault_fetch");
+  return M2D_OK;
+}
+
+// Test hook: raise the word as a timed-out launch would.
+int m2d_gru_persist_raise(void) {
+  GruPersistState* ps = gru_persist_state();
+  if (!ps || !ps->error_host) return M2D_ERR_ARG;
+  *(volatile unsigned*)ps->error_host = 1u;
+  return M2D_OK;
+}
+
 // BPTT for the whole stack on the anti-diagonal. dgi[l], dgh[l]: (B, T, 3H); dh_buf[l]: 2*B*H floats.
 int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* const* saved,
                       const float* const* w_hh, const float* const* w_ih, float* const* dgi, float* const* dgh,

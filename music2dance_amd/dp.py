@@ -69,6 +69,11 @@ class GradExchange:
         self._hooks = []
         self._suspended = 0
         self.launched_in_backward = 0  # diagnostics: buckets whose all-reduce left before start()
+        # one more float at the end of the LAST bucket: "a recurrent launch of this rank gave up" (kernels.fault_fetch
+        # fills it in before the bucket leaves). Summed / averaged with the gradients it is > 0 on EVERY rank as soon as
+        # one rank raised it: the flag all ranks' optimizers take as their step's `skip` word (fault_flag), so that the
+        # step one rank must void is voided everywhere and the replicas stay identical.
+        self.fault_fetch = None
 
     @property
     def active(self):
@@ -84,7 +89,7 @@ class GradExchange:
     def _bucket(self, i, device):
         if self._flat[i] is None:
             total = sum(p.numel() for p in self.buckets[i])
-            flat = torch.zeros(total, dtype=torch.float32, device=device)
+            flat = torch.zeros(total + (1 if i == len(self.buckets) - 1 else 0), dtype=torch.float32, device=device)
             views, off = [], 0
             for p in self.buckets[i]:
                 views.append(flat[off:off + p.numel()].view(p.shape))
@@ -109,6 +114,11 @@ class GradExchange:
             flat.zero_()  # slots of parameters without a gradient contribute zeros
         if src and not aliased:
             torch._foreach_copy_(dst, src)
+        if i == len(self.buckets) - 1:
+            if self.fault_fetch is not None:
+                self.fault_fetch(flat[-1:])
+            else:
+                flat[-1:].zero_()
         had = [p.grad is not None for p in bucket]
         if stream is not None:
             stream.wait_stream(torch.cuda.current_stream(device))
@@ -117,6 +127,13 @@ class GradExchange:
         else:
             work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         return work, had
+
+    def fault_flag(self, fetch):
+        """Arm the fault slot: `fetch(dst)` writes this rank's state (1.0 / 0.0) into the one-element device tensor dst
+        on the current stream. -> that tensor: after finish() it holds the reduced value (> 0: some rank raised it)."""
+        self.fault_fetch = fetch
+        flat, _ = self._bucket(len(self.buckets) - 1, self.params[0].device)
+        return flat[-1:]
 
     def overlap_backward(self):
         """Arm the backward-overlapped launch: from now on a bucket's all-reduce starts inside backward(),

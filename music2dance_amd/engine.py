@@ -88,6 +88,12 @@ class WganGpEngine:
         self.x_critic = GradExchange(critic.parameters()).overlap_backward() if data_parallel else None
         self.x_gen = GradExchange(gen.parameters()) if data_parallel else None
         self._critic_step_pending = False
+        # a persistent recurrent launch that times out must not take the run with it (_check_async): both optimizers
+        # read the fault word - directly, or (data parallel) as reduced over the ranks by their gradient exchange
+        k = kernels.impl()
+        if hasattr(self.optim_critic, "skip_flag") and hasattr(k, "fault_word") and dev.type == "cuda":
+            for opt, x in ((self.optim_critic, self.x_critic), (self.optim_gen, self.x_gen)):
+                opt.skip_flag = x.fault_flag(k.fault_fetch) if (x is not None and x.active) else k.fault_word()
         # the critic iteration as one hand-scheduled pass (critic_step.py) instead of three autograd passes; engines
         # whose critic qualifies (piecewise-linear heads) build it in their constructor. M2D_MANUAL_CRITIC=0: autograd
         self.manual_critic = None
@@ -204,13 +210,23 @@ class WganGpEngine:
             torch.cuda.synchronize()
         self._check_async()
 
-    @staticmethod
-    def _check_async():
-        # fail loudly if a persistent recurrent launch gave up waiting for its peers (it raises a word in pinned
-        # host memory; reading it costs nothing): the poses of that iteration would be garbage
-        chk = getattr(kernels.impl(), "check_async_errors", None)
-        if chk is not None:
-            chk()
+    def _check_async(self):
+        """A persistent recurrent launch that gave up waiting for its peers (CUs held by another resident kernel - an
+        RCCL collective, another process) raises a word in pinned host memory; reading it costs nothing. Round 3 died
+        here. Now: the optimizers take that word as their step's `skip` flag (optim.Adam / m2d_adam_multi), so every
+        update queued behind the failed launch voids itself ON THE DEVICE; the host, finding the word raised,
+        synchronises, clears it and carries on with per-step recurrent launches (kernels.recover_async_fault). The
+        affected iterations are lost, not the run; `async_faults` counts them. Data-parallel ranks must skip together:
+        there the word travels with every gradient exchange (one more float in the last bucket, dp.GradExchange.fault_flag),
+        and the REDUCED value is what the optimizers read."""
+        k = kernels.impl()
+        rec = getattr(k, "recover_async_fault", None)
+        if rec is None:
+            return
+        if rec():
+            import warnings
+            warnings.warn("a persistent recurrent launch timed out: its iteration(s) were skipped on the device, the "
+                          "recurrences run as per-step launches from here on (%d so far)" % k.async_faults)
 
     def train_step(self, *batch, inputs_ready=None):
         """One loop body of the reference: a critic iteration, plus a generator iteration every

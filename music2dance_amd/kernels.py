@@ -574,7 +574,7 @@ class HipKernels:
         (the engines call invalidate_packed() for everything else). skip: optional device float (non-zero = no-op)."""
         if not params:
             return
-        dev = _chk(*params, *grads, *exp_avgs, *exp_avg_sqs, skip)
+        dev = _chk(*params, *grads, *exp_avgs, *exp_avg_sqs, skip if torch.is_tensor(skip) else None)
         items = (_lib.AdamItem * len(params))()
         stream = _stream(dev)
         keep = []
@@ -593,7 +593,7 @@ class HipKernels:
         bc2s = (1.0 - beta2 ** step) ** 0.5
         with _on(dev):
             rc = _lib.lib().m2d_adam_multi(ctypes.addressof(items), len(params), lr, beta1, beta2, eps, bc1, bc2s,
-                                           _ptr(skip), stream)
+                                           (skip if isinstance(skip, int) else _ptr(skip)) or 0, stream)
         _lib.check(rc, "m2d_adam_multi")
         for key, ent in keep:
             self._packed[key] = ent
@@ -807,7 +807,7 @@ class HipKernels:
         h = _lib.lib()
         # scratch for the persistent form (one launch for the whole recurrence); the library decides
         counters = (torch.empty((h.m2d_gru_stack_counters(B, L),), dtype=torch.int32, device=dev)
-                    if persistent else None)
+                    if (persistent and self.persistent_gru) else None)
         with _on(dev):
             rc = h.m2d_gru_stack_fwd(_ptr(gi0), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
                                      sv[1], _ptr(lengths), B, T, H, L, _ptr(counters), _stream(dev))
@@ -822,6 +822,43 @@ class HipKernels:
             raise _lib.M2dError("persistent GRU launch timed out: outputs of that call are invalid "
                                 "(several processes on one GPU? set M2D_PERSISTENT_GRU=0)")
 
+    # -- recovery from such a timeout inside the process (engine.WganGpEngine._check_async)
+    persistent_gru = True        # False: every recurrence from now on runs as per-step launches
+    async_faults = 0             # timeouts recovered from
+
+    @staticmethod
+    def fault_word():
+        """Device-visible address of the word a persistent recurrence raises when it gives up (or None): the `skip`
+        argument of adam_multi - an optimizer step queued behind the failed launch then voids itself on the device."""
+        return _lib.lib().m2d_async_fault_word() or None
+
+    @staticmethod
+    def fault_fetch(dst):
+        """dst[0] (device float) = 1.0 when that word is raised, else 0.0, on the current stream (dp.GradExchange)"""
+        dev = _chk(dst)
+        with _on(dev):
+            _lib.check(_lib.lib().m2d_fault_fetch(_ptr(dst), _stream(dev)), "m2d_fault_fetch")
+
+    @staticmethod
+    def raise_async_fault():
+        """test hook: raise the word as a timed-out recurrence would"""
+        _lib.check(_lib.lib().m2d_gru_persist_raise(), "m2d_gru_persist_raise")
+
+    @classmethod
+    def recover_async_fault(cls):
+        """-> True when a persistent recurrence had timed out. The word is still raised at this point, so after the
+        device synchronisation made here EVERY optimizer step queued behind the failed launch has skipped itself (no
+        garbage reached the parameters); then the word is cleared, the scratch re-zeroed, and recurrences run as
+        per-step launches from now on (fresh launches - nothing is re-executed, the affected iterations are lost)."""
+        if not _lib.lib().m2d_gru_persist_peek():
+            return False
+        torch.cuda.synchronize()
+        _lib.lib().m2d_gru_persist_error()
+        reset_scratch()
+        cls.persistent_gru = False
+        cls.async_faults += 1
+        return True
+
     def gru_stack_bwd(self, dout, outs, saved, w_hh, w_ih, lengths=None, persistent=True):
         """BPTT of the stack; returns ([dgi_l (B,T,3H)], [dgh_l (B,T,3H)]). persistent: one launch for the whole
         recurrence when the library finds room for it (bit-identical to the step launches)."""
@@ -834,7 +871,7 @@ class HipKernels:
         keep = [self._ptr_array(v) for v in (outs, saved, w_hh, w_ih, dgi, dgh, dhb)]
         h = _lib.lib()
         counters = (torch.empty((h.m2d_gru_stack_counters(B, L),), dtype=torch.int32, device=dev)
-                    if persistent else None)
+                    if (persistent and self.persistent_gru) else None)
         with _on(dev):
             rc = h.m2d_gru_stack_bwd(_ptr(dout), keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
                                      keep[5][1], keep[6][1], _ptr(lengths), B, T, H, L, _ptr(counters), _stream(dev))

@@ -406,3 +406,48 @@ def test_suspended_backward_does_not_feed_the_exchange():
     assert quiet == 0 and launched == 2, (quiet, launched)
     x = torch.from_numpy(x)
     assert torch.allclose(torch.from_numpy(ga), x) and torch.allclose(torch.from_numpy(gb), 2 * x)
+
+
+def _fault_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    from music2dance_amd.dp import GradExchange
+    from music2dance_amd.optim import Adam
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.ones(5, 3)), torch.nn.Parameter(torch.ones(7))]
+    ex = GradExchange(params, bucket_mb=1e-5)
+    state = {"raised": False}
+    flag = ex.fault_flag(lambda dst: dst.fill_(1.0 if state["raised"] else 0.0))
+    opt = Adam(params, lr=0.1)
+    opt.skip_flag = flag
+    hist = []
+    for it in range(3):
+        state["raised"] = (it == 1 and rank == 1)       # rank 1's recurrent launch "times out" in iteration 1
+        for p in params:
+            p.grad = torch.full_like(p, float(rank + 1))
+        ex.exchange()
+        opt.step()
+        hist.append((float(flag), params[0].detach().clone().numpy()))
+    q.put((rank, hist))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_fault_on_one_rank_voids_the_optimizer_step_on_every_rank():
+    """The fault word travels in the last bucket (dp.GradExchange.fault_flag): when ONE rank raises it, the reduced flag is
+    non-zero on BOTH and both skip that Adam step (m2d_adam_multi's `skip` word) - the replicas stay identical; the
+    steps before and after are taken."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    for rank in (0, 1):
+        flags = [h[0] for h in res[rank]]
+        assert flags[0] == 0.0 and flags[1] > 0.0 and flags[2] == 0.0, flags
+        p0, p1, p2 = (torch.from_numpy(h[1]) for h in res[rank])
+        assert not torch.equal(p0, torch.ones(5, 3))      # iteration 0: stepped
+        assert torch.equal(p1, p0)                          # iteration 1: voided on both ranks
+        assert not torch.equal(p2, p1)                      # iteration 2: stepped again
+    assert all(torch.equal(torch.from_numpy(a[1]), torch.from_numpy(b[1])) for a, b in zip(res[0], res[1]))

@@ -808,3 +808,44 @@ def test_split_k_in_one_launch_equals_the_two_launch_form():
     # and again on the registered stream: the tickets a launch left behind serve the next one
     gw_again = k.conv1d_bwd_weight(x, dy, ks, s, p)
     assert torch.equal(gw_again, gw_fused)
+
+
+def test_a_timed_out_recurrence_voids_the_queued_optimizer_steps_and_the_run_goes_on():
+    """Recovery without leaving the process (round-3 verdict): the word a persistent GRU launch raises when it gives up is
+    the `skip` flag of both optimizers - an Adam step queued behind it is a no-op on the device; the engine then finds the
+    word, synchronises, clears it, counts the fault and runs the recurrences as per-step launches from there on."""
+    import bench
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+    dev = torch.device("cuda:0")
+    k = K()
+    gen, critic = bench.build_models(dev, 120)
+    eng = Phase3Engine(gen, critic, dict(bench.P3_DEFAULT, n_critic_steps=2), data_parallel=False)
+    real, audio, slices = synthetic_phase3_batch(4, 120, dev, seed=3)
+    try:
+        assert eng.optim_critic.skip_flag is not None and type(k).persistent_gru
+        for _ in range(2):
+            eng.train_step(real, audio, slices)
+        torch.cuda.synchronize()
+        before = [p.detach().clone() for p in list(critic.parameters())[:4]]
+        faults = type(k).async_faults
+        # gradients are in place from the last iteration; raise the word as a persistent launch that gave up would (on
+        # the device it is raised by a kernel that ran BEFORE the optimizer step queued behind it - from the host the
+        # closest stand-in is: raise, then queue the step)
+        for p in critic.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        k.raise_async_fault()
+        eng.optim_critic.step()
+        torch.cuda.synchronize()
+        after = [p.detach() for p in list(critic.parameters())[:4]]
+        assert all(torch.equal(a, b) for a, b in zip(before, after)), "an optimizer step ran although the fault word was raised"
+        with pytest.warns(UserWarning, match="timed out"):
+            eng.train_step(real, audio, slices)     # the engine finds the word at its next check: recovers, goes on
+        assert type(k).async_faults == faults + 1 and not type(k).persistent_gru
+        for _ in range(2):
+            out = eng.train_step(real, audio, slices)   # step launches now
+        eng.flush()
+        assert all(torch.isfinite(v).all() for v in out.values())
+        assert not all(torch.equal(a, b.detach()) for a, b in zip(before, list(critic.parameters())[:4]))
+    finally:
+        type(k).persistent_gru = True
