@@ -222,7 +222,7 @@ int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float*
                       const int* lengths, int B, int T, int H, int L, unsigned* counters, void* stream);
 int m2d_gru_persist_error(void);
 /* Recovery from such a timeout without leaving the process: m2d_gru_persist_peek() reads the word without clearing it,
- * m2d_async_fault_word() is its device-visible address (or NULL) - passed to m2d_adam_multi as `skip`, every optimizer
+ * m2d_async_fault_word() is the address of its device-memory copy (or NULL; a timed-out launch raises both) - passed to m2d_adam_multi as `skip`, every optimizer
  * step queued behind the failed recurrence voids itself on the device; the host then synchronises, clears the word
  * (m2d_gru_persist_error) and carries on with the per-step launches (engine.py). m2d_gru_persist_raise(): test hook. */
 int m2d_gru_persist_peek(void);

@@ -448,6 +448,7 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_stack_fwd_kernel(cons
 struct GruPersistArgs {
   GruStackFwdArgs s;
   unsigned* error;     // host-visible word
+  unsigned* mirror;    // its copy in device memory (what queued optimizer steps read: no PCIe round trip per workgroup)
   unsigned spin_limit;
 };
 
@@ -464,12 +465,16 @@ __device__ __forceinline__ void gru_st_sc1(float* p, float v) {
 }
 
 // one lane: wait until *cnt >= want, or somebody raised the error word; false on timeout / error
-__device__ __forceinline__ bool gru_wait_ge(unsigned* cnt, unsigned want, unsigned* error, unsigned limit) {
+__device__ __forceinline__ void gru_raise(unsigned* error, unsigned* mirror) {
+  __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((gru_gu32*)mirror, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool gru_wait_ge(unsigned* cnt, unsigned want, unsigned* error, unsigned* mirror, unsigned limit) {
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load((gru_gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
     if ((spins & 63u) == 63u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
     if (spins >= limit) {
-      __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      gru_raise(error, mirror);
       return false;
     }
     __builtin_amdgcn_s_sleep(2);
@@ -519,7 +524,7 @@ __device__ __forceinline__ bool gru_load_rows(__amdgpu_buffer_rsrc_t rs, const f
 __device__ __forceinline__ bool gru_spin_operands(bool use_i, __amdgpu_buffer_rsrc_t low_rs, const float* low, size_t low_off,
                                                   bool use_h, __amdgpu_buffer_rsrc_t own_rs, const float* own, size_t own_off,
                                                   bool rok, int H, int nblk, bool vec, int wave, int q, unsigned* error,
-                                                  unsigned limit, float (&ai)[GRU_FWD_MAXB][4], float (&ah)[GRU_FWD_MAXB][4],
+                                                  unsigned* mirror, unsigned limit, float (&ai)[GRU_FWD_MAXB][4], float (&ah)[GRU_FWD_MAXB][4],
                                                   unsigned& spin_acc) {
   bool need_i = use_i, need_h = use_h;
   for (unsigned spins = 0;; ++spins) {
@@ -533,7 +538,7 @@ __device__ __forceinline__ bool gru_spin_operands(bool use_i, __amdgpu_buffer_rs
     }
     if ((spins & 63u) == 63u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
     if (spins >= limit) {
-      __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      gru_raise(error, mirror);
       return false;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -613,7 +618,7 @@ __global__ void __launch_bounds__(64 * GRU_FWD_NW) m2d_gru_persist_fwd_kernel(co
     //      layer (the critical dependency)
     float ai[GRU_FWD_MAXB][4], ah[GRU_FWD_MAXB][4];
     if (!gru_spin_operands(use_i, low_rs, a.out[use_i ? l - 1 : l], ((size_t)arow * T + t) * H, use_h, own_rs, a.out[l],
-                           ((size_t)arow * T + (use_h ? t - 1 : 0)) * H, rok, H, nblk, vec, wave, q, pa.error,
+                           ((size_t)arow * T + (use_h ? t - 1 : 0)) * H, rok, H, nblk, vec, wave, q, pa.error, pa.mirror,
                            pa.spin_limit, ai, ah, spin_acc))
       return;  // timeout or error elsewhere (waves that have left are not counted by the barriers)
     if (use_i) {
@@ -789,6 +794,7 @@ struct GruPersistBwdArgs {
   GruStackBwdArgs s;
   unsigned* counters;  // [L][nbt] x GRU_CNT_STRIDE, zeroed before the launch
   unsigned* error;
+  unsigned* mirror;
   unsigned spin_limit;
 };
 
@@ -891,7 +897,7 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
     }
     // ---- upper part: step t of the layer above (it runs one step ahead of this layer)
     if (has_up) {
-      if (tid == 0) go = gru_wait_ge(up_cnt, (unsigned)nth * (unsigned)(T - t), pa.error, pa.spin_limit) ? 1 : 0;
+      if (tid == 0) go = gru_wait_ge(up_cnt, (unsigned)nth * (unsigned)(T - t), pa.error, pa.mirror, pa.spin_limit) ? 1 : 0;
       __syncthreads();
       if (!go) return;
       gru_bwd_contract<NW>(a.dgi[l + 1], ((size_t)arow * T + t) * K, rok, bwih, K, wave, lane, vec, gi_rs, acc);
@@ -900,7 +906,7 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
     if (has_next) {
       if (nth > 1) {
         __syncthreads();  // everybody is past the previous read of `go`
-        if (tid == 0) go = gru_wait_ge(my_cnt, (unsigned)nth * (unsigned)(T - 1 - t), pa.error, pa.spin_limit) ? 1 : 0;
+        if (tid == 0) go = gru_wait_ge(my_cnt, (unsigned)nth * (unsigned)(T - 1 - t), pa.error, pa.mirror, pa.spin_limit) ? 1 : 0;
         __syncthreads();
         if (!go) return;
       }
@@ -936,6 +942,7 @@ __global__ void __launch_bounds__(64 * GRU_BWD_NW) m2d_gru_persist_bwd_kernel(co
 struct GruPersistState {
   unsigned* error_host = nullptr;  // hipHostMalloc (mapped): the kernel raises it, the host reads it
   unsigned* error_dev = nullptr;
+  unsigned* mirror = nullptr;      // device-memory copy of the word, raised with it (m2d_async_fault_word)
   unsigned spin_limit = 0;
   int cus = 0;
   int max_lds = 0;
@@ -968,6 +975,7 @@ static GruPersistState* gru_persist_state() {
     if (hipHostMalloc((void**)&ps.error_host, 64, hipHostMallocMapped) != hipSuccess) return &ps;
     *ps.error_host = 0u;
     if (hipHostGetDevicePointer((void**)&ps.error_dev, ps.error_host, 0) != hipSuccess) return &ps;
+    if (hipMalloc((void**)&ps.mirror, 64) != hipSuccess || hipMemset(ps.mirror, 0, 64) != hipSuccess) return &ps;
     // ~0.4 us per poll with s_sleep(4): 2^21 polls ~ 1 s before a workgroup gives up
     ps.spin_limit = 1u << 21;
     if (hipFuncSetAttribute((const void*)m2d_gru_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1039,6 +1047,7 @@ int m2d_gru_stack_fwd(const float* gi0, const float* const* w_ih_t, const float*
         GruPersistArgs pa;
         pa.s = a;
         pa.error = ps->error_dev;
+      pa.mirror = ps->mirror;
         pa.spin_limit = ps->spin_limit;
         hipLaunchKernelGGL(m2d_gru_persist_fwd_kernel, grid, dim3(64 * GRU_FWD_NW), gru_persist_lds(H), stream, pa);
         M2D_CHECK_LAUNCH("m2d_gru_persist_fwd_kernel");
@@ -1067,7 +1076,10 @@ int m2d_gru_persist_error(void) {
   }
 #endif
   const unsigned e = *(volatile unsigned*)ps->error_host;
-  if (e) *(volatile unsigned*)ps->error_host = 0u;
+  if (e) {
+    *(volatile unsigned*)ps->error_host = 0u;
+    if (ps->mirror) (void)hipMemset(ps->mirror, 0, 4);  // (the caller has synchronised: recovery path only)
+  }
   return e ? 1 : 0;
 }
 
@@ -1079,22 +1091,24 @@ int m2d_gru_persist_peek(void) {
   return *(volatile unsigned*)ps->error_host ? 1 : 0;
 }
 
-// Device-visible address of that word (mapped pinned host memory), or NULL when the persistent form is not in use:
-// what m2d_adam_multi takes as `skip` - an optimizer step queued behind a recurrence that gave up voids itself.
+// Address of the word's DEVICE-MEMORY copy (a timed-out launch raises both), or NULL when the persistent form is not
+// in use: what m2d_adam_multi takes as `skip` - an optimizer step queued behind a recurrence that gave up voids
+// itself. (Not the mapped host word: every workgroup of the step reads it, and 30 k PCIe round trips per step cost
+// 1.9 ms of a 12.2 ms C3 body - measured, round 4.)
 void* m2d_async_fault_word(void) {
   GruPersistState* ps = gru_persist_state();
-  return ps ? (void*)ps->error_dev : nullptr;
+  return ps ? (void*)ps->mirror : nullptr;
 }
 
 // dst[0] = 1.0f when the word is raised, else 0.0f (on `stream`): the form in which a data-parallel gradient exchange
 // carries this rank's state to its peers - one more float in the last bucket, MAX-like after the sum / average.
 __global__ void m2d_fault_fetch_kernel(const unsigned* word, float* dst) {
-  dst[0] = (word && __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) ? 1.f : 0.f;
+  dst[0] = (word && __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.f : 0.f;
 }
 int m2d_fault_fetch(float* dst, void* stream) {
   if (!dst) M2D_FAIL(M2D_ERR_ARG, "m2d_fault_fetch: NULL destination");
   GruPersistState* ps = gru_persist_state();
-  hipLaunchKernelGGL(m2d_fault_fetch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ps ? ps->error_dev : nullptr, dst);
+  hipLaunchKernelGGL(m2d_fault_fetch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ps ? ps->mirror : nullptr, dst);
   M2D_CHECK_LAUNCH("m2d_fault_fetch");
   return M2D_OK;
 }
@@ -1104,6 +1118,8 @@ int m2d_gru_persist_raise(void) {
   GruPersistState* ps = gru_persist_state();
   if (!ps || !ps->error_host) return M2D_ERR_ARG;
   *(volatile unsigned*)ps->error_host = 1u;
+  const unsigned one = 1u;
+  if (ps->mirror && hipMemcpy(ps->mirror, &one, 4, hipMemcpyHostToDevice) != hipSuccess) return M2D_ERR_HIP;
   return M2D_OK;
 }
 
@@ -1133,6 +1149,7 @@ int m2d_gru_stack_bwd(const float* dout, const float* const* out, const float* c
       pa.s = a;
       pa.counters = counters;
       pa.error = ps->error_dev;
+      pa.mirror = ps->mirror;
       pa.spin_limit = ps->spin_limit;
       hipLaunchKernelGGL(m2d_gru_persist_bwd_kernel, grid, dim3(64 * GRU_BWD_NW), gru_persist_bwd_lds(H), stream, pa);
       M2D_CHECK_LAUNCH("m2d_gru_persist_bwd_kernel");

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) m2d_adam_multi_kernel(const M2dAdamBatch 
                                                              float eps, float bc2_sqrt, const float* skip) {
   // (any non-zero BIT pattern counts: the word may be an unsigned flag, e.g. m2d_async_fault_word(); read past the
   // caches - it can live in mapped host memory and be raised by a kernel that ran just before)
-  if (skip && __hip_atomic_load((const unsigned*)skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+  if (skip && __hip_atomic_load((const unsigned*)skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   int k = 0;
   while (k + 1 < b.n && (int)blockIdx.x >= b.first_block[k + 1]) ++k;   // wave-uniform
   const M2dAdamItem& t = b.it[k];
