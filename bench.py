@@ -466,18 +466,19 @@ def main():
                 "hbm": hbm,
             }
             if args.phase == 3:
-                # what the part sustains under fp32 MFMA load, measured here and now: the engine on a plain 4096^3 GEMM
-                # (no gather, no tails, a balanced grid). fp32 MFMA is power-limited on this part - matrix-pipe busy x
-                # clock is ~1.6 GHz for every large launch (profiles/*_pmc_shapes.json) - so this, not the nominal
-                # 157.3, is the ceiling a perfectly fed kernel reaches; `frac` above stays priced against the nominal peak
+                # the engine on a plain 4096^3 GEMM, measured here and now (mode 2: both operands K-major, the LDS-direct
+                # kernel the conv forward / backward-data launches use; no gather, no tails, a balanced grid): what the
+                # engine's own loop and epilogue reach when nothing about the step's shapes is in the way. Standalone
+                # kernels reach 140-147 (tools/probes/gemm_ceiling.hip, profiles/r04_gemm_ceiling_*.txt); the round-3
+                # "power ceiling of 105" was a misreading. `frac` stays priced against the nominal peak
                 n = 4096
                 ga, gb = torch.randn(n, n, device=device), torch.randn(n, n, device=device)
-                K.gemm(1, ga, gb)
+                K.gemm(2, ga, gb)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(10):
-                    K.gemm(1, ga, gb)
+                    K.gemm(2, ga, gb)
                 e1.record()
                 torch.cuda.synchronize()
                 plain = 10 * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
