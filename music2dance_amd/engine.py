@@ -86,7 +86,9 @@ class WganGpEngine:
         self.total_iterations = 0
         # the critic's exchange (every iteration) starts bucket by bucket underneath its own backward pass
         self.x_critic = GradExchange(critic.parameters()).overlap_backward() if data_parallel else None
-        self.x_gen = GradExchange(gen.parameters()) if data_parallel else None
+        # the generator's exchange (every n_critic-th iteration) leaves in 4 MB buckets from the hooks of its backward
+        # pass (one autograd backward per generator iteration): only the last bucket's ring is exposed
+        self.x_gen = GradExchange(gen.parameters(), bucket_mb=4.0).overlap_backward() if data_parallel else None
         self._critic_step_pending = False
         # a persistent recurrent launch that times out must not take the run with it (_check_async): both optimizers
         # read the fault word - directly, or (data parallel) as reduced over the ranks by their gradient exchange

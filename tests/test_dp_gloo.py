@@ -229,6 +229,61 @@ def test_deferred_critic_step_is_taken_every_iteration():
         assert (a == b).all()
 
 
+def _gen_overlap_worker(rank, world, port, q, B, T, alphas, noises, real, steps, overlap):
+    _setup(rank, world, port)
+    import music2dance_amd.losses as L
+    from music2dance_amd.engine import Phase2Engine
+    from music2dance_amd.dp import GradExchange
+    gen, critic = _make_p2()
+    eng = Phase2Engine(gen, critic, dict(CFG, n_critic_steps=1), data_parallel=True)
+    assert eng.x_gen._hooks, "the engine arms the generator's exchange"
+    eng.x_gen = GradExchange(gen.parameters(), bucket_mb=0.004)
+    if overlap:
+        eng.x_gen.overlap_backward()
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    it = {"i": 0}
+    eng._noise = lambda b, t, d: noises[it["i"]][lo:hi]
+    L.torch.rand = lambda *a, **k: alphas[it["i"]][lo:hi].clone()
+    for i in range(steps):
+        it["i"] = i
+        eng.train_step(real[lo:hi])
+    eng.flush()
+    q.put((rank, overlap, [p.detach().numpy().copy() for p in gen.parameters()],
+           (len(eng.x_gen.buckets), eng.x_gen.launched_in_backward)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_generator_exchange_leaves_under_its_backward_and_changes_nothing():
+    """Every train_step holds a generator iteration (n_critic_steps = 1). With the hooks armed, all buckets but the last
+    leave from inside the generator's backward pass from the second iteration on; the parameters after three Adam steps
+    are bit-identical to the blocking exchange's (a two-rank sum does not depend on when a bucket was sent)."""
+    B, T, steps = 4, 24, 3
+    g = torch.Generator().manual_seed(11)
+    alphas = [torch.rand(B, 1, generator=g) for _ in range(steps)]
+    noises = [torch.randn(B, T, 8, generator=g) for _ in range(steps)]
+    real = torch.rand(B, T, 69, generator=g)
+    out = {}
+    for overlap in (False, True):
+        world, port = 2, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_gen_overlap_worker, args=(r, world, port, q, B, T, alphas, noises, real, steps, overlap))
+                 for r in range(world)]
+        [p.start() for p in procs]
+        res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+        [p.join(60) for p in procs]
+        out[overlap] = res
+    for rank in range(2):
+        nb, inb = out[True][rank][3]
+        assert nb >= 3 and inb >= (steps - 1) * (nb - 1), (nb, inb)
+        assert out[False][rank][3][1] == 0
+        for a, b in zip(out[True][rank][2], out[False][rank][2]):
+            assert (a == b).all()
+    for a, b in zip(out[True][0][2], out[True][1][2]):
+        assert (a == b).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # Synchronised BatchNorm (ops.set_sync_batchnorm): with the batch statistics and the two backward
 # sums all-reduced, a generator sharded over two ranks produces the poses and (averaged) gradients of
