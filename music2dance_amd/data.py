@@ -247,11 +247,20 @@ class StickDataset(Dataset):
             poses = self.scaler.transform(_flatten_features(poses)).reshape(poses.shape)
         self.skeletons = poses
 
+    static_items = True  # an item is a fixed row (ResidentLoader gathers a whole epoch at once)
+
     def __len__(self):
         return self.skeletons.shape[0]
 
     def __getitem__(self, idx):
         return torch.as_tensor(self.skeletons[idx], dtype=torch.float32)
+
+    def sample_batch(self, indices, device=None):
+        """default_collate([self[i] for i in indices]) as ONE row gather - from the HBM-resident copy with `device`."""
+        where = device if device is not None else "cpu"
+        if getattr(self, "_dev", None) is None or self._dev.device != torch.device(where):
+            self._dev = torch.as_tensor(self.skeletons, dtype=torch.float32).to(where)
+        return self._dev[torch.as_tensor([int(i) for i in indices], device=where)]
 
     def statistics(self):
         return self.skeletons.mean(axis=0), self.skeletons.std(axis=0)
@@ -393,6 +402,44 @@ def collate_fn(batch, withaudio=True, device=None):
     return padded, lengths, torch.stack(cols[1]).to(where, non_blocking=True), labels, dirs
 
 
+class ResidentLoader:
+    """`DataLoader(dataset, batch_size, sampler=sampler, drop_last=..., collate_fn=collate_fn)` for a dataset that lives
+    in HBM: the train scripts' loaders (phase1/train_wgan-gp.py:71-72, phase2/train.py:115-116, phase3/train.py:150-162)
+    fetch 64 items and collate them on the host, 5-33 ms per batch against 0.8-12 ms of GPU work per loop body; here the
+    whole dataset (the 61 takes of the reference's data are < 1 GB of fp32) is uploaded once and a batch is the sampler's
+    indices + the window draws on the host and ONE gather on the device (`dataset.sample_batch(indices, device)`).
+    Draw for draw the DataLoader's stream: its iterator's base-seed draw from torch's global generator, the sampler's
+    draws, the datasets' crop draws in item order - a seeded run sees the same batches either way
+    (tests/test_data_pipeline.py). `sampler` is any torch sampler over item indices."""
+
+    def __init__(self, dataset, batch_size, sampler, device, drop_last=False):
+        self.dataset, self.sampler, self.device = dataset, sampler, device
+        self.batch_size, self.drop_last = int(batch_size), bool(drop_last)
+
+    def __len__(self):
+        n = len(self.sampler)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        torch.empty((), dtype=torch.int64).random_()  # (what a DataLoader iterator draws for its workers' base seed)
+        if getattr(self.dataset, "static_items", False):
+            # items without per-draw randomness (still poses): the whole epoch in ONE gather, batches are views of it
+            order = list(self.sampler)
+            rows = self.dataset.sample_batch(order, self.device) if order else None
+            stop = len(order) - (len(order) % self.batch_size if self.drop_last else 0)
+            for i in range(0, stop, self.batch_size):
+                yield rows[i:i + self.batch_size]
+            return
+        chunk = []
+        for i in self.sampler:
+            chunk.append(i)
+            if len(chunk) == self.batch_size:
+                yield self.dataset.sample_batch(chunk, self.device)
+                chunk = []
+        if chunk and not self.drop_last:
+            yield self.dataset.sample_batch(chunk, self.device)
+
+
 # --------------------------------------------------------------------------------------- split + samplers
 def split_indices(dataset_size, validation_split=.2, test_split=.5, random_seed=14):
     """The seeded hold-out of phase3/train.py:112-124 -> (train, val, test) index lists: a permutation of range(n)
@@ -414,10 +461,11 @@ def class_balanced_weights(labels, indices):
     return (1. / counts)[inverse]
 
 
-def make_loaders(dataset, batch_size, withaudio=True, logdir=None):
+def make_loaders(dataset, batch_size, withaudio=True, logdir=None, device=None):
     """Train / validation loaders over the seeded split (phase3/train.py:112-162): trainvaltest_samples.json in
     `logdir`, each subset drawn through a class-balanced WeightedRandomSampler, validation served as ONE batch.
-    A dataset too small to hold anything out (< 5 takes) gets no validation loader (None)."""
+    A dataset too small to hold anything out (< 5 takes) gets no validation loader (None). `device`: the loaders keep
+    their subsets in that device's memory and gather batches there (ResidentLoader; same batches as the DataLoader)."""
     from torch.utils.data import DataLoader, WeightedRandomSampler
     parts = dict(zip(("train", "val", "test"), split_indices(len(dataset))))
     if logdir is not None:
@@ -428,8 +476,10 @@ def make_loaders(dataset, batch_size, withaudio=True, logdir=None):
         if not idx:
             return None
         weights = class_balanced_weights(dataset.labels, idx)
-        return DataLoader(dataset.subset(idx, withaudio), batch_size=per_batch,
-                          sampler=WeightedRandomSampler(weights, len(weights)),
+        sampler = WeightedRandomSampler(weights, len(weights))
+        if device is not None:
+            return ResidentLoader(dataset.subset(idx, withaudio), per_batch, sampler, device)
+        return DataLoader(dataset.subset(idx, withaudio), batch_size=per_batch, sampler=sampler,
                           collate_fn=lambda b: collate_fn(b, withaudio=withaudio))
 
     return loader(parts["train"], batch_size), loader(parts["val"], len(parts["val"])), tuple(parts.values())

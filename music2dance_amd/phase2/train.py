@@ -28,6 +28,9 @@ def main(argv=None):
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--no-run-dir", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch")
+    ap.add_argument("--host-loader", action="store_true",
+                    help="fetch and collate batches on the host (torch DataLoader) instead of gathering them from the "
+                         "HBM-resident dataset; same batches either way")
     opts = ap.parse_args(argv)
     if opts.framework != "wgangp":
         raise ValueError("Please state existing framework")
@@ -49,9 +52,12 @@ def main(argv=None):
         sticks = D.StickDataset(folder, normalize="minmax")
         dataset = D.SequenceDataset(folder, ds, dance_types=cfg["dance_types"], scaler=sticks.scaler, withaudio=False)
         stick_length = dataset.stick_length
-        loader = DataLoader(dataset, batch_size=batch_size, drop_last=True,
-                            collate_fn=lambda b: D.collate_fn(b, withaudio=False),
-                            sampler=SubsetRandomSampler(range(min(cfg["num_train"], len(dataset)))))
+        sampler = SubsetRandomSampler(range(min(cfg["num_train"], len(dataset))))
+        if device.type == "cuda" and not opts.host_loader:
+            loader = D.ResidentLoader(dataset, batch_size, sampler, device, drop_last=True)
+        else:
+            loader = DataLoader(dataset, batch_size=batch_size, drop_last=True, sampler=sampler,
+                                collate_fn=lambda b: D.collate_fn(b, withaudio=False))
     logdir = runner.make_run_dir(opts.name, enabled=(rank == 0 and not opts.no_run_dir))
     gen = SequenceGenerator(cfg["input_vector_size"], cfg["latent_vector_size"], cfg["size"], cfg["output_size"],
                             cfg["nblocks_gen"], cfg["n_cells"], device)
@@ -73,8 +79,12 @@ def main(argv=None):
                 g = torch.Generator().manual_seed(1 + (epoch * batches_per_epoch + b) * world + rank)
                 yield torch.rand(batch_size, stick_length, cfg["output_size"], generator=g).to(device)
 
-        source = synthetic() if loader is None else (
-            runner.staged((b[0].float().reshape(b[0].size(0), stick_length, -1),), device)[0][0] for b in loader)
+        if loader is None:
+            source = synthetic()
+        elif isinstance(loader, DataLoader):
+            source = (runner.staged((b[0].float().reshape(b[0].size(0), stick_length, -1),), device)[0][0] for b in loader)
+        else:
+            source = (b[0].reshape(b[0].size(0), stick_length, -1) for b, _ in runner.resident_batches(loader, device))
         for real in source:
             out = engine.train_step(real)
             it = engine.total_iterations

@@ -43,6 +43,9 @@ def main(argv=None):
     ap.add_argument("--no-run-dir", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch")
     ap.add_argument("--val-batches", type=int, default=1, help="held-out synthetic batches for l1_loss_val")
+    ap.add_argument("--host-loader", action="store_true",
+                    help="fetch and collate batches on the host (torch DataLoader, as the reference does) instead of "
+                         "gathering them from the HBM-resident dataset; same batches either way")
     opts = ap.parse_args(argv)
 
     rank, world, local = dp.init_from_env()
@@ -65,7 +68,8 @@ def main(argv=None):
         dataset = D.SequenceDataset(folder, ds, dance_types=cfg["dance_types"], scaler=sticks.scaler, withaudio=True)
         dataset.truncate()
         stick_length = dataset.stick_length
-        train_loader, val_loader, _ = D.make_loaders(dataset, batch_size, withaudio=True, logdir=logdir)
+        resident = device if (device.type == "cuda" and not opts.host_loader) else None
+        train_loader, val_loader, _ = D.make_loaders(dataset, batch_size, withaudio=True, logdir=logdir, device=resident)
         window, hop = int(cfg["window_size"] * dataset.aud_rate), dataset.ratio
     gen, critic = build(cfg, device, stick_length)
     engine = Phase3Engine(gen, critic, cfg, ablated=cfg["ablated"], sync_bn=opts.sync_bn)
@@ -81,9 +85,19 @@ def main(argv=None):
     n_valid_steps = 1  # phase3/train.py:168
 
     def loader_batches(loader):
+        # the window view of the padded track is made on the copy stream, in front of the `ready` event: the
+        # generator forward that reads it runs on a stream of its own and waits for nothing but that event
+        def with_slices(b):
+            real, audio = b[0], b[2] if len(b) > 2 else b[1]
+            return real, audio, slice_audio_batch(audio, window, hop, window - hop, lazy=True)
+
+        if isinstance(loader, D.ResidentLoader):
+            for (real, audio, slices), ready in runner.resident_batches(loader, device, derive=with_slices):
+                yield real, audio, slices, ready
+            return
         for real_h, _, audio_h, _, _ in loader:
-            (real, audio), ready = runner.staged((real_h.float(), audio_h), device)
-            yield real, audio, slice_audio_batch(audio, window, hop, window - hop, lazy=True), ready
+            (real, audio, slices), ready = runner.staged((real_h.float(), audio_h), device, derive=with_slices)
+            yield real, audio, slices, ready
 
     def val_batches():
         # the reference's validation loader serves the held-out 20 % split as one batch

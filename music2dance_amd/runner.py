@@ -91,18 +91,67 @@ def dataset_folder(cfg, override=None):
     return folder
 
 
-def staged(tensors, device):
+def _tensors(x):
+    if torch.is_tensor(x):
+        yield x
+    elif isinstance(x, (tuple, list)):
+        for y in x:
+            yield from _tensors(y)
+
+
+def resident_batches(loader, device, derive=None):
+    """Batches of a data.ResidentLoader, each gathered on the copy stream: yields (batch, event after which its tensors
+    are complete) like `staged` does for host batches - the gather of batch k + 1 runs beside the kernels of loop body k,
+    and `train_step(..., inputs_ready=event)` may start its generator forward as soon as the gather is done.
+    `derive(batch)` (optional) runs on the copy stream too, BEFORE the event: tensors computed from the batch that the
+    step's other streams read (phase 3's padded audio track) - it replaces the batch in what is yielded."""
+    from .layers import copy_stream
+    it = iter(loader)
+    cuda = torch.device(device).type == "cuda"
+    while True:
+        if not cuda:
+            try:
+                batch = next(it)
+            except StopIteration:
+                return
+            yield (derive(batch) if derive else batch), None
+            continue
+        cur = torch.cuda.current_stream(device)
+        cs = copy_stream(device)
+        # (no wait for `cur`: the dataset is uploaded by the first gather on this same stream and never written again,
+        # and the batch lands in fresh blocks of the copy stream's own pool)
+        with torch.cuda.stream(cs):
+            try:
+                batch = next(it)
+            except StopIteration:
+                return
+            if derive is not None:
+                batch = derive(batch)
+            ready = cs.record_event()
+        cur.wait_event(ready)
+        for t in _tensors(batch):
+            t.record_stream(cur)
+        yield batch, ready
+
+
+def staged(tensors, device, derive=None):
     """Host tensors of one loader batch -> device, on the copy stream; (device tensors, event after which they
-    are complete): what `train_step(..., inputs_ready=)` takes."""
+    are complete): what `train_step(..., inputs_ready=)` takes. `derive(device tensors)` (optional) runs on the copy
+    stream before the event and replaces them: whatever else the step's other streams read must be complete at the
+    event too (phase 3's padded audio track - made on the main stream it would sit behind the previous loop body
+    while the generator stream, which only waits for the event, already reads it)."""
     from .layers import copy_stream
     if torch.device(device).type != "cuda":
-        return [t.to(device) for t in tensors], None
+        out = [t.to(device) for t in tensors]
+        return (derive(out) if derive else out), None
     cur = torch.cuda.current_stream(device)
     cs = copy_stream(device)
     with torch.cuda.stream(cs):
         out = [t.to(device, non_blocking=True) for t in tensors]
+        if derive is not None:
+            out = derive(out)
         ready = cs.record_event()
     cur.wait_event(ready)
-    for t in out:
+    for t in _tensors(out):
         t.record_stream(cur)
     return out, ready

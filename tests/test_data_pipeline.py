@@ -143,3 +143,61 @@ def test_batched_window_gather_equals_itemwise_crops_and_small_datasets_have_no_
     assert len(ds.sequences[1]) == 150 and np.array_equal(ds.sequences[1], first[:150]) and len(ds.sequences[2]) > 0
     train_loader, val_loader, (tr, va, te) = D.make_loaders(ds, batch_size=2, logdir=None)
     assert val_loader is None and va == [] and len(tr) == 4 and next(iter(train_loader))[0].shape[0] == 2
+
+
+def test_resident_loader_serves_the_dataloaders_batches(tmp_path):
+    """data.ResidentLoader (dataset in device memory, one gather per batch) against torch's DataLoader over the same
+    dataset / sampler / seeds: phase 3's class-balanced loaders (make_loaders), phase 2's SubsetRandomSampler with
+    drop_last, phase 1's still poses - identical batches over two epochs, and the generators end in the same state."""
+    from torch.utils.data import DataLoader, SubsetRandomSampler
+    from music2dance_amd import data as D
+    folder = D.write_synthetic_dataset(str(tmp_path / "ds"), n_takes=11, seconds=6, seed=9)
+    cfg = {"audio_rate": 16000, "video_rate": 25, "seq_length": 4.8, "feat_size": 0.2}
+    sticks = D.StickDataset(folder, normalize="minmax")
+
+    def run(make, epochs=2):
+        torch.manual_seed(123)
+        out = []
+        loader = make()          # (make_loaders seeds numpy itself: the crop draws follow its split, as in the script)
+        for _ in range(epochs):
+            out.extend(loader)
+        return out, torch.rand(1), np.random.rand()
+
+    def same(a, b):
+        (ba, ta, na), (bb, tb, nb) = a, b
+        assert len(ba) == len(bb) and len(ba) > 2 and torch.equal(ta, tb) and na == nb
+        for x, y in zip(ba, bb):
+            x, y = (x, y) if isinstance(x, (tuple, list)) else ((x,), (y,))
+            assert len(x) == len(y)
+            for u, v in zip(x, y):
+                if torch.is_tensor(u):
+                    assert u.dtype == v.dtype and torch.equal(u, v)
+                else:
+                    assert list(u) == list(v)
+
+    # phase 3: poses + audio, WeightedRandomSampler, last batch partial
+    def p3(device):
+        ds = D.SequenceDataset(folder, cfg, scaler=sticks.scaler, withaudio=True)
+        ds.truncate()
+        return D.make_loaders(ds, 4, withaudio=True, device=device)[0]
+    same(run(lambda: p3(None)), run(lambda: p3("cpu")))
+    assert isinstance(p3("cpu"), D.ResidentLoader) and len(p3("cpu")) == len(p3(None))
+
+    # phase 2: poses only, SubsetRandomSampler, drop_last
+    def p2(resident):
+        np.random.seed(5)
+        ds = D.SequenceDataset(folder, cfg, scaler=sticks.scaler, withaudio=False)
+        sampler = SubsetRandomSampler(range(9))
+        if resident:
+            return D.ResidentLoader(ds, 4, sampler, "cpu", drop_last=True)
+        return DataLoader(ds, batch_size=4, drop_last=True, sampler=sampler, collate_fn=lambda b: D.collate_fn(b, withaudio=False))
+    same(run(lambda: p2(False)), run(lambda: p2(True)))
+
+    # phase 1: still poses
+    def p1(resident):
+        np.random.seed(5)
+        sampler = SubsetRandomSampler(range(min(700, len(sticks))))
+        if resident:
+            return D.ResidentLoader(sticks, 64, sampler, "cpu", drop_last=True)
+        return DataLoader(sticks, batch_size=64, drop_last=True, sampler=sampler)
+    same(run(lambda: p1(False)), run(lambda: p1(True)))

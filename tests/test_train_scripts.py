@@ -151,6 +151,36 @@ def test_train_scripts_run_on_a_dataset_folder(dev, tmp_path, monkeypatch):
         T3.main(["-c", c3, "-d", "0", "-n", "d3x", "--no-run-dir", "--folder", str(tmp_path / "nope")])
 
 
+@pytest.mark.gpu
+def test_resident_and_host_loaders_train_identically(tmp_path, monkeypatch):
+    """The train scripts' default on a GPU - dataset in HBM, one gather per batch on the copy stream
+    (data.ResidentLoader) - against --host-loader (torch DataLoader + collate on the host, as the reference does):
+    same batches, so the same parameters after a few loop bodies of each phase."""
+    assert kernels.impl().name == "hip"
+    from music2dance_amd.data import write_synthetic_dataset
+    from music2dance_amd.phase1 import train_wgan_gp as T1
+    from music2dance_amd.phase2 import train as T2
+    from music2dance_amd.phase3 import train as T3
+    monkeypatch.chdir(tmp_path)
+    folder = write_synthetic_dataset(str(tmp_path / "ds"), n_takes=12, seconds=6, seed=2)
+    faults = kernels.impl().async_faults
+    runs = {}
+    for extra in ([], ["--host-loader"]):
+        c3 = _cfg(tmp_path, "phase3/configs/default.yaml", batch_size=4, num_epochs=2, n_critic_steps=2, folder=folder)
+        e3 = T3.main(["-c", c3, "-d", "0", "-n", "r3", "--no-run-dir"] + extra)
+        c2 = _cfg(tmp_path, "phase2/configs/default.yaml", batch_size=4, num_train=10, num_epochs=2, n_critic_steps=2)
+        e2 = T2.main(["-c", c2, "-d", "0", "-n", "r2", "--no-run-dir", "--folder", folder] + extra)
+        c1 = _cfg(tmp_path, "phase1/configs/b2l50s32.yaml", batch_size=8, num_train=40, num_epochs=1)
+        e1 = T1.main(["-c", c1, "-d", "0", "-n", "r1", "--no-run-dir", "--folder", folder] + extra)
+        runs[bool(extra)] = [(e.total_iterations, [p.detach().clone() for m in (e.gen, e.critic) for p in m.parameters()])
+                             for e in (e3, e2, e1)]
+    assert kernels.impl().async_faults == faults, "a recurrent launch timed out during the runs (recovered, steps voided)"
+    for phase, ((na, pa), (nb, pb)) in zip((3, 2, 1), zip(runs[False], runs[True])):
+        assert na == nb and na >= 4
+        bad = [(i, float((a - b).abs().max())) for i, (a, b) in enumerate(zip(pa, pb)) if not torch.equal(a, b)]
+        assert not bad, "phase %d: %d of %d tensors differ: %s" % (phase, len(bad), len(pa), bad[:6])
+
+
 # ------------------------------------------------------------------------------ MultiStepLR
 def _lr_closed_form(lr0, gen_iters, milestones=(10000, 35000, 50000), gamma=0.8):
     return lr0 * gamma ** sum(1 for m in milestones if gen_iters >= m)
