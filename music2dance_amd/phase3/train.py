@@ -154,6 +154,7 @@ def main(argv=None):
                 runner.save_state(gen, logdir + "/models/gpgen_{}.pt".format(epoch + 1))
                 runner.save_state(critic, logdir + "/models/gpcritic_{}.pt".format(epoch + 1))
     engine.flush()
+    log.flush()
     if rank == 0:
         print("done: {} iterations, last {}".format(engine.total_iterations,
                                                     {k: float(v) for k, v in engine.last.items()}))

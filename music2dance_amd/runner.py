@@ -45,27 +45,52 @@ def make_run_dir(name, enabled=True):
 
 
 class ScalarLog:
-    """TensorBoard scalars under the reference's tags when tensorboard is importable;
-    otherwise a no-op. Values stay on the device until `every` iterations have passed, so
-    throughput runs do not pay one host sync per scalar per iteration."""
+    """TensorBoard scalars under the reference's tags when tensorboard is importable; otherwise a no-op.
+    The reference writes `loss.item()` every generator iteration (phase3/train.py:228-236): a host sync per scalar that
+    drains the launch queue. Here a logged value is copied to pinned host memory on the stream that made it
+    (non-blocking) and WRITTEN when that copy is known to have finished - on a later `scalars()` call, or in
+    `flush()` at the end of the run: same tags, steps and values, no stall in the loop."""
 
-    def __init__(self, logdir, every=1):
+    def __init__(self, logdir, every=1, writer=None):
         self.every = max(int(every), 1)
-        self.writer = None
+        self.writer = writer
         self.last = {}  # most recent value per tag (device tensors; tests and prints read it)
-        if logdir is not None:
+        self._queue = []  # (tag, step, host tensor or float, event or None)
+        if logdir is not None and writer is None:
             try:
                 from torch.utils.tensorboard import SummaryWriter
                 self.writer = SummaryWriter(logdir + "/logging")
             except Exception:
                 self.writer = None
 
+    def _drain(self, block=False):
+        while self._queue:
+            tag, step, host, ev = self._queue[0]
+            if ev is not None and not block and not ev.query():
+                return
+            if ev is not None and block:
+                ev.synchronize()
+            self._queue.pop(0)
+            self.writer.add_scalar(tag, float(host), step)
+
     def scalars(self, values, step, force=False):
         self.last.update(values)
         if self.writer is None or (step % self.every and not force):
             return
         for tag, v in values.items():
-            self.writer.add_scalar(tag, float(v), step)
+            if torch.is_tensor(v) and v.is_cuda:
+                host = torch.empty((), dtype=v.dtype, pin_memory=True)
+                host.copy_(v.detach().reshape(()), non_blocking=True)
+                self._queue.append((tag, step, host, torch.cuda.current_stream(v.device).record_event()))
+            else:
+                self._queue.append((tag, step, v, None))
+        self._drain()
+
+    def flush(self):
+        if self.writer is not None:
+            self._drain(block=True)
+            if hasattr(self.writer, "flush"):
+                self.writer.flush()
 
 
 def dump_architectures(logdir, gen, critic):

@@ -181,6 +181,30 @@ def test_resident_and_host_loaders_train_identically(tmp_path, monkeypatch):
         assert not bad, "phase %d: %d of %d tensors differ: %s" % (phase, len(bad), len(pa), bad[:6])
 
 
+def test_scalar_log_writes_every_value_without_blocking_the_loop(dev):
+    """runner.ScalarLog under a writer: values logged as device tensors arrive with their tags and steps, in order,
+    although `scalars()` never waits for the device (pinned copies + events; flush() at the end writes the rest)."""
+    class Writer:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append((tag, value, step))
+
+    w = Writer()
+    log = runner.ScalarLog(None, every=2, writer=w)
+    want = []
+    for step in range(1, 9):
+        vals = {"loss_gen": torch.tensor(float(step), device=dev) * 0.5, "gp": float(step) + 0.25}
+        log.scalars(vals, step)
+        if step % 2 == 0:
+            want += [("loss_gen", step * 0.5, step), ("gp", step + 0.25, step)]
+    log.scalars({"l1_loss_val": torch.tensor(3.0, device=dev)}, 9, force=True)
+    want.append(("l1_loss_val", 3.0, 9))
+    log.flush()
+    assert w.rows == want and float(log.last["l1_loss_val"]) == 3.0
+
+
 # ------------------------------------------------------------------------------ MultiStepLR
 def _lr_closed_form(lr0, gen_iters, milestones=(10000, 35000, 50000), gamma=0.8):
     return lr0 * gamma ** sum(1 for m in milestones if gen_iters >= m)
