@@ -33,7 +33,8 @@ def main(argv=None):
                          "HBM-resident dataset; same batches either way")
     ap.add_argument("--graphs", action="store_true",
                     help="replay each loop body from captured HIP graphs (the eager loop is bound by the host's launch "
-                         "rate: 2.8 -> 0.86 ms per body at batch 64); results equal the eager path's")
+                         "rate: 2.8 -> 0.86 ms per body at batch 64); results equal the eager path's. Default on one GPU")
+    ap.add_argument("--no-graphs", action="store_true", help="keep the eager launch loop on a single GPU too")
     opts = ap.parse_args(argv)
 
     rank, world, local = dp.init_from_env()
@@ -62,7 +63,7 @@ def main(argv=None):
                 torch.distributed.broadcast(t.data, 0)
         torch.manual_seed(torch.initial_seed() + rank)
     engine.host_noise = False  # phase1/train_wgan-gp.py:83 draws the noise on the device
-    if opts.graphs and device.type == "cuda":
+    if device.type == "cuda" and (opts.graphs or (world == 1 and not opts.no_graphs)):
         engine.enable_graphs()
     log = runner.ScalarLog(logdir, opts.log_every)
     B = cfg["batch_size"]
