@@ -465,6 +465,17 @@ def main():
                 # launches that move >= 64 MB (smaller ones are launch-bound, listed under "small")
                 "hbm": hbm,
             }
+            # the pose critic's k7 TemporalBlock convs (phase3/archis/default.py:207-210; Cout = 128, K = 128 * 7, the
+            # weight gradient with its bias column): 5 GFLOP launches that cannot fill 256 CUs x 5 resident workgroups
+            #  - their own rate, next to the engine average they pull down
+            tcn = [r for r in launches if FAMILIES[r[0]] == "gemm" and
+                   ((r[2] == 128 and r[4] == 896) or (r[2] == 128 and r[3] == 897))]
+            if tcn:
+                t_ms, t_fl = sum(r[5] for r in tcn), sum(r[6] for r in tcn)
+                out["roofline"]["tcn_critic"] = {
+                    "launches_per_step": round(len(tcn) / args.steps, 1), "ms_per_step": round(t_ms / args.steps, 3),
+                    "achieved": round(t_fl / t_ms / 1e9, 1) if t_ms > 0 else 0.0, "unit": "TFLOP/s",
+                    "frac": round(t_fl / t_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4) if t_ms > 0 else 0.0}
             if args.phase == 3:
                 # the engine on a plain 4096^3 GEMM, measured here and now (mode 2: both operands K-major, the LDS-direct
                 # kernel the conv forward / backward-data launches use; no gather, no tails, a balanced grid): what the
