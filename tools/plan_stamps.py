@@ -11,7 +11,7 @@ L = _lib.lib()
 dev = "cuda:0"
 buf = (ctypes.c_ulonglong * (8192 * 4))()
 CASES = {"tcn3b": (192, 128, 120, 128, 7, 1, 3), "tcn1b": (64, 128, 120, 128, 7, 1, 3), "stick1": (192, 69, 120, 128, 25, 1, 12),
-         "l3": (64, 64, 4800, 128, 25, 4, 11)}
+         "l3": (64, 64, 4800, 128, 25, 4, 11), "l4": (64, 128, 1200, 256, 25, 4, 11), "l5": (64, 256, 300, 512, 25, 4, 11)}
 b_, cin, Lx, cout, ks, s_, p_ = CASES[os.environ.get("CASE", "tcn3b")]
 
 
@@ -54,6 +54,6 @@ with K.weight_cache():
             else: os.environ["M2D_PLAN"] = "%d,%d" % pl
             try:
                 us = timeit(fn)
-                print("%s plan %-9s %7.1f us %6.1f TF | %s" % (pname, pl, us, gf / us * 1e-3, stamps(fn)), flush=True)
+                print("%s plan %-9s %7.1f us %6.1f TF | %s" % (pname, pl, us, gf / us * 1e3, stamps(fn)), flush=True)
             except Exception as e:
                 print(pname, pl, "failed:", str(e)[:80])
