@@ -440,7 +440,9 @@ def main():
         if prof is not None:
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-            traffic, traffic_src = pmc_traffic()
+            # (the committed PMC passes are of the default workload: other presets report no traffic)
+            c3_default = args.phase == 3 and (args.enc_type, args.frames, args.ablated, args.batch) == ("default", 120, False, 64)
+            traffic, traffic_src = pmc_traffic() if c3_default else (None, None)
             hbm, shapes = hbm_table(launches, args.steps)
             if args.dump_shapes:
                 with open(args.dump_shapes, "w") as f:
