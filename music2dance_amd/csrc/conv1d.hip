@@ -286,16 +286,39 @@ int m2d_conv1d_fwd_sum(const float* x, const float* w, const float* w_packed, co
 static inline int k4_shift(int pad) { return ((pad + 3) / 4) * 4 - pad; }                 // P - pad: phantom taps in front
 static inline int k4_groups(int ks, int pad) { return (ks + k4_shift(pad) + 3) / 4; }       // tap groups per channel
 
-// Wk4[(ci * NG + g) * Cout * 4 + co * 4 + m] = W[co][ci][4 g + m - (P - pad)], zero for taps outside [0, ks)
+// real slots of the last tap group; and whether the layer's K is walked in the phantom-paired order (m2d_conv_k4_kernel):
+// it has partial groups, at least two full groups between them (the cursor wraps at most twice per chunk), and channel
+// blocks of four (M2D_K4_PAIR=0: A/B lever)
+static inline int k4_nlast(int ks, int pad) { return ks + k4_shift(pad) - 4 * (k4_groups(ks, pad) - 1); }
+static inline int k4_paired(int Cin, int ks, int pad) {
+  static const bool on = [] { const char* e = getenv("M2D_K4_PAIR"); return !(e && e[0] == '0'); }();
+  // (the kernel's partial-group loops are instantiated for slots [1, 4) and [0, 2): k25 / pad 11, every layer that takes this path)
+  return on && (Cin % 4) == 0 && k4_groups(ks, pad) >= 4 && k4_shift(pad) == 1 && k4_nlast(ks, pad) == 2;
+}
+
+// Wk4[kg * Cout * 4 + co * 4 + m] = W[co][ci][4 g + m - (P - pad)], zero for taps outside [0, ks); plain order
+// kg = ci * NG + g, paired order: see m2d_conv_k4_kernel (all full groups channel-major, then the g = 0 groups, then
+// the g = NG - 1 groups)
 __global__ void __launch_bounds__(256) m2d_pack_weights_k4_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                                                    int Cout, int Cin, int ks, int ng, int shift) {
+                                                                    int Cout, int Cin, int ks, int ng, int shift, int pair) {
   const size_t total = (size_t)Cin * ng * Cout * 4;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int m = (int)(idx & 3);
     const size_t r = idx >> 2;
     const int co = (int)(r % Cout);
     const size_t kg = r / Cout;
-    const int g = (int)(kg % ng), ci = (int)(kg / ng);
+    int g = (int)(kg % ng), ci = (int)(kg / ng);
+    if (pair) {  // regions: Cin * (ng - 2) full groups channel-major, then every channel's g = 0, then every g = ng - 1
+      const int nfull = ng - 2;
+      const size_t r1 = (size_t)Cin * nfull;
+      if (kg < r1) {
+        ci = (int)(kg / nfull);
+        g = 1 + (int)(kg - (size_t)ci * nfull);
+      } else {
+        ci = (int)((kg - r1) % Cin);
+        g = kg - r1 < (size_t)Cin ? 0 : ng - 1;
+      }
+    }
     const int tap = 4 * g + m - shift;
     out[idx] = (tap >= 0 && tap < ks) ? w[((size_t)co * Cin + ci) * ks + tap] : 0.f;
   }
@@ -327,7 +350,7 @@ int m2d_conv1d_pack_weights_k4(const float* w, float* out, int Cout, int Cin, in
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(m2d_pack_weights_k4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, ks,
-                     k4_groups(ks, pad), k4_shift(pad));
+                     k4_groups(ks, pad), k4_shift(pad), k4_paired(Cin, ks, pad));
   M2D_CHECK_LAUNCH("m2d_pack_weights_k4_kernel");
   return M2D_OK;
 }
@@ -354,6 +377,9 @@ int m2d_conv1d_fwd_k4(const float* x, const float* w_k4, const float* bias, floa
   p.nhi = Cin;
   p.kdiv = 4 * ng;
   p.k4_ng = ng;
+  p.k4_pair = k4_paired(Cin, ks, pad);
+  p.k4_shift = k4_shift(pad);
+  p.k4_nlast = k4_nlast(ks, pad);
   p.phases = 1;
   p.A.base = w_k4;
   p.A.nbytes = m2d_extent_bytes((long long)m2d_conv1d_k4_packed_elems(Cout, Cin, ks, pad));

@@ -154,6 +154,7 @@ struct M2dGemmParams {
   // tap-vectorised stride-4 forward conv (m2d_conv_k4_kernel): K is walked in groups of 4 consecutive taps of one
   // channel, k4_ng groups per channel; B.k_hi_stride = the channel pitch (L)
   int k4_ng;
+  int k4_pair, k4_shift, k4_nlast;  // phantom-paired K order: leading phantom slots of group 0, real slots of the last group
   // > 0: the algorithmic FLOPs of the launch when the walked K holds structural zeros (phantom taps): what the
   // profiler reports instead of 2 M N K
   double work_flops;

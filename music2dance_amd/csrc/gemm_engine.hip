@@ -1185,6 +1185,59 @@ __device__ __forceinline__ m2d_f32x4 m2d_ds_read_b128(unsigned addr) {
   return v;
 }
 
+// One 16-deep chunk of the tap-vectorised kernel out of LDS: slots [LO, HI) of its four tap groups (all four = [0, 4)).
+// Fragment reads through inline asm: hipcc otherwise puts an `s_waitcnt vmcnt(0)` in front of the first ds_read of the
+// chunk (it cannot tell that the LDS-DMA just issued fills the OTHER stage), which serialises staging and multiplying.
+// The ordering the hardware needs is explicit: this stage was filled, waited for (vmcnt(0)) and fenced by the barrier
+// at the end of the previous iteration; its reads are waited for below before the MFMAs.
+template <int BM, int BN, int LO, int HI>
+__device__ __forceinline__ void m2d_k4_mma(const float* stage, int wm, int wn, int l31, int lh,
+                                           f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  const unsigned as = m2d_lds_addr(stage + (wm * (TM * 32) + l31) * 4);
+  const unsigned bs = m2d_lds_addr(stage + 16 * BM + (wn * (TN * 32) + l31) * 4);
+  // 64-row tiles read both 8-deep halves of the chunk up front (24 registers); 128-row tiles one half at a time:
+  // 32 fragment registers beside 64 accumulators would not fit the 96 registers of five waves per SIMD
+  constexpr bool UPFRONT = BM == 64;
+  m2d_f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    if (UPFRONT ? s2 == 0 : true) {
+#pragma unroll
+      for (int h2 = (UPFRONT ? 0 : s2); h2 < (UPFRONT ? 2 : s2 + 1); ++h2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[UPFRONT ? h2 : 0][i] = m2d_ds_read_b128(as + (((2 * h2 + lh) * BM + i * 32) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[UPFRONT ? h2 : 0][j] = m2d_ds_read_b128(bs + (((2 * h2 + lh) * BN + j * 32) << 4));
+      }
+    }
+    // reads return in order: the first half's TM + TN are in when at most the second half's are outstanding
+    if (UPFRONT && s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // every register of a fragment quad stays allocated until its read has landed: the compiler takes the asm read's
+    // result as present at once, and with slots left out (LO > 0 or HI < 4) it would hand the unused registers of
+    // the quad to something else while the LDS data is still on its way into them
+    if constexpr (LO > 0 || HI < 4) {
+#pragma unroll
+      for (int h2 = 0; h2 < (UPFRONT ? 2 : 1); ++h2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[h2][i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[h2][j]));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int m = LO; m < HI; ++m)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][m], fb[UPFRONT ? s2 : 0][j][m], acc[i][j], 0, 0, 0);
+    if (!UPFRONT) __builtin_amdgcn_sched_barrier(0);  // the second half's reads reuse the fragment registers
+  }
+}
+
 // ---- tap-vectorised stride-4 forward conv ----------------------------------------------------------------------------
 // y[n, co, l] = sum_{ci, t} W[co, ci, t] x[n, ci, 4 l + t - pad]  (the audio critic's k25 / s4 layers,
 // phase3/archis/default.py:298-303, and the forward-mode tangent of the penalty through them).
@@ -1250,11 +1303,39 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
   const int cps = (nchunks + p.splits - 1) / p.splits;
   const int c0 = split * cps;
   const int c1 = (c0 + cps < nchunks) ? (c0 + cps) : nchunks;
+  // Phantom-paired K order (p.k4_pair; the same order in m2d_pack_weights_k4_kernel): the aligned tap groups of a k25 /
+  // pad 11 layer are g0 = (phantom, 0, 1, 2), g1..g5 full, g6 = (23, 24, phantom, phantom) - 3 of 28 slots multiply
+  // zeros. The MFMA k-pairing puts slot m of one group beside slot m of the NEXT group of its chunk, so when a chunk holds
+  // the g0 groups of four channels (or their g6 groups) whole MFMAs are zero x anything and are left out. K is walked
+  // in three regions, each with its own loop: chunks [0, R1) the full groups (channel-major), [R1, R2) the g0 groups
+  // (slots 1..3 multiplied), [R2, nchunks) the last groups (slots 0..1): the real taps only. The staging cursor is one
+  // function of the chunk index, so the software pipeline runs across the region boundaries.
+  const bool pair = p.k4_pair != 0;
+  const int nfull = ng - 2;
+  const int R1 = pair ? (p.nhi * nfull) >> 2 : nchunks;
+  const int R2 = pair ? R1 + (p.nhi >> 2) : nchunks;
   if (c0 < c1) {
-    // wave-uniform cursor of THIS wave's tap group: kg = 4 c + wave = (ci, g)
+    // wave-uniform cursor of THIS wave's tap group of the chunk being staged (chunk index cs): (ci, g), advanced by
+    // (dci, dg) per chunk - (0, 4) with wraps where groups are walked channel-major, (4, 0) in the paired order's
+    // partial-group regions (one channel per wave and chunk, the group fixed); re-seeded where a region begins
+    int cs = c0;
     int kg = 4 * c0 + wave;
-    int ci = kg / ng;
-    int g = kg - ci * ng;
+    int ci, g, dci = 0, dg = 4;
+    const int period = pair ? nfull : ng;
+    int glim = pair ? 1 + nfull : ng;   // first group index past the walked range (paired region 1: groups 1..ng-2)
+    if (!pair) {
+      ci = kg / ng;
+      g = kg - ci * ng;
+    } else if (c0 < R1) {
+      ci = kg / nfull;
+      g = 1 + kg - ci * nfull;
+    } else {
+      ci = 4 * (c0 - (c0 < R2 ? R1 : R2)) + wave;
+      g = c0 < R2 ? 0 : ng - 1;
+      dci = 4;
+      dg = 0;
+      glim = 0x7fffffff;
+    }
     auto stage = [&](float* st) {
       const bool kok = kg < nkg;
       const int sa = kg * (A.r_lo_stride << 2);                // A.r_lo_stride = Cout * 4 floats per group
@@ -1272,56 +1353,39 @@ __global__ void __launch_bounds__(256, 5) m2d_conv_k4_kernel(const M2dGemmParams
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (m2d_lds_f*)(db + h * 256), 16, (int)(ok ? vb[h] + (unsigned)sb : M2D_OOB), 0, 0, 0);
       }
       kg += 4;
-      g += 4;
-      if (g >= ng) { g -= ng; ci += 1; }
-      if (g >= ng) { g -= ng; ci += 1; }  // ng < 4 (short kernels): at most two wraps per step for ng >= 2
+      cs += 1;
+      if (cs == R1 || cs == R2) {   // (paired order only: R1 = R2 = nchunks otherwise, where nothing real is staged)
+        ci = wave;
+        g = cs == R1 ? 0 : ng - 1;
+        dci = 4;
+        dg = 0;
+        glim = 0x7fffffff;   // (no wraps: the group is fixed from here on)
+      } else {
+        ci += dci;
+        g += dg;
+        if (g >= glim) { g -= period; ci += 1; }
+        if (g >= glim) { g -= period; ci += 1; }  // fewer than 4 groups per period: at most two wraps for >= 2
+      }
     };
     stage(smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     M2D_STAMP_AT(1);
-    for (int c = c0; c < c1; ++c) {
-      const int cur = (c - c0) & 1;
-      stage(smem + (cur ^ 1) * STAGE);  // chunk c + 1 (past the end: zeros or the next split's data, harmless)
-      // Fragment reads through inline asm: hipcc otherwise puts an `s_waitcnt vmcnt(0)` in front of the first ds_read of
-      // the chunk (it cannot tell that the LDS-DMA just issued fills the OTHER stage), which serialises staging and
-      // multiplying. The ordering the hardware needs is explicit here: this stage was filled, waited for (vmcnt(0)) and
-      // fenced by the barrier at the end of the previous iteration; its reads are waited for below before the MFMAs.
-      const unsigned as = m2d_lds_addr(smem + cur * STAGE + (wm * (TM * 32) + l31) * 4);
-      const unsigned bs = m2d_lds_addr(smem + cur * STAGE + 16 * BM + (wn * (TN * 32) + l31) * 4);
-      // 64-row tiles read both 8-deep halves of the chunk up front (24 registers); 128-row tiles one half at a time:
-      // 32 fragment registers beside 64 accumulators would not fit the 96 registers of five waves per SIMD
-      constexpr bool UPFRONT = BM == 64;
-      m2d_f32x4 fa[2][TM], fb[2][TN];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        if (UPFRONT ? s2 == 0 : true) {
-#pragma unroll
-          for (int h2 = (UPFRONT ? 0 : s2); h2 < (UPFRONT ? 2 : s2 + 1); ++h2) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[UPFRONT ? h2 : 0][i] = m2d_ds_read_b128(as + (((2 * h2 + lh) * BM + i * 32) << 4));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[UPFRONT ? h2 : 0][j] = m2d_ds_read_b128(bs + (((2 * h2 + lh) * BN + j * 32) << 4));
-          }
-        }
-        // reads return in order: the first half's TM + TN are in when at most the second half's are outstanding
-        if (UPFRONT && s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][0], fb[UPFRONT ? s2 : 0][j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][1], fb[UPFRONT ? s2 : 0][j][1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][2], fb[UPFRONT ? s2 : 0][j][2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[UPFRONT ? s2 : 0][i][3], fb[UPFRONT ? s2 : 0][j][3], acc[i][j], 0, 0, 0);
-          }
-        if (!UPFRONT) __builtin_amdgcn_sched_barrier(0);  // the second half's reads reuse the fragment registers
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+    // one region's chunks [cb, ce): stage chunk c + 1 (past the end: zeros or the next split's data, harmless) while
+    // slots [LO, HI) of chunk c are multiplied
+#define M2D_K4_REGION(cb, ce, LO, HI)                                                                          \
+    for (int c = (cb); c < (ce); ++c) {                                                                        \
+      const int cur = (c - c0) & 1;                                                                            \
+      stage(smem + (cur ^ 1) * STAGE);                                                                         \
+      m2d_k4_mma<BM, BN, LO, HI>(smem + cur * STAGE, wm, wn, l31, lh, acc);                                    \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+      __syncthreads();                                                                                         \
     }
+    const int e1 = c1 < R1 ? c1 : R1, b2 = c0 > R1 ? c0 : R1, e2 = c1 < R2 ? c1 : R2, b3 = c0 > R2 ? c0 : R2;
+    M2D_K4_REGION(c0, e1, 0, 4)
+    M2D_K4_REGION(b2, e2, 1, 4)
+    M2D_K4_REGION(b3, c1, 0, 2)
+#undef M2D_K4_REGION
   }
   const M2dOutMap& O = p.O;
   M2D_STAMP_AT(2);
