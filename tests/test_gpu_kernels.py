@@ -77,6 +77,14 @@ CONV_CASES = [
     # batch large enough for split-K plans and several column tiles per sample boundary
     ("split.a", 40, 32, 100, 48, 5, 2, 2),
     ("split.b", 70, 16, 33, 130, 3, 1, 1),
+    # tap-vectorised k25 / s4 / pad 11 forwards in the phantom-paired K order: channel counts 16 / 48 /
+    # 64 and batches whose split-K ranges begin inside each of its three regions (full groups, first groups, last groups)
+    ("k4pair.a", 1, 16, 512, 64, 25, 4, 11),
+    ("k4pair.b", 3, 64, 4800, 128, 25, 4, 11),
+    ("k4pair.c", 5, 48, 1024, 64, 25, 4, 11),
+    ("k4pair.d", 9, 32, 2048, 64, 25, 4, 11),
+    # the same kernel on a layer it walks in the plain order (k24: no partial groups at the end)
+    ("k4plain.a", 2, 32, 1024, 64, 24, 4, 11),
 ]
 
 
