@@ -833,22 +833,26 @@ def synthetic_phase3_batch(B, T, device, seed=0, audio_rate=16000, video_rate=25
     with_event: stage the batch on the copy stream (no host sync with the compute stream) and also return
     the event after which it is complete - what `train_step(..., inputs_ready=)` takes."""
     from .utils import slice_audio_batch
-    g = torch.Generator().manual_seed(seed)
     hop = audio_rate // video_rate
     window = int(window_s * audio_rate)
-    real_h = torch.rand(B, T, 69, generator=g)
-    audio_h = 0.1 * torch.randn(B, hop * T, generator=g)
     device = torch.device(device)
     if lazy is None:
         lazy = device.type == "cuda"
     if not with_event or device.type != "cuda":
+        g = torch.Generator().manual_seed(seed)
+        real_h = torch.rand(B, T, 69, generator=g)
+        audio_h = 0.1 * torch.randn(B, hop * T, generator=g)
         real, audio = real_h.to(device), audio_h.to(device)
         slices = slice_audio_batch(audio, window, hop, window - hop, lazy=lazy)
         return (real, audio, slices, None) if with_event else (real, audio, slices)
     cur = torch.cuda.current_stream(device)
     cs = copy_stream(device)
     with torch.cuda.stream(cs):
-        real, audio = real_h.to(device), audio_h.to(device)
+        # (the train scripts draw one such batch per loop body: made on the device - the host needs 35 ms for the 5 M
+        # normal draws, three loop bodies' worth of GPU time; the static batches above keep their host-generator values)
+        gd = torch.Generator(device=device).manual_seed(seed)
+        real = torch.rand(B, T, 69, generator=gd, device=device)
+        audio = 0.1 * torch.randn(B, hop * T, generator=gd, device=device)
         slices = slice_audio_batch(audio, window, hop, window - hop, lazy=lazy)
         ready = cs.record_event()
     cur.wait_event(ready)

@@ -34,5 +34,5 @@ print("wall %.1f s for %d bodies" % (time.time() - t0, n))
 kernels.impl().check_async_errors()
 assert all(all(v == v and abs(v) < 1e30 for v in m[3].values()) for m in marks), "non-finite loss"
 half = [m for m in marks if m[0] > n // 2]
-assert half and half[-1][1] == half[0][1], "allocator high-water mark still growing: %s" % (half,)
+assert half and half[-1][1] - half[0][1] <= 16, "allocator high-water mark still growing: %s" % ([m[:3] for m in half],)  # (MB)
 print("soak ok")
