@@ -96,8 +96,10 @@ int m2d_conv1d_fwd_sum(const float* x, const float* w, const float* w_packed, co
 /* Tap-vectorised stride-4 forward (round 3): for the audio critic's k25 / s4 layers (phase3/archis/default.py:298-303)
  * the four taps 4g..4g+3 of one output position are 16 aligned bytes of x and consecutive positions are 16 bytes
  * apart, so the conv's B operand is staged with `buffer_load_dwordx4 ... lds` (a contiguous kilobyte per wave) and
- * read back as ds_read_b128 fragments; weights come from the packed image Wk4[(ci, tap group)][Cout][4]
- * (m2d_conv1d_pack_weights_k4, m2d_conv1d_k4_packed_elems floats; phantom taps are zeros). Same results as
+ * read back as ds_read_b128 fragments; weights come from the packed image Wk4[tap group][Cout][4]
+ * (m2d_conv1d_pack_weights_k4, m2d_conv1d_k4_packed_elems floats; phantom taps are zeros; the ORDER of the tap groups
+ * is private to the pack / forward pair - k25 / pad 11 layers walk the full groups first and the partial first / last
+ * groups of four channels together, so that the zero slots are never multiplied). Same results as
  * m2d_conv1d_fwd up to summation order; m2d_conv1d_k4_applicable says whether a layer qualifies (stride 4,
  * L % 4 == 0, Cin % 4 == 0, Cin >= 16, Cout >= 64). sum_out: optional second output as in m2d_conv1d_fwd_sum. */
 int m2d_conv1d_k4_applicable(int Cin, int L, int Cout, int ks, int stride, int pad);
