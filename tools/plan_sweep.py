@@ -18,7 +18,8 @@ B = 64
 N = B * 120
 CASES = [("temporal.k7 B32", 32, 128, 120, 128, 7, 1, 3), ("temporal.k7 B64", 64, 128, 120, 128, 7, 1, 3),
          ("temporal.k7 B96", 96, 128, 120, 128, 7, 1, 3), ("temporal.k7 B128", 128, 128, 120, 128, 7, 1, 3),
-         ("temporal.k7 B192", 192, 128, 120, 128, 7, 1, 3),
+         ("temporal.k7 B192", 192, 128, 120, 128, 7, 1, 3), ("temporal.k7 C5 48x300", 48, 128, 300, 128, 7, 1, 3),
+         ("temporal.k7 C5 16x300", 16, 128, 300, 128, 7, 1, 3),
          ("stick.conv1 B64", 64, 69, 120, 128, 25, 1, 12),
          ("audio_d.l2", B, 32, 19200, 64, 25, 4, 11), ("audio_d.l3", B, 64, 4800, 128, 25, 4, 11),
          ("audio_d.l4", B, 128, 1200, 256, 25, 4, 11), ("audio_d.l5", B, 256, 300, 512, 25, 4, 11),
