@@ -189,6 +189,18 @@ int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const floa
                     float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
                     int C, int L, float eps, float momentum, int act, float slope, const float* residual,
                     void* stream);
+/* m2d_bn_fwd / m2d_bn_fwd_sums with y_batch_stride elements between consecutive samples of y (0 or C * L: dense). A
+ * larger stride writes the result into a channel block of a wider (B, C', L) buffer: the U-Net's skip concatenations
+ * (torch.cat((upsample(d), skip), 1), phase3/archis/default.py:240-245) are then produced in place - the skip's
+ * BatchNorm and m2d_upsample2_fwd_to write the two halves, no cat pass over both. */
+int m2d_bn_fwd_to(const float* x, const float* gamma, const float* beta, float* running_mean,
+                  float* running_var, float* y, float* save_mean, float* save_invstd, int B, int C, int L,
+                  float eps, float momentum, int training, int act, float slope, const float* residual, void* ws,
+                  size_t ws_bytes, void* scratch, long long y_batch_stride, void* stream);
+int m2d_bn_fwd_sums_to(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
+                       int C, int L, float eps, float momentum, int act, float slope, const float* residual,
+                       long long y_batch_stride, void* stream);
 int m2d_bn_bwd_stats(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                      const float* save_invstd, double* sums, int B, int C, int L, int act, float slope,
                      void* scratch, void* stream);
@@ -299,6 +311,8 @@ int m2d_adam_multi(const M2dAdamItem* items, int n, float lr, float beta1, float
 int m2d_maxpool2_fwd(const float* x, float* y, size_t rows, int L, void* stream);
 int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, int L, void* stream);
 int m2d_upsample2_fwd(const float* x, float* y, size_t rows, int L, void* stream);
+int m2d_upsample2_fwd_to(const float* x, float* y, size_t B, int C, int L, long long y_batch_stride, void* stream);
+int m2d_maxpool2_fwd_from(const float* x, float* y, size_t B, int C, int L, long long x_batch_stride, void* stream);
 int m2d_upsample2_bwd(const float* dy, float* dx, size_t rows, int L, void* stream);
 
 #ifdef __cplusplus

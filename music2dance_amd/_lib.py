@@ -61,6 +61,9 @@ SIGNATURES = {
     "m2d_bn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F, _F]),
     "m2d_bn_stats": (_I, [_F, _F, _I, _I, _I, _F, _F]),
     "m2d_bn_fwd_sums": (_I, [_F, _F, _c.c_double, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _f, _F, _F]),
+    "m2d_bn_fwd_to": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _I, _f, _F, _F, _S, _F, _c.c_longlong, _F]),
+    "m2d_bn_fwd_sums_to": (_I, [_F, _F, _c.c_double, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _f, _F,
+                                _c.c_longlong, _F]),
     "m2d_bn_bwd_stats": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _F]),
     "m2d_bn_bwd_sums": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _c.c_double, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F]),
     "m2d_channel_sums": (_I, [_F, _F, _f, _F, _I, _I, _I, _F, _S, _F, _F]),
@@ -89,6 +92,8 @@ SIGNATURES = {
     "m2d_maxpool2_fwd": (_I, [_F, _F, _S, _I, _F]),
     "m2d_maxpool2_bwd": (_I, [_F, _F, _F, _S, _I, _F]),
     "m2d_upsample2_fwd": (_I, [_F, _F, _S, _I, _F]),
+    "m2d_upsample2_fwd_to": (_I, [_F, _F, _S, _I, _I, _c.c_longlong, _F]),
+    "m2d_maxpool2_fwd_from": (_I, [_F, _F, _S, _I, _I, _c.c_longlong, _F]),
     "m2d_upsample2_bwd": (_I, [_F, _F, _S, _I, _F]),
 }
 

@@ -314,6 +314,7 @@ struct BnApplyArgs {
   int C, L;
   float L_inv;
   int row_len;            // C*L
+  long long out_pitch;    // elements between consecutive samples of `out` (>= row_len; the inputs are dense)
   int backward, act;
   float slope;
 };
@@ -397,19 +398,24 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
         ov[j] = g[j] * is[j] * (dz - sdz[j] - xh * sdzx[j]);
       }
     }
+    const size_t odx = (size_t)r * (size_t)a.out_pitch + e0;
     if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(a.out + idx) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      *reinterpret_cast<float4*>(a.out + odx) = make_float4(ov[0], ov[1], ov[2], ov[3]);
     } else if constexpr (VEC == 2) {
-      *reinterpret_cast<float2*>(a.out + idx) = make_float2(ov[0], ov[1]);
+      *reinterpret_cast<float2*>(a.out + odx) = make_float2(ov[0], ov[1]);
     } else {
-      a.out[idx] = ov[0];
+      a.out[odx] = ov[0];
     }
   }
 }
 
 static int launch_apply(BnApplyArgs& a, int B, hipStream_t stream) {
-  const bool vec4 = (a.row_len % 4 == 0) && (a.L == 1 || a.L % 4 == 0);
-  const bool vec2 = !vec4 && (a.row_len % 2 == 0) && (a.L == 1 || a.L % 2 == 0);  // e.g. the WaveGAN encoder's L = 794
+  if (a.out_pitch <= 0) a.out_pitch = a.row_len;
+  if (a.out_pitch < a.row_len) M2D_FAIL(M2D_ERR_ARG, "BatchNorm apply: output batch stride smaller than a sample");
+  // (vector stores: the output's sample starts must keep the vector alignment too)
+  const bool vec4 = (a.row_len % 4 == 0) && (a.L == 1 || a.L % 4 == 0) && (a.out_pitch % 4 == 0) && (((uintptr_t)a.out & 15) == 0);
+  const bool vec2 = !vec4 && (a.row_len % 2 == 0) && (a.L == 1 || a.L % 2 == 0) && (a.out_pitch % 2 == 0) &&
+                    (((uintptr_t)a.out & 7) == 0);  // e.g. the WaveGAN encoder's L = 794
   const int rvl = vec4 ? a.row_len / 4 : vec2 ? a.row_len / 2 : a.row_len;
   unsigned gx, gy;
   if (rvl >= 256) {
@@ -456,9 +462,11 @@ static int bn_apply_bwd(const float* dy, const float* x, const float* gamma, con
                         int act, float slope, hipStream_t stream);
 
 static int bn_apply_fwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
-                        float* y, int B, int C, int L, int act, float slope, const float* residual, hipStream_t stream) {
+                        float* y, int B, int C, int L, int act, float slope, const float* residual, hipStream_t stream,
+                        long long y_batch_stride = 0) {
   BnApplyArgs a;
   memset(&a, 0, sizeof(a));
+  a.out_pitch = y_batch_stride;
   a.x = x;
   a.residual = residual;
   a.gamma = gamma; a.beta = beta;
@@ -495,17 +503,27 @@ int m2d_bn_stats(const float* x, double* sums, int B, int C, int L, void* scratc
 
 // Training forward from given sums over `count` elements per channel (count = B*L, or the global
 // count under synchronised BatchNorm): mean / invstd, running statistics, then y = residual + act(bn(x)).
-int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const float* gamma, const float* beta,
-                    float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
-                    int C, int L, float eps, float momentum, int act, float slope, const float* residual,
-                    void* stream_) {
+// (y_batch_stride: elements between consecutive samples of y - 0 or C * L = dense. A larger stride writes the result
+// into a channel block of a wider (B, C', L) buffer: the U-Net's skip concatenations, phase3/archis/default.py:240-245 of
+// the reference, are produced in place instead of by a torch.cat pass over both halves.)
+int m2d_bn_fwd_sums_to(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
+                       int C, int L, float eps, float momentum, int act, float slope, const float* residual,
+                       long long y_batch_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int rc = bn_check("m2d_bn_fwd_sums", B, C, L)) return rc;
   if (!sums || !(count > 0.0)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd_sums: no statistics");
   hipLaunchKernelGGL(m2d_bn_finalize_fwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream, sums, save_mean,
                      save_invstd, running_mean, running_var, C, count, eps, momentum);
   M2D_CHECK_LAUNCH("m2d_bn_finalize_fwd_kernel");
-  return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream);
+  return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream, y_batch_stride);
+}
+int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
+                    int C, int L, float eps, float momentum, int act, float slope, const float* residual,
+                    void* stream_) {
+  return m2d_bn_fwd_sums_to(x, sums, count, gamma, beta, running_mean, running_var, y, save_mean, save_invstd, B, C, L, eps,
+                            momentum, act, slope, residual, 0, stream_);
 }
 
 // Training / eval forward of nn.BatchNorm1d fused with ReLU (act=1) / LeakyReLU (act=2)
@@ -513,10 +531,10 @@ int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const floa
 // training != 0: batch statistics, running stats updated in place (may be NULL),
 //                save_mean / save_invstd (C floats each) written for the backward.
 // training == 0: running statistics; save_* still written (mean, 1/sqrt(var+eps)).
-int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
-               float* running_var, float* y, float* save_mean, float* save_invstd, int B, int C, int L,
-               float eps, float momentum, int training, int act, float slope, const float* residual,
-               void* ws, size_t ws_bytes, void* scratch, void* stream_) {
+int m2d_bn_fwd_to(const float* x, const float* gamma, const float* beta, float* running_mean,
+                  float* running_var, float* y, float* save_mean, float* save_invstd, int B, int C, int L,
+                  float eps, float momentum, int training, int act, float slope, const float* residual,
+                  void* ws, size_t ws_bytes, void* scratch, long long y_batch_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int rc = bn_check("m2d_bn_fwd", B, C, L)) return rc;
   if (ws_bytes < m2d_bn_workspace_bytes(C) || !ws) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_bn_fwd: workspace too small");
@@ -535,18 +553,25 @@ int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* run
       M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 4.0 * B * C * (double)L, "bn_stats", B, C, L);
       if (int rc = launch_reduce(r, stream)) return rc;
     }
-    return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream);
+    return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream, y_batch_stride);
   }
   if (training) {
     if (int rc = m2d_bn_stats(x, (double*)ws, B, C, L, nullptr, stream_)) return rc;
-    return m2d_bn_fwd_sums(x, (const double*)ws, (double)B * L, gamma, beta, running_mean, running_var, y, save_mean,
-                           save_invstd, B, C, L, eps, momentum, act, slope, residual, stream_);
+    return m2d_bn_fwd_sums_to(x, (const double*)ws, (double)B * L, gamma, beta, running_mean, running_var, y, save_mean,
+                              save_invstd, B, C, L, eps, momentum, act, slope, residual, y_batch_stride, stream_);
   }
   if (!running_mean || !running_var) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd: eval mode needs running stats");
   hipLaunchKernelGGL(m2d_bn_eval_stats_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream,
                      (const float*)running_mean, (const float*)running_var, save_mean, save_invstd, C, eps);
   M2D_CHECK_LAUNCH("m2d_bn_eval_stats_kernel");
-  return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream);
+  return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream, y_batch_stride);
+}
+int m2d_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+               float* running_var, float* y, float* save_mean, float* save_invstd, int B, int C, int L,
+               float eps, float momentum, int training, int act, float slope, const float* residual,
+               void* ws, size_t ws_bytes, void* scratch, void* stream_) {
+  return m2d_bn_fwd_to(x, gamma, beta, running_mean, running_var, y, save_mean, save_invstd, B, C, L, eps, momentum, training,
+                       act, slope, residual, ws, ws_bytes, scratch, 0, stream_);
 }
 
 // Backward reductions as raw sums: sums[2c] = sum dz, sums[2c + 1] = sum dz * xhat, with

@@ -360,12 +360,18 @@ __global__ void __launch_bounds__(256) m2d_maxpool2_fwd_kernel(const float* x, f
 
 // L even: rows do not matter - y[i] = max(x[2i], x[2i+1]) over the flat tensor, four outputs (32 B in, 16 B out) per
 // thread and step, no index arithmetic (the row form above does a 64-bit division per output: 5.3 -> 6+ TB/s)
+// (vps > 0: the input's samples - vps 8-float vectors each - are xpitch floats apart: a channel block of a wider buffer)
 __global__ void __launch_bounds__(256) m2d_maxpool2_fwd_flat_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                    size_t nvec) {
+                                                                    size_t nvec, size_t vps, long long xpitch) {
 #pragma unroll 2
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
-    const float4 a = *reinterpret_cast<const float4*>(x + 8 * v);
-    const float4 b = *reinterpret_cast<const float4*>(x + 8 * v + 4);
+    size_t xo = 8 * v;
+    if (vps) {
+      const size_t smp = v / vps;
+      xo = smp * (size_t)xpitch + 8 * (v - smp * vps);
+    }
+    const float4 a = *reinterpret_cast<const float4*>(x + xo);
+    const float4 b = *reinterpret_cast<const float4*>(x + xo + 4);
     float4 o;
     o.x = a.x > a.y ? a.x : a.y;
     o.y = a.z > a.w ? a.z : a.w;
@@ -409,7 +415,16 @@ __global__ void __launch_bounds__(256) m2d_maxpool2_bwd_kernel(const float* x, c
 
 // Upsample(scale_factor=2, mode="linear", align_corners=False):
 //   src = max((j + 0.5) / 2 - 0.5, 0); i0 = floor(src); i1 = min(i0 + 1, L - 1); w = src - i0
-__global__ void __launch_bounds__(256) m2d_upsample2_fwd_kernel(const float* x, float* y, size_t rows, int L) {
+// (C, ypitch: the output row r = (b, c) starts at b * ypitch + c * 2L - the result may be a channel block of a wider
+// buffer; C == 0: dense rows)
+__device__ __forceinline__ size_t m2d_up_row(size_t r, int L, int C, long long ypitch) {
+  if (C <= 0) return r * 2 * (size_t)L;
+  const size_t b = r / (size_t)C;
+  return b * (size_t)ypitch + (r - b * (size_t)C) * 2 * (size_t)L;
+}
+
+__global__ void __launch_bounds__(256) m2d_upsample2_fwd_kernel(const float* x, float* y, size_t rows, int L, int C,
+                                                                long long ypitch) {
   const int Lo = 2 * L;
   const size_t total = rows * Lo;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -421,7 +436,7 @@ __global__ void __launch_bounds__(256) m2d_upsample2_fwd_kernel(const float* x, 
     const int i1 = i0 + 1 < L ? i0 + 1 : L - 1;
     const float w1 = src - (float)i0;
     const float w0 = 1.0f - w1;
-    y[i] = w0 * x[r * L + i0] + w1 * x[r * L + i1];
+    y[m2d_up_row(r, L, C, ypitch) + j] = w0 * x[r * L + i0] + w1 * x[r * L + i1];
   }
 }
 
@@ -429,7 +444,7 @@ __global__ void __launch_bounds__(256) m2d_upsample2_fwd_kernel(const float* x, 
 // eight outputs (two 16-byte stores), walking the rows with a fixed position - no division per element. Same
 // expression per output as the kernel above (w0 * x[i0] + w1 * x[i1] with w in {1, 0.75, 0.25, 0}): same bits.
 __global__ void __launch_bounds__(256) m2d_upsample2_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                    size_t rows, int L) {
+                                                                    size_t rows, int L, int C, long long ypitch) {
   const int rvl = L >> 2;  // vectors per row (<= 256: launcher-checked)
   const int rpb = 256 / rvl;
   const int pv = threadIdx.x % rvl, rib = threadIdx.x / rvl;
@@ -452,7 +467,7 @@ __global__ void __launch_bounds__(256) m2d_upsample2_fwd_vec_kernel(const float*
     o[3] = 0.75f * c.y + 0.25f * c.z;
     o[5] = 0.75f * c.z + 0.25f * c.w;
     o[7] = 0.75f * c.w + 0.25f * rgt;
-    float* yr = y + r * 2 * L + 2 * p0;
+    float* yr = y + m2d_up_row(r, L, C, ypitch) + 2 * p0;
     *reinterpret_cast<float4*>(yr) = make_float4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<float4*>(yr + 4) = make_float4(o[4], o[5], o[6], o[7]);
   }
@@ -461,7 +476,7 @@ __global__ void __launch_bounds__(256) m2d_upsample2_fwd_vec_kernel(const float*
 // any L <= 256: a thread owns ONE input position of a row (three scalar loads from the same lines) and writes its two
 // outputs as one 8-byte store, walking the rows with a fixed position. Same expressions: same bits.
 __global__ void __launch_bounds__(256) m2d_upsample2_fwd_row_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                    size_t rows, int L) {
+                                                                    size_t rows, int L, int C, long long ypitch) {
   const int rpb = 256 / L;
   const int p = threadIdx.x % L, rib = threadIdx.x / L;
   if (rib >= rpb) return;
@@ -474,7 +489,7 @@ __global__ void __launch_bounds__(256) m2d_upsample2_fwd_row_kernel(const float*
     float2 o;
     o.x = p > 0 ? 0.25f * lft + 0.75f * c : 1.0f * c + 0.0f * rgt;
     o.y = 0.75f * c + 0.25f * rgt;
-    *reinterpret_cast<float2*>(y + r * 2 * L + 2 * p) = o;
+    *reinterpret_cast<float2*>(y + m2d_up_row(r, L, C, ypitch) + 2 * p) = o;
   }
 }
 
@@ -727,9 +742,26 @@ int m2d_maxpool2_fwd(const float* x, float* y, size_t rows, int L, void* stream_
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 6.0 * rows * (double)L, "maxpool2_fwd");
   if (L == 2 * Lout && (rows * Lout) % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0)
     hipLaunchKernelGGL(m2d_maxpool2_fwd_flat_kernel, dim3(grid_for(rows * Lout / 4, 4096)), dim3(256), 0, stream, x, y,
-                       rows * Lout / 4);
+                       rows * Lout / 4, (size_t)0, 0LL);
   else
     hipLaunchKernelGGL(m2d_maxpool2_fwd_kernel, dim3(grid_for(rows * Lout, 4096)), dim3(256), 0, stream, x, y, rows, L, Lout);
+  M2D_CHECK_LAUNCH("m2d_maxpool2_fwd");
+  return M2D_OK;
+}
+// x: (B, C, L) whose samples are x_batch_stride floats apart (a channel block of a wider buffer, see
+// m2d_upsample2_fwd_to); y dense (B, C, L / 2). L even, C * L a multiple of 8, 16-byte aligned sample starts.
+int m2d_maxpool2_fwd_from(const float* x, float* y, size_t B, int C, int L, long long x_batch_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B == 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_maxpool2_fwd: bad shape");
+  const long long cl = (long long)C * L;
+  if (x_batch_stride <= 0 || x_batch_stride == cl) return m2d_maxpool2_fwd(x, y, B * (size_t)C, L, stream_);
+  if ((L & 1) || (cl & 7) || x_batch_stride < cl || (x_batch_stride & 3) || (((uintptr_t)x | (uintptr_t)y) & 15u))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_maxpool2_fwd_from: L even, C * L %% 8 == 0, 16-byte aligned samples");
+  const size_t rows = B * (size_t)C;
+  M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 6.0 * rows * (double)L, "maxpool2_fwd");
+  const size_t nvec = rows * (size_t)(L / 2) / 4;
+  hipLaunchKernelGGL(m2d_maxpool2_fwd_flat_kernel, dim3(grid_for(nvec, 4096)), dim3(256), 0, stream, x, y, nvec,
+                     (size_t)(cl / 8), x_batch_stride);
   M2D_CHECK_LAUNCH("m2d_maxpool2_fwd");
   return M2D_OK;
 }
@@ -749,23 +781,33 @@ int m2d_maxpool2_bwd(const float* x, const float* dy, float* dx, size_t rows, in
 }
 
 // nn.Upsample(scale_factor=2, mode="linear", align_corners=False) (phase3/archis/default.py:236)
-int m2d_upsample2_fwd(const float* x, float* y, size_t rows, int L, void* stream_) {
+// x (B, C, L) -> y: sample b's channels at y + b * y_batch_stride (y_batch_stride 0 or C * 2L: dense (B, C, 2L)); a larger
+// stride writes into a channel block of a wider buffer (the U-Net's skip concatenation made in place)
+int m2d_upsample2_fwd_to(const float* x, float* y, size_t B, int C, int L, long long y_batch_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (rows == 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_fwd: bad shape");
+  if (B == 0 || C <= 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_fwd: bad shape");
+  const size_t rows = B * (size_t)C;
+  const bool dense = y_batch_stride <= 0 || y_batch_stride == (long long)C * 2 * L;
+  if (!dense && y_batch_stride < (long long)C * 2 * L) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_fwd: output batch stride smaller than a sample");
+  const int Cp = dense ? 0 : C;
+  const long long yp = dense ? 0 : y_batch_stride;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L, "upsample2_fwd");
-  if ((L & 3) == 0 && L <= 1024 && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0) {
+  if ((L & 3) == 0 && L <= 1024 && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && (yp & 3) == 0) {
     const size_t rpb = 256 / (L >> 2);
     hipLaunchKernelGGL(m2d_upsample2_fwd_vec_kernel, dim3(grid_for((rows + rpb - 1) / rpb * 256, 4096)), dim3(256), 0, stream,
-                       x, y, rows, L);
-  } else if (L <= 256 && ((uintptr_t)y & 7u) == 0) {
+                       x, y, rows, L, Cp, yp);
+  } else if (L <= 256 && ((uintptr_t)y & 7u) == 0 && (yp & 1) == 0) {
     const size_t rpb = 256 / L;
     hipLaunchKernelGGL(m2d_upsample2_fwd_row_kernel, dim3(grid_for((rows + rpb - 1) / rpb * 256, 8192)), dim3(256), 0, stream,
-                       x, y, rows, L);
+                       x, y, rows, L, Cp, yp);
   } else {
-    hipLaunchKernelGGL(m2d_upsample2_fwd_kernel, dim3(grid_for(rows * 2 * L, 4096)), dim3(256), 0, stream, x, y, rows, L);
+    hipLaunchKernelGGL(m2d_upsample2_fwd_kernel, dim3(grid_for(rows * 2 * L, 4096)), dim3(256), 0, stream, x, y, rows, L, Cp, yp);
   }
   M2D_CHECK_LAUNCH("m2d_upsample2_fwd");
   return M2D_OK;
+}
+int m2d_upsample2_fwd(const float* x, float* y, size_t rows, int L, void* stream_) {
+  return m2d_upsample2_fwd_to(x, y, rows, 1, L, 0, stream_);
 }
 
 int m2d_upsample2_bwd(const float* dy, float* dx, size_t rows, int L, void* stream_) {

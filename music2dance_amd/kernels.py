@@ -655,21 +655,31 @@ class HipKernels:
         _lib.check(rc, "m2d_channel_sums")
         return out
 
+    @staticmethod
+    def _out_block(out, like):
+        """`out`: where a (B, C, L) result goes when it is a channel block of a wider buffer - a view shaped like the
+        result whose samples are out.stride(0) elements apart, dense inside a sample. -> (tensor, batch stride)"""
+        if out is None:
+            return torch.empty_like(like), 0
+        assert out.shape == like.shape and out.dtype == torch.float32 and out.device == like.device
+        assert out.dim() == 3 and out.stride(2) == 1 and out.stride(1) == out.shape[2] and out.stride(0) >= out.shape[1] * out.shape[2]
+        return out, out.stride(0)
+
     def bn_fwd(self, x, gamma, beta, running_mean, running_var, training, eps, momentum, act=0, slope=0.0,
-               residual=None):
+               residual=None, out=None):
         dev = _chk(x, gamma, beta, running_mean, running_var, residual)
         B, C = x.shape[0], x.shape[1]
         L = x.shape[2] if x.dim() == 3 else 1
-        y = torch.empty_like(x)
+        y, ypitch = self._out_block(out, x)
         save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
         save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
         h = _lib.lib()
         ws = _ws(_ws_bytes('m2d_bn_workspace_bytes', C), dev)
         with _on(dev):
-            rc = h.m2d_bn_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
-                              _ptr(save_mean), _ptr(save_invstd), B, C, L, eps, momentum, 1 if training else 0,
-                              act, slope, _ptr(residual), _ptr(ws), ws.numel() * 4,
-                              _ptr(_bn_scratch(dev, C)) if training else 0, _stream(dev))
+            rc = h.m2d_bn_fwd_to(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
+                                 _ptr(save_mean), _ptr(save_invstd), B, C, L, eps, momentum, 1 if training else 0,
+                                 act, slope, _ptr(residual), _ptr(ws), ws.numel() * 4,
+                                 _ptr(_bn_scratch(dev, C)) if training else 0, ypitch, _stream(dev))
         _lib.check(rc, "m2d_bn_fwd")
         return y, save_mean, save_invstd
 
@@ -690,21 +700,21 @@ class HipKernels:
         return sums
 
     def bn_fwd_sums(self, x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act=0, slope=0.0,
-                    residual=None):
+                    residual=None, out=None):
         """Training forward from batch sums over `count` elements per channel (bn_stats, a conv's epilogue, or
         their all-reduce across data-parallel ranks). -> y, save_mean, save_invstd."""
         dev = _chk(x, gamma, beta, running_mean, running_var, residual)
         B, C = x.shape[0], x.shape[1]
         L = x.shape[2] if x.dim() == 3 else 1
         self._sums_ok(sums, C, dev)
-        y = torch.empty_like(x)
+        y, ypitch = self._out_block(out, x)
         save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
         save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
         with _on(dev):
-            rc = _lib.lib().m2d_bn_fwd_sums(_ptr(x), _ptr(sums), float(count), _ptr(gamma), _ptr(beta),
-                                            _ptr(running_mean), _ptr(running_var), _ptr(y), _ptr(save_mean),
-                                            _ptr(save_invstd), B, C, L, eps, momentum, act, slope, _ptr(residual),
-                                            _stream(dev))
+            rc = _lib.lib().m2d_bn_fwd_sums_to(_ptr(x), _ptr(sums), float(count), _ptr(gamma), _ptr(beta),
+                                               _ptr(running_mean), _ptr(running_var), _ptr(y), _ptr(save_mean),
+                                               _ptr(save_invstd), B, C, L, eps, momentum, act, slope, _ptr(residual),
+                                               ypitch, _stream(dev))
         _lib.check(rc, "m2d_bn_fwd_sums")
         return y, save_mean, save_invstd
 
@@ -977,8 +987,18 @@ class HipKernels:
 
     # ---------------------------------------------------------------- U-Net resampling
     def maxpool2_fwd(self, x):
-        dev = _chk(x)
+        """x: (B, C, L) dense, or a channel block of a wider buffer (samples x.stride(0) apart, dense inside)"""
         B, C, L = x.shape
+        if not x.is_contiguous() and x.stride(2) == 1 and x.stride(1) == L and x.stride(0) > C * L and x.is_cuda \
+                and x.dtype == torch.float32 and L % 2 == 0 and (C * L) % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+            dev = x.device
+            y = torch.empty((B, C, L // 2), dtype=torch.float32, device=dev)
+            with _on(dev):
+                rc = _lib.lib().m2d_maxpool2_fwd_from(_ptr(x), _ptr(y), B, C, L, x.stride(0), _stream(dev))
+            _lib.check(rc, "m2d_maxpool2_fwd_from")
+            return y
+        x = x if x.is_contiguous() else x.contiguous()
+        dev = _chk(x)
         y = torch.empty((B, C, L // 2), dtype=torch.float32, device=dev)
         with _on(dev):
             rc = _lib.lib().m2d_maxpool2_fwd(_ptr(x), _ptr(y), B * C, L, _stream(dev))
@@ -994,12 +1014,17 @@ class HipKernels:
         _lib.check(rc, "m2d_maxpool2_bwd")
         return dx
 
-    def upsample2_fwd(self, x):
+    def upsample2_fwd(self, x, out=None):
         dev = _chk(x)
         B, C, L = x.shape
-        y = torch.empty((B, C, 2 * L), dtype=torch.float32, device=dev)
+        if out is None:
+            y, ypitch = torch.empty((B, C, 2 * L), dtype=torch.float32, device=dev), 0
+        else:
+            assert tuple(out.shape) == (B, C, 2 * L) and out.dtype == torch.float32 and out.device == dev
+            assert out.stride(2) == 1 and out.stride(1) == 2 * L and out.stride(0) >= 2 * C * L
+            y, ypitch = out, out.stride(0)
         with _on(dev):
-            rc = _lib.lib().m2d_upsample2_fwd(_ptr(x), _ptr(y), B * C, L, _stream(dev))
+            rc = _lib.lib().m2d_upsample2_fwd_to(_ptr(x), _ptr(y), B, C, L, ypitch, _stream(dev))
         _lib.check(rc, "m2d_upsample2_fwd")
         return y
 

@@ -99,14 +99,15 @@ class BatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d on (N, C) / (N, C, L) with the following ReLU / LeakyReLU and an
     optional residual add fused into the normalisation pass."""
 
-    def forward(self, x, act=ops.ACT_NONE, slope=0.0, residual=None, sums=None):
-        """sums: batch statistics of x from the producing conv's epilogue (Conv1d(..., with_stats=True))."""
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0, residual=None, sums=None, out=None):
+        """sums: batch statistics of x from the producing conv's epilogue (Conv1d(..., with_stats=True)).
+        out: ops.batch_norm's (no autograd graph only)."""
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError("m2d BatchNorm1d: only the reference's configuration is supported")
         if self.training and not _BN_COUNT_BATCHED[0]:
             self.num_batches_tracked.add_(1)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                              self.eps, self.momentum, act, slope, residual, sums if self.training else None)
+                              self.eps, self.momentum, act, slope, residual, sums if self.training else None, out)
 
     @torch.no_grad()
     def observe(self, x):

@@ -488,31 +488,39 @@ def _global_count(local_count, device):
     return g
 
 
+def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, eps, momentum, act, slope, sums, out=None):
+    """-> (y, mean, invstd, world); out: see kernels.bn_fwd (the result written into a channel block of a wider buffer)"""
+    x, residual = _c(x), _c(residual)
+    world = 1
+    if training:
+        world = _sync_world()
+    kw = {} if out is None else {"out": out}
+    if training and sums is None and world == 1:
+        # one process, no sums handed over: statistics, mean / invstd and the running buffers in one launch
+        y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, True, eps, momentum, act, slope,
+                                     residual, **kw)
+    elif training:
+        # batch statistics as raw sums: from the producing conv's epilogue when it supplied them
+        if sums is None:
+            sums = K().bn_stats(x)
+        count = float(x.numel() // x.shape[1])
+        if world > 1:
+            sums = _all_reduce_sums(sums)
+            count = _global_count(count, x.device)
+        y, mean, invstd = K().bn_fwd_sums(x, sums, count, gamma, beta, running_mean, running_var, eps, momentum,
+                                          act, slope, residual, **kw)
+    else:
+        y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, False, eps, momentum, act,
+                                     slope, residual, **kw)
+    return x, y, mean, invstd, world
+
+
 class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, eps, momentum, act, slope, sums):
         ctx.set_materialize_grads(False)
-        x, residual = _c(x), _c(residual)
-        world = 1
-        if training:
-            world = _sync_world()
-        if training and sums is None and world == 1:
-            # one process, no sums handed over: statistics, mean / invstd and the running buffers in one launch
-            y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, True, eps, momentum, act, slope,
-                                         residual)
-        elif training:
-            # batch statistics as raw sums: from the producing conv's epilogue when it supplied them
-            if sums is None:
-                sums = K().bn_stats(x)
-            count = float(x.numel() // x.shape[1])
-            if world > 1:
-                sums = _all_reduce_sums(sums)
-                count = _global_count(count, x.device)
-            y, mean, invstd = K().bn_fwd_sums(x, sums, count, gamma, beta, running_mean, running_var, eps, momentum,
-                                              act, slope, residual)
-        else:
-            y, mean, invstd = K().bn_fwd(x, gamma, beta, running_mean, running_var, False, eps, momentum, act,
-                                         slope, residual)
+        x, y, mean, invstd, world = _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, eps,
+                                                momentum, act, slope, sums)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.cfg = (training, act, slope, residual is not None, world)
         return y
@@ -538,9 +546,15 @@ class _BatchNormAct(Function):
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=ACT_NONE,
-               slope=0.0, residual=None, sums=None):
+               slope=0.0, residual=None, sums=None, out=None):
     """y = residual + act(batch_norm(x)); running buffers are updated in place when training.
-    sums: the batch statistics of x as raw sums (conv1d(..., with_stats=True)), else computed here."""
+    sums: the batch statistics of x as raw sums (conv1d(..., with_stats=True)), else computed here.
+    out (no autograd graph only): a (B, C, L) view whose samples are out.stride(0) apart - the result is written there
+    (a channel block of a wider buffer: UBlock's skip concatenations made in place)."""
+    if out is not None:
+        assert not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, gamma, beta, residual)))
+        return _bn_forward(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps), float(momentum),
+                           int(act), float(slope), sums, out)[1]
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps),
                                float(momentum), int(act), float(slope), sums)
 
@@ -772,8 +786,15 @@ class _Upsample2(Function):
 
 
 def maxpool2(x):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return K().maxpool2_fwd(x)   # (takes a channel block of a wider buffer as it is: UBlock's in-place concatenations)
     return _MaxPool2.apply(x)
 
 
-def upsample2_linear(x):
+def upsample2_linear(x, out=None):
+    """nn.Upsample(scale_factor=2, mode='linear', align_corners=False) on (B, C, L). out (no autograd graph only): as
+    batch_norm's - a channel block of a wider buffer to write into."""
+    if out is not None:
+        assert not (torch.is_grad_enabled() and x.requires_grad)
+        return K().upsample2_fwd(_c(x), out=out)
     return _Upsample2.apply(x)

@@ -33,17 +33,17 @@ _FUSED_BN_STATS = os.environ.get("M2D_FUSED_BN_STATS", "1") != "0"  # dev switch
 RELU_IN = (ops.ACT_RELU, 0.0)  # "my input is the sole-consumer output of a fused conv + ReLU" (ops.conv1d)
 
 
-def _conv_bn(conv, bn, x, act, slope=0.0):
+def _conv_bn(conv, bn, x, act, slope=0.0, into=None):
     """bn(conv(x)) + activation. In training mode the conv's epilogue hands the BatchNorm its batch
     statistics (no second pass over the activation); x may be a WindowView of the padded track
-    (first encoder conv: the audio windows are read in place)."""
+    (first encoder conv: the audio windows are read in place). into: ops.batch_norm's `out`."""
     stats = bn.training and _FUSED_BN_STATS
     if isinstance(x, WindowView):
         out = conv.forward_windows(x.track, x.T, x.hop, x.window, with_stats=stats)
     else:
         out = conv(x, with_stats=stats)
     y, sums = out if stats else (out, None)
-    return bn(y, act=act, slope=slope, sums=sums)
+    return bn(y, act=act, slope=slope, sums=sums, out=into)
 
 
 def _head(module, conv, x, in_act=None):
@@ -148,8 +148,8 @@ class BasisConvBlock(nn.Module):
         self.bn = BatchNorm1d(channels_out)
         self.relu = nn.LeakyReLU(0.2)
 
-    def forward(self, x):
-        return _conv_bn(self.conv, self.bn, x, ops.ACT_LEAKY, 0.2)
+    def forward(self, x, out=None):
+        return _conv_bn(self.conv, self.bn, x, ops.ACT_LEAKY, 0.2, into=out)
 
 
 class UBlock(nn.Module):
@@ -168,6 +168,24 @@ class UBlock(nn.Module):
         self.upsample = nn.Upsample(scale_factor=2, mode="linear", align_corners=False)
 
     def forward(self, x):
+        if not torch.is_grad_enabled() and x.dim() == 3 and x.shape[2] % 8 == 0:
+            # no autograd graph (the critic iterations' generator forward, validation, sampling): the three skip
+            # concatenations are never copied together - each skip's BatchNorm and the upsampling write the two channel
+            # halves of one (B, 2C, L) buffer (m2d_bn_fwd_sums_to / m2d_upsample2_fwd_to). Same values, same order.
+            B, C, L = x.shape
+            cat1 = torch.empty((B, 2 * C, L), dtype=x.dtype, device=x.device)
+            cat2 = torch.empty((B, 2 * C, L // 2), dtype=x.dtype, device=x.device)
+            cat3 = torch.empty((B, 2 * C, L // 4), dtype=x.dtype, device=x.device)
+            d1 = self.convblock1(x, out=cat1[:, C:])
+            d2 = self.convblock2(ops.maxpool2(d1), out=cat2[:, C:])
+            d3 = self.convblock3(ops.maxpool2(d2), out=cat3[:, C:])
+            d4 = self.convblock4(ops.maxpool2(d3))
+            ops.upsample2_linear(d4, out=cat3[:, :C])
+            u3 = self.convblock5(cat3)
+            ops.upsample2_linear(u3, out=cat2[:, :C])
+            u2 = self.convblock6(cat2)
+            ops.upsample2_linear(u2, out=cat1[:, :C])
+            return self.convblock7(cat1)
         d1 = self.convblock1(x)
         d2 = self.convblock2(ops.maxpool2(d1))
         d3 = self.convblock3(ops.maxpool2(d2))

@@ -144,8 +144,16 @@ class FakeKernels:
             x = x * _mf(mask, slope)
         return x.sum(dim=(0, 2)) if x.dim() == 3 else x.sum(dim=0)
 
+    @staticmethod
+    def _into(out, y):
+        """the `out` contract of the kernel layer: write the result into a channel block of a wider buffer"""
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+
     def bn_fwd(self, x, gamma, beta, running_mean, running_var, training, eps, momentum, act=0, slope=0.0,
-               residual=None):
+               residual=None, out=None):
         dims = (0,) if x.dim() == 2 else (0, 2)
         shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
         if training:
@@ -161,7 +169,7 @@ class FakeKernels:
         y = _act((x - mean.view(shape)) * invstd.view(shape) * gamma.view(shape) + beta.view(shape), act, slope)
         if residual is not None:
             y = y + residual
-        return y, mean, invstd
+        return self._into(out, y), mean, invstd
 
     @staticmethod
     def _interleave(a, b):
@@ -173,7 +181,7 @@ class FakeKernels:
         return self._interleave(xd.sum(dims), (xd * xd).sum(dims))
 
     def bn_fwd_sums(self, x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act=0, slope=0.0,
-                    residual=None):
+                    residual=None, out=None):
         shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
         mean64 = sums[0::2] / count
         var64 = (sums[1::2] / count - mean64 * mean64).clamp_min(0.0)
@@ -185,7 +193,7 @@ class FakeKernels:
         y = _act((x - mean.view(shape)) * invstd.view(shape) * gamma.view(shape) + beta.view(shape), act, slope)
         if residual is not None:
             y = y + residual
-        return y, mean, invstd
+        return self._into(out, y), mean, invstd
 
     def _bn_dz(self, dy, x, gamma, beta, save_mean, save_invstd, act, slope):
         shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
@@ -345,8 +353,8 @@ class FakeKernels:
             y = F.max_pool1d(xr, 2, 2)
         return torch.autograd.grad(y, xr, dy)[0]
 
-    def upsample2_fwd(self, x):
-        return F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
+    def upsample2_fwd(self, x, out=None):
+        return self._into(out, F.interpolate(x, scale_factor=2, mode="linear", align_corners=False))
 
     def upsample2_bwd(self, dy):
         B, C, Lo = dy.shape

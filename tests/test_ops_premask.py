@@ -54,3 +54,23 @@ def test_premasked_chain_matches_masked_operands(dev, act, slope):
     for a, b in zip(*res):
         scale = float(a.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_unet_block_without_a_graph_makes_its_concatenations_in_place(dev, training):
+    """UBlock (phase3/archis/default.py:213-246 of the reference) under no_grad writes every skip concatenation's halves
+    straight into one buffer (BatchNorm / upsampling with an output batch stride, max-pool reading a channel block):
+    bit-identical to the torch.cat path the autograd forward takes, running statistics included."""
+    import copy
+    from music2dance_amd.phase3.archis.default import UBlock
+    torch.manual_seed(3)
+    blk = UBlock(16).to(dev)
+    blk.train(training)
+    x = torch.randn(5, 16, 200, generator=torch.Generator().manual_seed(1)).to(dev)
+    ref_blk = copy.deepcopy(blk)
+    ref = ref_blk(x.clone().requires_grad_(True)).detach()        # autograd path: torch.cat
+    with torch.no_grad():
+        got = blk(x)                                               # in-place concatenations
+    assert torch.equal(got, ref)
+    for a, b in zip(blk.buffers(), ref_blk.buffers()):
+        assert torch.equal(a, b)
