@@ -106,8 +106,11 @@ def cpu_baseline(full_b=64, sample_b=32, T=120, threads=None, cap_s=75.0):
     t_w = time.perf_counter() - t0
     if 9.5 * t_w <= cap_s:
         t1 = time.perf_counter()
-        O.p3_train_iterations(gsd, dsd, O.P3Config(n_critic=8), real, audio, slices, 8, 0)  # 8 critic + 1 generator
+        trace, _, _ = O.p3_train_iterations(gsd, dsd, O.P3Config(n_critic=8), real, audio, slices, 8, PARITY_SEED)  # 8 critic + 1 generator
         cycle = time.perf_counter() - t1
+        # the cycle just timed is also a B = 64 loss trace from known weights / batch / draws: parity_at_bench_size()
+        # replays it on the GPU (outside every timed region)
+        host["_parity"] = dict(gsd=gsd, dsd=dsd, batch=(real, audio, slices), n_critic=8, iters=8, trace=trace)
         return dict({"value": round(8.0 * full_b / cycle, 3), "unit": "seq/s", "cores": cores, "kind": "port",
                      "sample": "MEASURED: one whole 8+1 cycle of the oracle's phase-3 default-encoder step at batch %d "
                                "(%.1f s, after one warm-up critic iteration of %.1f s)" % (full_b, cycle, t_w)}, **host)
@@ -117,8 +120,9 @@ def cpu_baseline(full_b=64, sample_b=32, T=120, threads=None, cap_s=75.0):
     t1 = time.perf_counter()
     O.p3_train_iterations(gsd, dsd, crit_only, real, audio, slices, 2, 0)  # 2 critic iterations
     t2 = time.perf_counter()
-    O.p3_train_iterations(gsd, dsd, O.P3Config(n_critic=1), real, audio, slices, 2, 0)  # 2 x (critic + generator)
+    trace, _, _ = O.p3_train_iterations(gsd, dsd, O.P3Config(n_critic=1), real, audio, slices, 2, PARITY_SEED)  # 2 x (critic + generator)
     t3 = time.perf_counter()
+    host["_parity"] = dict(gsd=gsd, dsd=dsd, batch=(real, audio, slices), n_critic=1, iters=2, trace=trace)
     t_critic = (t2 - t1) / 2.0
     t_gen = max((t3 - t2) / 2.0 - t_critic, 0.0)
     cycle = 8 * t_critic + t_gen
@@ -127,6 +131,104 @@ def cpu_baseline(full_b=64, sample_b=32, T=120, threads=None, cap_s=75.0):
                            "oracle step at batch %d, 5 critic + 2 generator iterations (%.1f s), scaled to one 8+1 cycle; "
                            "critic %.2f s, generator %.2f s per iteration"
                            % (full_b, t_w, int(cap_s), sample_b, t3 - t0, t_critic, t_gen)}, **host)
+
+
+PARITY_SEED = 0  # host-generator seed of the oracle's timed cycle and of its GPU replay (noise / alpha draws)
+
+
+def parity_at_bench_size(pay, device):
+    """The oracle cycle `cpu_baseline` has just timed, replayed by a FRESH engine on the GPU: same constructor-seeded
+    weights, same synthetic batch (drawn on the host, copied over), same host-generator seed, so the generator noise and
+    the penalty's interpolation weights are the same draws in the reference's order (phase3/archis/default.py:31-34,
+    losses.py:15). Eager, no pipelining (no `inputs_ready`): the draw order is the reference's. Runs after the timed
+    region and after the roofline pass; the oracle is the checker here, never the thing measured.
+    -> {"steps", "batch", per scalar: worst relative error over the steps, "worst_rel"}"""
+    from music2dance_amd.engine import Phase3Engine
+    gen, critic = build_models("cpu")
+    gen.load_state_dict(pay["gsd"]), critic.load_state_dict(pay["dsd"])
+    gen.to(device), critic.to(device)
+    gen.train(), critic.train()
+    cfg = dict(P3_DEFAULT, n_critic_steps=pay["n_critic"])
+    eng = Phase3Engine(gen, critic, cfg, data_parallel=False)
+    from music2dance_amd.utils import slice_audio_batch
+    real, audio = (t.to(device) for t in pay["batch"][:2])
+    win = pay["batch"][2].shape[-1]
+    hop = audio.shape[1] // pay["batch"][2].shape[1]
+    slices = slice_audio_batch(audio, win, hop, win - hop, lazy=True)  # the window view the timed region uses
+    torch.manual_seed(PARITY_SEED)
+    got = {"loss_critic": [], "gp": [], "w_dist": [], "loss_gen": [], "l1_loss_train": []}
+    for _ in range(pay["iters"]):
+        out = eng.train_step(real, audio, slices)
+        for k in got:
+            if k in out:
+                got[k].append(float(out[k]))
+    eng.flush()
+    tr = pay["trace"]
+    want = {"loss_critic": tr["loss_critic"], "gp": tr["gp"], "w_dist": tr["w_dist"], "loss_gen": tr["loss_gen"],
+            "l1_loss_train": tr["err_l1"]}
+    res = {"steps": pay["iters"], "batch": int(real.shape[0]), "generator_iterations": len(want["loss_gen"]),
+           "rel": "|gpu - oracle| / max(|oracle|, 1e-3), worst over the steps"}
+    worst = 0.0
+    for k, w in want.items():
+        g = got[k]
+        if len(g) != len(w):
+            res[k] = "length mismatch: %d vs %d" % (len(g), len(w))
+            worst = float("inf")
+            continue
+        e = max([abs(a - b) / max(abs(b), 1e-3) for a, b in zip(g, w)] + [0.0])
+        res[k] = float("%.3e" % e)
+        worst = max(worst, e)
+    res["worst_rel"] = float("%.3e" % worst)
+    res["oracle_last"] = {k: (w[-1] if w else None) for k, w in want.items()}
+    res["gpu_last"] = {k: (g[-1] if g else None) for k, g in got.items()}
+    return res
+
+
+def dist_info(rank, world, local, device, engine):
+    """What a reader of a multi-GPU line needs to check that it ran as claimed: world size and backend as
+    torch.distributed reports them, the RCCL version, every rank's device, and how many gradient buckets left
+    underneath the backward pass (dp.GradExchange.launched_in_backward) on this rank."""
+    info = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "backend": dist.get_backend() if dist.is_initialized() else None,
+            "rccl_version": None, "devices": None}
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        pass
+    mine = "rank %d: cuda:%d %s" % (rank, local, torch.cuda.get_device_name(device))
+    if dist.is_initialized() and world > 1:
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        info["devices"] = allr
+    else:
+        info["devices"] = [mine]
+    for name in ("x_critic", "x_gen"):
+        x = getattr(engine, name, None)
+        if x is not None:
+            info[name] = {"active": bool(x.active), "buckets": len(x.buckets),
+                          "launched_in_backward": int(x.launched_in_backward)}
+    return info
+
+
+def arm_watchdog():
+    """A rank that hangs (a collective whose peer died, a persistent kernel that never returns) must not hold the
+    launcher for ever: after M2D_BENCH_TIMEOUT seconds (default 1800) the process dumps its Python stacks and exits
+    non-zero from a timer thread - no re-exec, no signal to anybody else."""
+    import faulthandler
+    import threading
+    limit = float(os.environ.get("M2D_BENCH_TIMEOUT", "1800"))
+
+    def fire():
+        sys.stderr.write("bench.py: rank %s exceeded %.0f s - exiting\n" % (os.environ.get("RANK", "0"), limit))
+        faulthandler.dump_traceback(file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(4)
+
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 PRESETS = {  # BASELINE.json configs[0..4] at their per-GPU shapes
@@ -286,6 +388,7 @@ def main():
     from music2dance_amd import dp, kernels, runner
     from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
 
+    watchdog = arm_watchdog()
     rank, world, local = dp.init_from_env(args.backend)
     if args.same_device:
         local = 0
@@ -366,6 +469,7 @@ def main():
     # the module graph stalls the launch thread for 60-80 ms (tools/spike_probe.py)
     runner.settle_garbage_collector()
     K = kernels.impl()
+    faults0 = int(getattr(type(K), "async_faults", 0))
     barrier()
     # one event per step on the main stream (asynchronous: no host sync) for the per-cycle figure
     step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -377,6 +481,10 @@ def main():
     engine.flush()
     barrier()
     elapsed = time.perf_counter() - t0
+    # persistent-kernel timeouts recovered from inside the timed window (engine._check_async clears the word as it
+    # recovers, so K.check_async_errors() below cannot see them): their optimizer steps were voided on the device -
+    # a rate over such a window is not a training rate. Reported on the line; the run then exits non-zero.
+    faults_timed = int(getattr(type(K), "async_faults", 0)) - faults0
     step_ms = [a.elapsed_time(b) for a, b in zip(step_events, step_events[1:])]
     if os.environ.get("M2D_STEP_TIMES"):  # dev aid: per-step GPU time to stderr
         print("step ms:", " ".join("%.2f" % v for v in step_ms), file=sys.stderr)
@@ -416,11 +524,12 @@ def main():
         prof = K.prof_end()
 
     K.check_async_errors()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, float(faults_timed)], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
+    elapsed, faults_timed = t[0].item(), int(t[1].item())
     last = {k: float(v) for k, v in engine.last.items()}
+    dinfo = dist_info(rank, world, local, device, engine)
 
     if rank == 0:
         seqs = args.steps * args.batch * world
@@ -434,6 +543,9 @@ def main():
             "config": {"workload": workload, "global_batch": args.batch * world, "seq_len": args.frames,
                        "parallelism": "dp%d" % world, "backend": args.backend if world > 1 else None},
             "losses_last_step": last,
+            # recovered persistent-kernel timeouts inside the timed window, max over ranks (0 = every step was taken)
+            "async_faults": faults_timed,
+            "distributed": dinfo,
         }
         if whole_cycles is not None:
             out["whole_cycles"] = whole_cycles
@@ -508,12 +620,26 @@ def main():
                     "step_tflops": round(ref_gf * 1e9 * whole_cycles["value"] / 1e12, 2)}
         default_cfg = args.phase == 3 and (args.enc_type, args.frames, args.ablated) == ("default", 120, False)
         if not args.no_cpu_baseline and world == 1 and default_cfg:
+            pay = None
             try:
                 out["cpu_baseline"] = cpu_baseline()
+                pay = out["cpu_baseline"].pop("_parity", None)
             except Exception as e:  # the baseline is informational; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "seq/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+            if pay is not None:
+                try:
+                    out["parity_at_bench_size"] = parity_at_bench_size(pay, device)
+                except Exception as e:
+                    out["parity_at_bench_size"] = {"failed": repr(e)}
         print(json.dumps(out), flush=True)
+    watchdog.cancel()
+    if faults_timed:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit("bench.py: %d persistent-kernel timeout(s) inside the timed window: optimizer steps were voided, the "
+                 "rate above is not a training rate" % faults_timed)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -229,6 +229,15 @@ class WganGpEngine:
             import warnings
             warnings.warn("a persistent recurrent launch timed out: its iteration(s) were skipped on the device, the "
                           "recurrences run as per-step launches from here on (%d so far)" % k.async_faults)
+        # Captured graphs have the persistent recurrent kernels baked in: after a recovery (by this engine or by another
+        # engine of the process - the switch to per-step launches is process-wide) every replay would run them again and
+        # could time out again, voiding iterations for ever. Graphs captured before the latest recovery are dropped
+        # (with their private scratch, which a killed launch may have left non-zero); the next train_step re-captures,
+        # now with per-step recurrent launches.
+        gen = int(getattr(k, "async_faults", 0))
+        if getattr(self, "_graphs", None) and getattr(self, "_graphs_gen", gen) != gen:
+            self._graphs = {}
+        self._graphs_gen = gen
 
     def train_step(self, *batch, inputs_ready=None):
         """One loop body of the reference: a critic iteration, plus a generator iteration every

@@ -126,7 +126,7 @@ def _bn_scratch(dev, C):
     re-allocated), zeroed once here and left zeroed by every call. None inside a capture that has not been given one
     (`private_scratch`): the call then takes the stateless three-launch form."""
     if C > _BN_MAX_C:
-        raise _lib.M2dError("reducing call over %d channels: the per-stream scratch holds %d" % (C, _BN_MAX_C))
+        return None  # wider than the fixed scratch (a GRU with hidden size > _BN_MAX_C / 3): the stateless three-launch form
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
     t = _BN_SCRATCH.get(key)
     if t is None:
@@ -255,7 +255,7 @@ class HipKernels:
                 self._packed.pop((id(w), "T"), None)
                 for key in [k for k in self._packed if isinstance(k, tuple) and k[0] == id(w)]:
                     self._packed.pop(key, None)
-            self._adam_kept = ()
+            self._adam_kept = set()
 
     def packed_weights(self, w):
         """(w_fwd (Cin, ks, Cout), w_bwd (Cout, ks, Cin)): the K-major images of a conv weight the forward / backward-data
@@ -597,7 +597,9 @@ class HipKernels:
         _lib.check(rc, "m2d_adam_multi")
         for key, ent in keep:
             self._packed[key] = ent
-        self._adam_kept = {k for k, _ in keep}
+        # (accumulated over the launches of one optimizer step - several step groups / 48-tensor batches - and consumed
+        # by the invalidate_packed() that follows the step)
+        self._adam_kept = set(getattr(self, "_adam_kept", ())) | {k for k, _ in keep}
 
     def transposed(self, w):
         """w.t().contiguous() of a 2-D weight (the GRU kernels read W^T), kept like the packed conv images: built

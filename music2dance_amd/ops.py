@@ -471,19 +471,25 @@ def _global_count(local_count, device):
     """Elements per channel over ALL ranks. Reduced once per distinct local count (a host read, i.e. a device sync: not
     something to do per layer and step) and cached - which is only sound when every rank sees the same sequence of
     local counts (a rank with a cached value skips the collective another rank would wait in for ever). So EQUAL shards
-    are required and checked: the first reduction of a count must return count x world size, else this raises on every
-    rank at once (use drop_last / equal per-rank batches with synchronised BatchNorm)."""
+    are required and checked: the first reduction of a count also reduces its minimum and maximum over the ranks
+    (as MAX of (-count, count), the same collective on every rank), and EVERY rank raises when they differ - a test on
+    the sum alone lets a rank whose count happens to equal the mean (10 / 12 / 14) pass, cache and walk into the next
+    collective alone (use drop_last / equal per-rank batches with synchronised BatchNorm)."""
     import torch.distributed as dist
     key = (float(local_count), id(_sync_bn["group"]))
     g = _sync_counts.get(key)
     if g is None:
         t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
+        mm = torch.tensor([-float(local_count), float(local_count)], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_sync_bn["group"])
+        dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=_sync_bn["group"])
         g = float(t.item())
+        lo, hi = -float(mm[0].item()), float(mm[1].item())
         world = dist.get_world_size(_sync_bn["group"])
-        if abs(g - float(local_count) * world) > 0.5:
+        if hi - lo > 0.5:
             raise RuntimeError("synchronised BatchNorm needs equal shards on every rank: this rank has %d elements per "
-                               "channel, all %d ranks together %d" % (int(local_count), world, int(g)))
+                               "channel, the %d ranks hold between %d and %d (%d together)"
+                               % (int(local_count), world, int(lo), int(hi), int(g)))
         _sync_counts[key] = g
     return g
 

@@ -25,6 +25,19 @@ class Adam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         k = kernels.impl()
+        skip = self.skip_flag
+        if isinstance(skip, int) and skip:
+            # the LIVE fault word: a recurrent launch on another stream (the generator forward runs one iteration ahead)
+            # may raise it while this step's launches execute, and workgroups that read it before / after would apply /
+            # void different tensors. The decision is taken ONCE per step instead: the word is fetched into a device
+            # float of this optimizer on the step's stream, and every launch of the step reads that float (data-parallel
+            # runs already read a value that was fetched once, into their last gradient bucket).
+            dev = next((p.device for g in self.param_groups for p in g["params"] if p.grad is not None), None)
+            if dev is not None and dev.type == "cuda":
+                if getattr(self, "_skip_buf", None) is None or self._skip_buf.device != dev:
+                    self._skip_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+                k.fault_fetch(self._skip_buf)
+                skip = self._skip_buf
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             lr = group["lr"]
@@ -47,5 +60,5 @@ class Adam(torch.optim.Adam):
             for step, rows in by_step.items():
                 ps, gs, ms, vs = zip(*rows)
                 k.adam_multi(list(ps), list(gs), list(ms), list(vs), lr, beta1, beta2, group["eps"], step,
-                             skip=self.skip_flag)
+                             skip=skip)
         return loss

@@ -857,3 +857,34 @@ def test_a_timed_out_recurrence_voids_the_queued_optimizer_steps_and_the_run_goe
         assert not all(torch.equal(a, b.detach()) for a, b in zip(before, list(critic.parameters())[:4]))
     finally:
         type(k).persistent_gru = True
+
+
+def test_a_recovery_drops_the_captured_graphs_and_they_are_recaptured_without_the_persistent_kernel():
+    """ADVICE (round 4): the fault recovery flips `persistent_gru`, which only the eager launches consult - graphs
+    captured earlier have the persistent recurrent kernel baked in and would replay (and time out) for ever. After a
+    recovery the engine drops them; the next train_step re-captures with per-step recurrent launches."""
+    import bench
+    from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
+    dev = torch.device("cuda:0")
+    k = K()
+    gen, critic = bench.build_models(dev, 120)
+    eng = Phase3Engine(gen, critic, dict(bench.P3_DEFAULT, n_critic_steps=2), data_parallel=False).enable_graphs()
+    real, audio, slices = synthetic_phase3_batch(4, 120, dev, seed=3)
+    try:
+        assert type(k).persistent_gru
+        for _ in range(2):
+            eng.train_step(real, audio, slices)
+        torch.cuda.synchronize()
+        assert len(eng._graphs) == 1
+        old = next(iter(eng._graphs.values()))
+        k.raise_async_fault()
+        with pytest.warns(UserWarning, match="timed out"):
+            eng.train_step(real, audio, slices)
+        assert not type(k).persistent_gru
+        assert len(eng._graphs) == 1 and next(iter(eng._graphs.values())) is not old, "the stale graph was replayed"
+        for _ in range(2):
+            out = eng.train_step(real, audio, slices)
+        eng.flush()
+        assert all(torch.isfinite(v).all() for v in out.values())
+    finally:
+        type(k).persistent_gru = True

@@ -500,6 +500,19 @@ int main(int argc, char** argv) {
       v.push_back({"dl 256x256x16 4x2 dma16 frag1 (8 waves)" + ms, launch_dl<256, 256, 4, 2, 16, 16, 1>, 256, 256, map, false});
       v.push_back({"dl 256x256x16 2x2 dma16 frag1 (4 waves)" + ms, launch_dl<256, 256, 2, 2, 16, 16, 1>, 256, 256, map, false});
     }
+  } else if (set == 3) {
+    // round 5: eight waves per workgroup on the SAME 128x128x16 tile (two waves per SIMD from one workgroup: 4 x 32 KB of
+    // LDS is what a CU holds - the allocation granule is 1280 B, so five 32 768-byte workgroups do not fit - i.e. four
+    // waves per SIMD today, eight with this form), against the engine's four-wave scheme; on shapes given as M N K
+    v.push_back({"dl 128x128x16 2x2 dma4 frag0 pinned (4 waves)", launch_dl<128, 128, 2, 2, 16, 4, 0, 2, true>, 128, 128, 0, false});
+    v.push_back({"dl 128x128x16 2x2 dma16 frag1 (4 waves)", launch_dl<128, 128, 2, 2, 16, 16, 1, 2>, 128, 128, 0, false});
+    v.push_back({"dl 128x128x16 2x4 dma4 frag0 (8 waves, 64x32 each)", launch_dl<128, 128, 2, 4, 16, 4, 0, 2>, 128, 128, 0, false});
+    v.push_back({"dl 128x128x16 2x4 dma4 frag0 pinned (8 waves)", launch_dl<128, 128, 2, 4, 16, 4, 0, 2, true>, 128, 128, 0, false});
+    v.push_back({"dl 128x128x16 4x2 dma4 frag0 (8 waves, 32x64 each)", launch_dl<128, 128, 4, 2, 16, 4, 0, 2>, 128, 128, 0, false});
+    v.push_back({"dl 128x128x16 2x4 dma16 frag0 (8 waves)", launch_dl<128, 128, 2, 4, 16, 16, 0, 2>, 128, 128, 0, false});
+    v.push_back({"dl 128x128x16 2x4 dma16 frag0 (8 waves) xcd", launch_dl<128, 128, 2, 4, 16, 16, 0, 2>, 128, 128, 1, false});
+    v.push_back({"dl 128x64x16 2x2 dma4 frag0 (4 waves, 24 KB)", launch_dl<128, 64, 2, 2, 16, 4, 0, 2>, 128, 64, 0, false});
+    v.push_back({"dl3 128x128x16 3 stages (4 waves)", launch_dl3<128, 128, 2, 2, 16, 3>, 128, 128, 0, false});
   } else if (set == 2) {
     v.push_back({"dl 128x128x16 dma4 frag0 minw2 + pinned", launch_dl<128, 128, 2, 2, 16, 4, 0, 2, true>, 128, 128, 0, false});
     v.push_back({"dl 128x128x16 dma16 frag1 minw2", launch_dl<128, 128, 2, 2, 16, 16, 1, 2>, 128, 128, 0, false});
