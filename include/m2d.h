@@ -116,6 +116,14 @@ int m2d_conv1d_bwd_data_res(const float* dy, const float* w, const float* w_pack
 int m2d_conv1d_bwd_weight_from(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
                                int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
                                int bias_from_sample, void* ws, size_t ws_bytes, void* stream);
+/* Round 5. m2d_conv1d_bwd_data over a batch whose two halves pass through the SAME activation masks: `out_mask` holds
+ * mask_batch samples (B / 2 <= mask_batch <= B); sample n >= mask_batch of dx is masked by mask sample n - mask_batch.
+ * The audio branch of the phase-3 critic (phase3/archis/default.py:312-319) is evaluated on the same audio for the
+ * interpolated, real and fake poses, so the penalty's first backward (losses.py:40-44) and the loss backward
+ * (phase3/train.py:215) run through identical ReLU masks: ONE launch per layer over 2B gradient rows. */
+int m2d_conv1d_bwd_data_shared_mask(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin,
+                                    int L, int Cout, int ks, int stride, int pad, const float* out_mask,
+                                    float out_mask_slope, int mask_batch, void* ws, size_t ws_bytes, void* stream);
 int m2d_gemm_ld(int mode, const float* a, int lda, const float* b, int ldb, const float* bias, float* c, int ldc,
                 int M, int N, int K, int act, float slope, const float* a_mask, float a_mask_slope,
                 const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream);

@@ -33,6 +33,8 @@ then need both their tangent and their activations, so the pose branch runs on a
 [tangent | interpolated | real | fake], gradient side [first backward | tanh'' chain | real | fake]; row r pairs with
 row r in the one weight-gradient launch per layer), the audio branch adds w to the cotangent of its forward half.
 """
+import os
+
 import torch
 
 from . import kernels, ops
@@ -77,6 +79,9 @@ class CriticStep:
         # the pose branch's launches are small (they leave most CUs idle between dependent kernels): they run on a
         # side stream underneath the audio branch's large convolutions, section by section
         self.overlap = self.audio is not None and getattr(type(critic), "overlap_branches", True)
+        # the penalty's first backward and the score backward of the audio branch as ONE 2B-row launch per layer
+        # (M2D_MERGE_AUDIO_BWD=0: two B-row chains, the round-4 schedule)
+        self.merge_audio_chains = os.environ.get("M2D_MERGE_AUDIO_BWD", "1") != "0"
         self._side = None
 
     # ------------------------------------------------------------------ helpers
@@ -274,11 +279,17 @@ class CriticStep:
         v_audio = pen_a = None
 
         def audio_chain(half):
-            """backward-data through the audio branch for rows `half` of the (2B, ...) gradient buffers"""
-            k.gemm(1, ca2[half], l6w2d, out_mask=y5, out=HD[4][half].view(B, -1))
+            """backward-data through the audio branch for rows `half` of the (2B, ...) gradient buffers; half = None:
+            BOTH halves in one launch per layer - they pass through the same activation masks (the forward's, rows B:
+            of Y), which the kernel reads once more for the second half (m2d_conv1d_bwd_data_shared_mask)"""
+            for hf in ((lo, hi) if half is None else (half,)):
+                k.gemm(1, ca2[hf], l6w2d, out_mask=y5, out=HD[4][hf].view(B, -1))
             for n in range(4, 0, -1):
                 w, _, s_, pd = _conv_params(layers[n])
-                k.conv1d_bwd_data(HD[n][half], w, Y[n - 1].shape[2], s_, pd, out_mask=Y[n - 1][B:], out=HD[n - 1][half])
+                if half is None:
+                    k.conv1d_bwd_data(HD[n], w, Y[n - 1].shape[2], s_, pd, out_mask=Y[n - 1][B:], out=HD[n - 1])
+                else:
+                    k.conv1d_bwd_data(HD[n][half], w, Y[n - 1].shape[2], s_, pd, out_mask=Y[n - 1][B:], out=HD[n - 1][half])
 
         if au is not None:
             lo, hi = slice(0, B), slice(B, 2 * B)
@@ -287,9 +298,12 @@ class CriticStep:
             torch.add(de_a[R - 2 * B:R - B], de_a[R - B:], out=ca2[hi])
             HD = [torch.empty_like(Y[n]) for n in range(5)]
             y5 = Y[4][B:].view(B, -1)
-            audio_chain(lo)
-            if not tanh:
-                audio_chain(hi)   # (tanh heads: after the tangent pass - the tanh'' cotangent joins this half)
+            if tanh or not self.merge_audio_chains:
+                audio_chain(lo)
+                if not tanh:
+                    audio_chain(hi)   # (tanh heads: after the tangent pass - the tanh'' cotangent joins this half)
+            else:
+                audio_chain(None)
             w, _, s_, pd = _conv_params(layers[0])
             v_audio = k.conv1d_bwd_data(HD[0][lo], w, audio.shape[2], s_, pd)
             pen_a, norms_a = k.gp_penalty_fwd(v_audio.view(B, -1), False)

@@ -447,10 +447,14 @@ int m2d_conv1d_fwd_windows(const float* track, int B, int S, int T, int hop, int
 static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin, int L,
                                 int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
                                 const float* out_mask, float out_mask_slope, void* ws, size_t ws_bytes, void* stream,
-                                const float* residual) {
+                                const float* residual, int mask_batch = 0) {
   const int Lout = conv_out_len(L, ks, stride, pad);
   if (B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0)
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_data: bad shape");
+  // shared mask: out_mask holds mask_batch samples, sample n of dx reads mask sample n - mask_batch once n >= mask_batch
+  if (mask_batch < 0 || (mask_batch > 0 && (!out_mask || 2 * mask_batch < B)))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_data: a shared mask needs an out_mask of >= B / 2 samples (mask_batch=%d, B=%d)", mask_batch, B);
+  const unsigned mask_wrap = (mask_batch > 0 && mask_batch < B) ? (unsigned)((long long)mask_batch * Cin * L) : 0u;
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout) ||
       !fits_i32((long long)Cout * Cin * ks))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_bwd_data: tensor exceeds 2^31 elements");
@@ -473,6 +477,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     m2d_operand_plain(p.B, w, p.N, 1, Cin * ks, (long long)Cout * Cin * ks);
     m2d_outmap_plain(p.O, dx, Cin * ks, 1);
     p.O.mask = out_mask;
+    p.O.mask_wrap = mask_wrap;
     p.O.mask_slope = out_mask_slope;
     p.O.residual = residual;
     p.O.mask_last = 1;
@@ -542,6 +547,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     p.O.c_pos_off = s * qlo - pad;
     p.O.c_lim = L;
     p.O.mask = out_mask;
+    p.O.mask_wrap = mask_wrap;
     p.O.mask_slope = out_mask_slope;
     p.O.residual = residual;
     p.O.mask_last = 1;
@@ -621,6 +627,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
   p.O.c_pos_mul = stride;
   p.O.c_lim = L;
   p.O.mask = out_mask;
+  p.O.mask_wrap = mask_wrap;
   p.O.mask_slope = out_mask_slope;
   p.O.residual = residual;
   p.O.mask_last = 1;
@@ -665,6 +672,20 @@ int m2d_conv1d_bwd_data_res(const float* dy, const float* w, const float* w_pack
                             size_t ws_bytes, void* stream) {
   return conv1d_bwd_data_impl(dy, w, w_packed, dx, B, Cin, L, Cout, ks, stride, pad, dy_mask, dy_mask_slope, out_mask,
                               out_mask_slope, ws, ws_bytes, stream, residual);
+}
+
+// m2d_conv1d_bwd_data over a batch whose two halves share ONE set of activation masks: out_mask holds `mask_batch`
+// samples (B / 2 <= mask_batch <= B) and sample n >= mask_batch of dx reads mask sample n - mask_batch. The audio branch
+// of the phase-3 critic (phase3/archis/default.py:312-319) sees the same audio in the penalty pass and in the real /
+// fake passes, so the penalty's first backward (losses.py:40-44) and the loss backward (phase3/train.py:215) travel
+// through identical ReLU masks: one launch over 2B gradient rows per layer instead of two over B.
+int m2d_conv1d_bwd_data_shared_mask(const float* dy, const float* w, const float* w_packed, float* dx, int B, int Cin,
+                                    int L, int Cout, int ks, int stride, int pad, const float* out_mask,
+                                    float out_mask_slope, int mask_batch, void* ws, size_t ws_bytes, void* stream) {
+  if (m2d_thin_applicable(Cin, Cout, ks, stride))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_data_shared_mask: not for the thin (Cin = 1) layer");
+  return conv1d_bwd_data_impl(dy, w, w_packed, dx, B, Cin, L, Cout, ks, stride, pad, nullptr, 0.f, out_mask,
+                              out_mask_slope, ws, ws_bytes, stream, nullptr, mask_batch);
 }
 
 // Replaces the weight-gradient half of convolution_backward. K = (sample, position) is the long

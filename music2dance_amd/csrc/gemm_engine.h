@@ -83,6 +83,12 @@ struct M2dOutMap {
   const float* residual;
   float* sum_out;
   int mask_last;
+  // > 0: `mask` holds only the first mask_wrap elements of the output's index space and repeats behind them - element
+  // `addr` reads mask[addr - mask_wrap] once addr >= mask_wrap (ONE wrap: the output spans at most 2 x mask_wrap).
+  // A (2B, C, L) gradient whose two halves pass through the SAME activation masks (the audio branch of the critic:
+  // the penalty's first backward and the score backward, phase3/archis/default.py:312-319 under losses.py:40-44) is
+  // then one launch over 2B rows instead of two over B.
+  unsigned mask_wrap;
   // set by the launcher when the tile can leave as 16-byte rows (m2d_tile_epilogue, WIDE): unit column stride, every
   // pitch / offset / column count a multiple of 4, 16-byte aligned pointers, no window / redirect column
   int wide;

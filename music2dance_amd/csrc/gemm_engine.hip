@@ -3,6 +3,20 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Wave layout of a BM x BN block tile: NW waves as WM x WN, each owning TM x TN accumulator tiles of 32 x 32.
+// NW = 4 (256 threads) everywhere except the LDS-direct 128 x 128 kernel, which also runs with NW = 8 (512 threads, a
+// wave owns 64 x 32): a CU holds four 32 KB workgroups (the LDS allocation granule is 1280 B: five do not fit), so
+// four-wave workgroups give a SIMD 4 waves to pick from, eight-wave ones 8 at 57-64 VGPRs - what a launch with one or
+// two workgroups per CU (the pose critic's 5 GFLOP problems) needs to hide its own operand latency.
+template <int BM, int BN, int NW>
+struct M2dTiling {
+  static constexpr int WM = BM >= 64 ? 2 : 1;
+  static constexpr int WN = NW / WM;
+  static constexpr int TM = BM / (32 * WM);
+  static constexpr int TN = BN / (32 * WN);
+  static constexpr int NTH = 64 * NW;
+};
+
 // n / d and n % d for 0 <= n < 2^24 (exact in fp32; the launcher rejects larger extents). Branch-free.
 __device__ __forceinline__ void m2d_divmod(int n, int d, float inv, int& q, int& r) {
   q = (int)((float)n * inv);
@@ -83,9 +97,9 @@ __device__ __forceinline__ int m2d_hi_offset(const M2dOperand& op, int hi) {
 //                 vector offset only, so that part is always a real element's offset.
 // UNIFORM chunks (no lo tail, window independent of lo or known to pass): validity is one test
 // per thread per chunk. General chunks test every element.
-template <bool KF, int BR, bool MASKED>
+template <bool KF, int BR, bool MASKED, int NTH = 256>
 struct TileMap {
-  static constexpr int NE = BR * M2D_BK / 256;
+  static constexpr int NE = BR * M2D_BK / NTH;
   static constexpr int NR = KF ? NE : 1;
   static constexpr int NM = MASKED ? NE : 1;
   unsigned eoff[NR];
@@ -106,7 +120,7 @@ struct TileMap {
       posr = 0;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        const int g = row0 + tid / M2D_BK + i * (256 / M2D_BK);
+        const int g = row0 + tid / M2D_BK + i * (NTH / M2D_BK);
         const bool rv = g < op.nrows;
         int hi, lo;
         m2d_divmod(rv ? g : 0, op.rdiv, op.rdiv_inv, hi, lo);
@@ -133,6 +147,7 @@ struct TileMap {
   static constexpr int DL_KSTEP = BR >= 64 ? 1 : 64 / BR;
   __device__ __forceinline__ void prep_dl(const M2dOperand& op, int row0, int tid) {
     static_assert(!KF && !MASKED && (BR == 32 || BR >= 64), "LDS-direct staging: row-fast, unmasked");
+    static_assert(BR >= 64 || NTH == 256, "32-row LDS-direct staging: four waves");
     if constexpr (BR >= 64) {
       prep(op, row0, tid);
     } else {
@@ -236,7 +251,7 @@ struct TileMap {
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int kl = KF ? (tid % M2D_BK) : ((tid / BR) * NE + i);
-      const int rl = KF ? (tid / M2D_BK + i * (256 / M2D_BK)) : (tid % BR);
+      const int rl = KF ? (tid / M2D_BK + i * (NTH / M2D_BK)) : (tid % BR);
       float x = v[i];
       if constexpr (MASKED) x *= (mv[i] > 0.f ? 1.f : op.mask_slope);
       if constexpr (!KF) x = force_one ? one_val : x;
@@ -285,18 +300,24 @@ struct ChunkCursor {
   }
 };
 
+// byte offset of an element's mask value (M2dOutMap.mask_wrap; wrapb = 0xffffffff: the mask is as large as the output)
+__device__ __forceinline__ unsigned m2d_mask_off(unsigned voff, unsigned wrapb) {
+  return (voff != M2D_OOB && voff >= wrapb) ? voff - wrapb : voff;
+}
+
 // -> the value stored at out[addr]; with O.sum_out the second output is written here too
 __device__ __forceinline__ float m2d_epilogue(const M2dOutMap& o, float v, int row, int col, int addr) {
+  const int maddr = (o.mask_wrap && addr >= (int)o.mask_wrap) ? addr - (int)o.mask_wrap : addr;
   if (o.bias_mode == 1) v += o.bias[row];
   else if (o.bias_mode == 2) v += o.bias[col];
   if (o.act == 1) v = v > 0.f ? v : 0.f;
   else if (o.act == 2) v = v > 0.f ? v : v * o.slope;
   if (o.mask_last) {
     if (o.residual) v += o.residual[addr];
-    if (o.mask) v *= (o.mask[addr] > 0.f ? 1.f : o.mask_slope);
+    if (o.mask) v *= (o.mask[maddr] > 0.f ? 1.f : o.mask_slope);
     return v;
   }
-  if (o.mask) v *= (o.mask[addr] > 0.f ? 1.f : o.mask_slope);
+  if (o.mask) v *= (o.mask[maddr] > 0.f ? 1.f : o.mask_slope);
   if (o.sum_out) {
     o.sum_out[addr] = v + o.residual[addr];
     return v;
@@ -352,14 +373,12 @@ __device__ __forceinline__ void m2d_chunk_mma(const TileMap<AKF, BM, MASKED>& ta
 // epilogue has no bias lookup at all (bias[row] was a global load on every row's dependency chain there). Not under the
 // two-launch split-K (its reduction kernel adds the bias); with the in-kernel fix-up only split 0 starts from the bias
 // (the last arriver sums every split's image, split 0's included, from zero).
-template <int BM, int BN>
+template <int BM, int BN, int NW = 4>
 __device__ __forceinline__ void m2d_acc_init(const M2dGemmParams& p, const M2dOutMap& O, int N, int split, int m0, int n0, int wm,
                                              int wn, int l31, int lh,
-                                             f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
-  constexpr int WM = BM >= 64 ? 2 : 1;
-  constexpr int WN = 4 / WM;
-  constexpr int TM = BM / (32 * WM);
-  constexpr int TN = BN / (32 * WN);
+                                             f32x16 (&acc)[M2dTiling<BM, BN, NW>::TM][M2dTiling<BM, BN, NW>::TN]) {
+  constexpr int TM = M2dTiling<BM, BN, NW>::TM;
+  constexpr int TN = M2dTiling<BM, BN, NW>::TN;
   const bool with_bias = O.bias_mode != 0 && (p.splits <= 1 || (p.tickets && split == 0));
   if (!with_bias) {
 #pragma unroll
@@ -430,14 +449,13 @@ __device__ __forceinline__ float4 m2d_bload4(__amdgpu_buffer_rsrc_t r, unsigned 
 // All global accesses of the pass are raw buffer operations with a 32-bit byte offset (the launcher checks that the
 // output map stays below 2 GiB): one address register per access, and an element that must not be touched simply gets
 // the offset M2D_OOB - the range check drops the store / returns 0.0 - instead of a branch around the instruction.
-template <int BM, int BN, bool WIDE>
+template <int BM, int BN, bool WIDE, int NW = 4>
 __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const M2dOutMap& O, int N, int split, int m0,
                                                   int n0, int wm, int wn, int lane, float* wl,
-                                                  f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
-  constexpr int WM = BM >= 64 ? 2 : 1;
-  constexpr int WN = 4 / WM;
-  constexpr int TM = BM / (32 * WM);
-  constexpr int TN = BN / (32 * WN);
+                                                  f32x16 (&acc)[M2dTiling<BM, BN, NW>::TM][M2dTiling<BM, BN, NW>::TN]) {
+  constexpr int WN = M2dTiling<BM, BN, NW>::WN;
+  constexpr int TM = M2dTiling<BM, BN, NW>::TM;
+  constexpr int TN = M2dTiling<BM, BN, NW>::TN;
   const int l31 = lane & 31, lh = lane >> 5;
   // two-launch split-K: the raw partial tile goes to this split's slab [M][N] - the same pass under a plain map
   const bool slab = p.splits > 1 && !p.tickets;
@@ -446,6 +464,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
   const bool two_out = O.sum_out != nullptr && !slab;
   const int act = slab ? 0 : O.act;
   const float ms = O.mask_slope;
+  const unsigned wrapb = O.mask_wrap ? O.mask_wrap * 4u : 0xffffffffu;
   const int m_stride = slab ? p.N : O.m_stride;
   const int m_div = slab ? 0 : O.m_div;
   const int c_lim = slab ? 0 : O.c_lim;
@@ -455,7 +474,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
 #define M2D_RS(ptr) m2d_rsrc((ptr), 0x7ffffffcu)
   // BM = 128: both tiles of a 32-row band are dumped together (2 x 4 KB per wave = the whole 32 KB of stage buffers)
   // (only the 16-byte pass needs the second tile's registers; the one-element pass takes a tile at a time)
-  constexpr int NT = (BM == 128 && WIDE) ? TN : 1;
+  constexpr int NT = (BM == 128 && WIDE) ? TN : 1;   // (TN = 1 with eight waves: a tile at a time)
   // WIDE: lane -> row rl0 + 8 it, columns c4 .. c4 + 3 (it = 0..3); else: lane -> row 2 it + lh, column l31 (it = 0..15)
   const int rl0 = lane >> 3, c4 = (lane & 7) * 4;
   constexpr int PER_TILE = WIDE ? 4 : 16;
@@ -523,7 +542,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
                 float4 mraw[NI];
 #pragma unroll
                 for (int it = 0; it < NI; ++it)
-                  mraw[it] = m2d_bload4(rsm, (RS * it < nrow && v0 != M2D_OOB) ? v0 + (unsigned)it * step : M2D_OOB);
+                  mraw[it] = m2d_bload4(rsm, m2d_mask_off((RS * it < nrow && v0 != M2D_OOB) ? v0 + (unsigned)it * step : M2D_OOB, wrapb));
 #pragma unroll
                 for (int it = 0; it < NI; ++it)
                   keep |= ((mraw[it].x > 0.f ? 1u : 0u) | (mraw[it].y > 0.f ? 2u : 0u) | (mraw[it].z > 0.f ? 4u : 0u) | (mraw[it].w > 0.f ? 8u : 0u)) << (4 * it);
@@ -531,7 +550,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
                 float mraw[NI];
 #pragma unroll
                 for (int it = 0; it < NI; ++it)
-                  mraw[it] = m2d_bload(rsm, (RS * it < nrow && v0 != M2D_OOB) ? v0 + (unsigned)it * step : M2D_OOB, 0);
+                  mraw[it] = m2d_bload(rsm, m2d_mask_off((RS * it < nrow && v0 != M2D_OOB) ? v0 + (unsigned)it * step : M2D_OOB, wrapb), 0);
 #pragma unroll
                 for (int it = 0; it < NI; ++it) keep |= (mraw[it] > 0.f ? 1u : 0u) << it;
               }
@@ -608,7 +627,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
               int jj, rl, row;
               unsigned voff;
               locate(q0 + q, jj, rl, row, voff);
-              mraw[q] = m2d_bload4(M2D_RS(O.mask), voff);
+              mraw[q] = m2d_bload4(M2D_RS(O.mask), m2d_mask_off(voff, wrapb));
             }
 #pragma unroll
             for (int q = 0; q < GROUP; ++q)
@@ -620,7 +639,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
               int jj, rl, row;
               unsigned voff;
               locate(q0 + q, jj, rl, row, voff);
-              mraw[q] = m2d_bload(M2D_RS(O.mask), voff, 0);
+              mraw[q] = m2d_bload(M2D_RS(O.mask), m2d_mask_off(voff, wrapb), 0);
             }
 #pragma unroll
             for (int q = 0; q < GROUP; ++q) keep |= (mraw[q] > 0.f ? 1u : 0u) << q;
@@ -711,14 +730,13 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
 // accumulators then hold the whole K and the ordinary epilogue runs. Everybody else returns false and leaves.
 // (The separate m2d_splitk_reduce_kernel costs a launch gap plus 8-35 us and reads every slab from a cold grid; here
 // the partials are read by ONE workgroup per tile while they are still in the cache hierarchy.) Launcher: splits <= 16 (more: the separate reduction kernel, one workgroup reading that many images is the slower way).
-template <int BM, int BN>
+template <int BM, int BN, int NW = 4>
 __device__ __forceinline__ bool m2d_splitk_fixup(const M2dGemmParams& p, int split, int tid, volatile int* flag,
-                                                 f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
-  constexpr int WM = BM >= 64 ? 2 : 1;
-  constexpr int WN = 4 / WM;
-  constexpr int TM = BM / (32 * WM);
-  constexpr int TN = BN / (32 * WN);
+                                                 f32x16 (&acc)[M2dTiling<BM, BN, NW>::TM][M2dTiling<BM, BN, NW>::TN]) {
+  constexpr int TM = M2dTiling<BM, BN, NW>::TM;
+  constexpr int TN = M2dTiling<BM, BN, NW>::TN;
   constexpr unsigned TILE_BYTES = BM * BN * 4;
+  constexpr int PLANE = M2dTiling<BM, BN, NW>::NTH * 16;   // bytes of one float4 per thread: the image's plane pitch
   // (`flag`: a word of the stage buffers, free after the last chunk - a __shared__ of its own would be the 4 bytes that
   // push the LDS-direct kernels from five to four workgroups per CU)
   const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
@@ -734,7 +752,7 @@ __device__ __forceinline__ bool m2d_splitk_fixup(const M2dGemmParams& p, int spl
         m2d_vf32x4 v;
         v[0] = acc[i][j][4 * r4]; v[1] = acc[i][j][4 * r4 + 1]; v[2] = acc[i][j][4 * r4 + 2]; v[3] = acc[i][j][4 * r4 + 3];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(m2d_u32x4, v), rs,
-                                               (int)(mine + (unsigned)(((i * TN + j) * 4 + r4) * 4096)), 0, 16 /* sc1 */);
+                                               (int)(mine + (unsigned)(((i * TN + j) * 4 + r4) * PLANE)), 0, 16 /* sc1 */);
       }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -759,7 +777,7 @@ __device__ __forceinline__ bool m2d_splitk_fixup(const M2dGemmParams& p, int spl
         for (int r4 = 0; r4 < 4; ++r4)
           // (whole-vector bit cast: an element-wise cast of this builtin's result is narrowed to one dword load)
           f[r4] = __builtin_bit_cast(m2d_vf32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                      rs, (int)(from + (unsigned)(((i * TN + j) * 4 + r4) * 4096)), 0, 16 /* sc1 */));
+                                                      rs, (int)(from + (unsigned)(((i * TN + j) * 4 + r4) * PLANE)), 0, 16 /* sc1 */));
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           acc[i][j][4 * r4] += f[r4][0]; acc[i][j][4 * r4 + 1] += f[r4][1];
@@ -924,13 +942,11 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_kernel(const M2dGemmParams p)
 // the chunk's loads write the LDS image themselves (`buffer_load ... lds`), so the tile needs neither the 16 staging
 // registers nor the ds_write pass, and with rows lane-consecutive on both sides the image needs no padding: 32 KB of
 // LDS and <= 102 VGPRs per workgroup = FIVE workgroups per CU instead of four.
-template <int BM, int BN>
+template <int BM, int BN, int NW = 4>
 __device__ __forceinline__ void m2d_chunk_mma_dl(const float* stage, int wm, int wn, int l31, int lh,
-                                                 f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
-  constexpr int WM = BM >= 64 ? 2 : 1;
-  constexpr int WN = 4 / WM;
-  constexpr int TM = BM / (32 * WM);
-  constexpr int TN = BN / (32 * WN);
+                                                 f32x16 (&acc)[M2dTiling<BM, BN, NW>::TM][M2dTiling<BM, BN, NW>::TN]) {
+  constexpr int TM = M2dTiling<BM, BN, NW>::TM;
+  constexpr int TN = M2dTiling<BM, BN, NW>::TN;
   const float* as = stage + wm * (TM * 32) + l31;
   const float* bs = stage + M2D_BK * BM + wn * (TN * 32) + l31;
   float fa[M2D_BK / 2][TM], fb[M2D_BK / 2][TN];
@@ -961,14 +977,12 @@ __device__ __forceinline__ void m2d_chunk_mma_dl(const float* stage, int wm, int
 // four dword stores a stride of 16 bytes apart. Addresses are 4-byte aligned only (the row offset is s q - pad).
 typedef float m2d_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-template <int BM, int BN>
+template <int BM, int BN, int NW = 4>
 __device__ __forceinline__ void m2d_tile_epilogue_quad(const M2dGemmParams& p, const M2dOutMap& O, int N, int m0, int n0,
                                                        int wm, int wn, int l31, int lh,
-                                                       f32x16 (&acc)[BM / (32 * (BM >= 64 ? 2 : 1))][BN / (32 * (4 / (BM >= 64 ? 2 : 1)))]) {
-  constexpr int WM = BM >= 64 ? 2 : 1;
-  constexpr int WN = 4 / WM;
-  constexpr int TM = BM / (32 * WM);
-  constexpr int TN = BN / (32 * WN);
+                                                       f32x16 (&acc)[M2dTiling<BM, BN, NW>::TM][M2dTiling<BM, BN, NW>::TN]) {
+  constexpr int TM = M2dTiling<BM, BN, NW>::TM;
+  constexpr int TN = M2dTiling<BM, BN, NW>::TN;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * (TN * 32) + j * 32 + l31;
@@ -985,6 +999,8 @@ __device__ __forceinline__ void m2d_tile_epilogue_quad(const M2dGemmParams& p, c
         const int row = m0 + wm * (TM * 32) + i * 32 + 8 * g + 4 * lh;
         if (row >= p.M) continue;
         const int addr = (row >> 2) * O.m_stride + caddr;
+        // (signed: a quad that starts left of the row - addr < 0 for the first positions of sample 0 - must not wrap)
+        const int maddr = (O.mask_wrap && addr >= (int)O.mask_wrap) ? addr - (int)O.mask_wrap : addr;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1002,13 +1018,13 @@ __device__ __forceinline__ void m2d_tile_epilogue_quad(const M2dGemmParams& p, c
               for (int e = 0; e < 4; ++e) v[e] += rr[e];
             }
             if (O.mask) {
-              const m2d_f32x4u mm = *reinterpret_cast<const m2d_f32x4u*>(O.mask + addr);
+              const m2d_f32x4u mm = *reinterpret_cast<const m2d_f32x4u*>(O.mask + maddr);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] *= (mm[e] > 0.f ? 1.f : O.mask_slope);
             }
           } else {
             if (O.mask) {
-              const m2d_f32x4u mm = *reinterpret_cast<const m2d_f32x4u*>(O.mask + addr);
+              const m2d_f32x4u mm = *reinterpret_cast<const m2d_f32x4u*>(O.mask + maddr);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] *= (mm[e] > 0.f ? 1.f : O.mask_slope);
             }
@@ -1027,11 +1043,13 @@ __device__ __forceinline__ void m2d_tile_epilogue_quad(const M2dGemmParams& p, c
           for (int e = 0; e < 4; ++e) {
             if ((unsigned)(pos + e) >= (unsigned)O.c_lim) continue;
             float x = v[e];
+            // (element by element: a quad that hangs over the left end of a row starts at addr < its sample's origin)
+            const int me = (O.mask_wrap && addr + e >= (int)O.mask_wrap) ? addr + e - (int)O.mask_wrap : addr + e;
             if (O.mask_last) {
               if (O.residual) x += O.residual[addr + e];
-              if (O.mask) x *= (O.mask[addr + e] > 0.f ? 1.f : O.mask_slope);
+              if (O.mask) x *= (O.mask[me] > 0.f ? 1.f : O.mask_slope);
             } else {
-              if (O.mask) x *= (O.mask[addr + e] > 0.f ? 1.f : O.mask_slope);
+              if (O.mask) x *= (O.mask[me] > 0.f ? 1.f : O.mask_slope);
               if (O.residual) x += O.residual[addr + e];
             }
             O.out[addr + e] = x;
@@ -1043,12 +1061,16 @@ __device__ __forceinline__ void m2d_tile_epilogue_quad(const M2dGemmParams& p, c
 }
 
 // EPI: 0 dword epilogue, 1 wide (16-byte rows through LDS), 2 quad (sub-pixel rows)
-template <int BM, int BN, int EPI>
-__global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams p) {
-  constexpr int WM = BM >= 64 ? 2 : 1;
-  constexpr int WN = 4 / WM;
-  constexpr int TM = BM / (32 * WM);
-  constexpr int TN = BN / (32 * WN);
+// (eight waves: 8 waves per SIMD asked for - <= 64 VGPRs AND <= 96 SGPRs; at the 106 SGPRs the four-wave kernels use a
+// SIMD's 800 scalar registers hold 7 waves, i.e. only THREE eight-wave workgroups per CU: measured as a second dispatch
+// round, 548 -> 588 us on the 960-tile encoder conv)
+template <int BM, int BN, int EPI, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 8 : 2) m2d_gemm_dl_kernel(const M2dGemmParams p) {
+  constexpr int WM = M2dTiling<BM, BN, NW>::WM;
+  constexpr int TM = M2dTiling<BM, BN, NW>::TM;
+  constexpr int TN = M2dTiling<BM, BN, NW>::TN;
+  constexpr int NTH = M2dTiling<BM, BN, NW>::NTH;
+  static_assert(NW == 4 || (NW == 8 && BM == 128 && BN == 128), "eight waves: the 128 x 128 tile");
   constexpr int STAGE = M2D_BK * (BM + BN);
   __shared__ float smem[2 * STAGE];
   const int tid = threadIdx.x;
@@ -1093,8 +1115,8 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   }
   const int m0 = by * BM;
   const int n0 = bx * BN;
-  TileMap<false, BM, false> ta;
-  TileMap<false, BN, false> tb;
+  TileMap<false, BM, false, NTH> ta;
+  TileMap<false, BN, false, NTH> tb;
   ta.prep_dl(A, m0, tid);
   tb.prep_dl(B, n0, tid);
   const __amdgpu_buffer_rsrc_t ra = m2d_rsrc(A.base, A.nbytes);
@@ -1109,7 +1131,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   } else {
-    m2d_acc_init<BM, BN>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
+    m2d_acc_init<BM, BN, NW>(p, O, N, split, m0, n0, wm, wn, l31, lh, acc);
   }
 
   const int cph = (p.kdiv + M2D_BK - 1) / M2D_BK;
@@ -1151,7 +1173,7 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
         tb.template load_lds<false, BN>(B, rb, cc.hi, cc.lo0, cc.extent(), nxt + M2D_BK * BM, tid);
       }
 #endif
-      m2d_chunk_mma_dl<BM, BN>(smem + cur * STAGE, wm, wn, l31, lh, acc);
+      m2d_chunk_mma_dl<BM, BN, NW>(smem + cur * STAGE, wm, wn, l31, lh, acc);
 #ifdef M2D_X_SIMPLE_CURSOR  // experiment: plain GEMM cursor (nhi = 1)
       cc.lo0 += M2D_BK;
 #else
@@ -1164,9 +1186,9 @@ __global__ void __launch_bounds__(256, 2) m2d_gemm_dl_kernel(const M2dGemmParams
   // (two instantiations, not a branch: with both epilogues in one kernel every accumulator stays live across the
   // choice and the kernel needs 30 more registers, i.e. one resident wave per SIMD fewer)
   M2D_STAMP_AT(2);
-  if (p.tickets && !m2d_splitk_fixup<BM, BN>(p, split, tid, reinterpret_cast<volatile int*>(smem), acc)) return;
-  if constexpr (EPI == 2) m2d_tile_epilogue_quad<BM, BN>(p, O, N, m0, n0, wm, wn, l31, lh, acc);
-  else m2d_tile_epilogue<BM, BN, EPI == 1>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * (BM == 128 ? 2048 : 1024), acc);
+  if (p.tickets && !m2d_splitk_fixup<BM, BN, NW>(p, split, tid, reinterpret_cast<volatile int*>(smem), acc)) return;
+  if constexpr (EPI == 2) m2d_tile_epilogue_quad<BM, BN, NW>(p, O, N, m0, n0, wm, wn, l31, lh, acc);
+  else m2d_tile_epilogue<BM, BN, EPI == 1, NW>(p, O, N, split, m0, n0, wm, wn, lane, smem + wave * ((BM == 128 && NW == 4) ? 2048 : 1024), acc);
 #ifdef M2D_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1684,10 +1706,25 @@ static inline bool dl_eligible(const M2dGemmParams& p, bool akf, bool bkf) {
          p.B.rdiv2 <= 0 && p.A.kdiv2 <= 0 && p.B.kdiv2 <= 0;
 }
 
+// M2D_DL8=0: 128-row LDS-direct launches keep four waves per workgroup (A/B lever)
+static bool dl8_enabled() {
+  static const bool on = [] { const char* e = getenv("M2D_DL8"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <int BM>
 static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hipStream_t stream) {
   {
     if (dl_enabled() && dl_eligible(p, akf, bkf)) {
+      if constexpr (BM == 128) {
+        // eight waves per workgroup on the same tile (M2dTiling); the one-element epilogue does not fit the 64 VGPRs of
+        // eight waves per SIMD without scratch: those launches (strided backward-data) keep four waves
+        if (dl8_enabled() && (p.O.wide || (p.O.quad && p.splits <= 1))) {
+          if (p.O.wide) hipLaunchKernelGGL((m2d_gemm_dl_kernel<128, 128, 1, 8>), grid, dim3(512), 0, stream, p);
+          else hipLaunchKernelGGL((m2d_gemm_dl_kernel<128, 128, 2, 8>), grid, dim3(512), 0, stream, p);
+          return 0;
+        }
+      }
       if (p.O.wide) hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 1>), grid, dim3(256), 0, stream, p);
       else if (p.O.quad && p.splits <= 1) hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 2>), grid, dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((m2d_gemm_dl_kernel<BM, 128, 0>), grid, dim3(256), 0, stream, p);
@@ -1798,7 +1835,7 @@ static void decide_wide(M2dGemmParams& p, int splits, const void* ws) {
     w = w && al16(ws);
   } else {
     w = w && o.m_div <= 0 && o.c_lo_stride == 1 && o.c_lim <= 0 && (o.cdiv % 4) == 0 && (o.c_hi_stride % 4) == 0 &&
-        (o.m_stride % 4) == 0 && (o.c_off % 4) == 0 && al16(o.out) && al16(o.mask) && al16(o.residual) &&
+        (o.m_stride % 4) == 0 && (o.c_off % 4) == 0 && (o.mask_wrap % 4) == 0 && al16(o.out) && al16(o.mask) && al16(o.residual) &&
         al16(o.sum_out) && (o.bias_mode != 2 || al16(o.bias));
   }
   p.O.wide = w ? 1 : 0;

@@ -373,13 +373,26 @@ class HipKernels:
 
     def conv1d_bwd_data(self, dy, w, L, stride, pad, dy_mask=None, dy_mask_slope=0.0, out_mask=None,
                         out_mask_slope=0.0, residual=None, out=None):
-        """dx = out_mask * (conv^T(dy * dy_mask, w) + residual); out: write dx there."""
+        """dx = out_mask * (conv^T(dy * dy_mask, w) + residual); out: write dx there.
+        out_mask may hold only the first B / 2 .. B samples: the samples behind them then read the mask from its start
+        again (include/m2d.h: m2d_conv1d_bwd_data_shared_mask; no dy_mask / residual in that form)."""
         dev = _chk(dy, w, dy_mask, out_mask, residual, out)
         B, Cout, Lout = dy.shape
         Cout2, Cin, ks = w.shape
         assert Cout == Cout2 and Lout == conv_out_len(L, ks, stride, pad)
         dx = torch.empty((B, Cin, L), dtype=torch.float32, device=dev) if out is None else out
         assert tuple(dx.shape) == (B, Cin, L)
+        if out_mask is not None and out_mask.shape[0] != B:
+            mb = out_mask.shape[0]
+            assert tuple(out_mask.shape[1:]) == (Cin, L) and 2 * mb >= B and dy_mask is None and residual is None
+            wp = self.packed_weights(w)[1]
+            ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 1, B, Cin, L, Cout, ks, stride, pad), dev)
+            with _on(dev):
+                rc = _lib.lib().m2d_conv1d_bwd_data_shared_mask(_ptr(dy), _ptr(w), _ptr(wp), _ptr(dx), B, Cin, L, Cout, ks,
+                                                                stride, pad, _ptr(out_mask), out_mask_slope, mb, _ptr(ws),
+                                                                0 if ws is None else ws.numel() * 4, _stream(dev))
+            _lib.check(rc, "m2d_conv1d_bwd_data_shared_mask")
+            return dx
         h = _lib.lib()
         full_length = Lout == 1 and pad == 0 and L == ks
         if (out_mask is not None or residual is not None) and self._thin(Cin, ks, stride):

@@ -74,6 +74,8 @@ class FakeKernels:
         if residual is not None:  # residual BEFORE the mask
             dx = dx + residual
         if out_mask is not None:
+            if out_mask.shape[0] != dx.shape[0]:  # shared mask: the samples behind the mask's read it from its start again
+                out_mask = torch.cat([out_mask, out_mask[:dx.shape[0] - out_mask.shape[0]]], 0)
             dx = dx * _mf(out_mask, out_mask_slope)
         return self._into(out, dx)
 

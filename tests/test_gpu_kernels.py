@@ -888,3 +888,29 @@ def test_a_recovery_drops_the_captured_graphs_and_they_are_recaptured_without_th
         assert all(torch.isfinite(v).all() for v in out.values())
     finally:
         type(k).persistent_gru = True
+
+
+@pytest.mark.parametrize("cin,cout,ks,s,p,L", [(32, 64, 25, 4, 11, 384), (64, 128, 25, 4, 11, 256), (256, 512, 25, 4, 11, 300),
+                                                 (128, 128, 7, 1, 3, 120), (69, 128, 25, 1, 12, 120)])
+@pytest.mark.parametrize("B,mb", [(6, 3), (5, 3), (128, 64)])
+def test_backward_data_with_a_shared_mask_equals_the_repeated_mask(cin, cout, ks, s, p, L, B, mb):
+    """m2d_conv1d_bwd_data_shared_mask (round 5): the mask holds the first `mb` samples and the samples behind them read
+    it from its start again - bit-equal to the ordinary call with the mask tensor repeated (sub-pixel, polyphase,
+    stride-1 / 16-byte and split-K epilogues)."""
+    if B == 128 and L > 256:
+        pytest.skip("large case on the short layers only")
+    k = K()
+    g = torch.Generator().manual_seed(5)
+    Lout = (L + 2 * p - ks) // s + 1
+    dy = torch.randn(B, cout, Lout, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, ks, generator=g) / math.sqrt(cin * ks)).to(DEV)
+    # (the mask is the FRONT of a larger buffer whose tail is poison: a read past the shared mask shows)
+    buf = torch.full((mb + 1, cin, L), float("nan"), device=DEV)
+    buf[:mb] = torch.randn(mb, cin, L, generator=g).to(DEV)
+    mask = buf[:mb]
+    full = torch.cat([mask, mask[:B - mb]], 0).contiguous()
+    for slope in (0.0, 0.2):
+        with k.weight_cache():
+            want = k.conv1d_bwd_data(dy, w, L, s, p, out_mask=full, out_mask_slope=slope)
+            got = k.conv1d_bwd_data(dy, w, L, s, p, out_mask=mask, out_mask_slope=slope)
+        assert torch.equal(got, want), (got - want).abs().max()
