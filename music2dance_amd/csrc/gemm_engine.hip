@@ -464,7 +464,6 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
   const bool two_out = O.sum_out != nullptr && !slab;
   const int act = slab ? 0 : O.act;
   const float ms = O.mask_slope;
-  const unsigned wrapb = O.mask_wrap ? O.mask_wrap * 4u : 0xffffffffu;
   const int m_stride = slab ? p.N : O.m_stride;
   const int m_div = slab ? 0 : O.m_div;
   const int c_lim = slab ? 0 : O.c_lim;
@@ -537,6 +536,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
             unsigned keep = 0xffffffffu;
             if (has_mask) {
               const __amdgpu_buffer_rsrc_t rsm = m2d_rsrc(O.mask, 0x7ffffffcu);
+              const unsigned wrapb = O.mask_wrap ? O.mask_wrap * 4u : 0xffffffffu;   // (formed where it is used: register budget)
               keep = 0u;
               if constexpr (WIDE) {
                 float4 mraw[NI];
@@ -620,6 +620,7 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
         unsigned keep = 0xffffffffu;
         if (has_mask) {
           keep = 0u;
+          const unsigned wrapb = O.mask_wrap ? O.mask_wrap * 4u : 0xffffffffu;
           if constexpr (WIDE) {
             float4 mraw[GROUP];
 #pragma unroll
@@ -1605,6 +1606,15 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
   const double pen = small_tile_penalty > 1.0 ? small_tile_penalty : 1.0;
   const double tc[3] = {0.98, 0.56 * pen, 0.33 * pen};
   const int resident[3] = {3, 5, 7};         // blocks per CU (VGPR / LDS budget)
+  // Round 5: a chunk step of ONE workgroup cannot be shorter than its staging round trip (issue -> landed -> barrier),
+  // whatever the tile height: measured 1.46 us per chunk for a lone 128-row workgroup, 1.2-1.39 us for 64-row ones
+  // (two per CU: the audio critic's 32 -> 64 weight gradient ran 73 splits = 2 workgroups per CU at 730 us, 256 splits
+  // at 623), 1.2 us for 32-row ones. The old floor, tc + 0.55, priced a 64-row step at 1.11 us and a 32-row one at 0.88,
+  // so plans with two or three workgroups per CU looked as good as plans that fill the CU. M2D_PLAN_MODEL=4: old floor,
+  // old split cap (A/B lever).
+  static const bool model5 = [] { const char* e = getenv("M2D_PLAN_MODEL"); return !(e && e[0] == '4'); }();
+  const double lchunk[3] = {1.50, 1.35, 1.20};
+  const long long max_splits = model5 ? 512 : 128;
   PlanCand all[40];
   int na = 0;
   for (int b = 0; b < 3; ++b) {
@@ -1615,7 +1625,7 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
     if (can_split && nchunks >= 8) {
       for (int k = 1; k <= 8; ++k) {
         long long sp = (256LL * k) / tiles;
-        if (sp > 128) sp = 128;
+        if (sp > max_splits) sp = max_splits;
         if (sp > nchunks / 4) sp = nchunks / 4;
         if (sp > 1) cand[nc++] = sp;
       }
@@ -1632,7 +1642,8 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
       const long long conc = per_cu < resident[b] ? per_cu : resident[b];
       const double cps = (double)m2d_ceil_div64(nchunks > 0 ? nchunks : 1, sp);
       const double thr = (double)per_cu * tc[b];
-      const double lat = (double)m2d_ceil_div64(per_cu, conc) * (tc[b] + 0.55);
+      const double step = (model5 && lchunk[b] > tc[b] + 0.55) ? lchunk[b] : tc[b] + 0.55;
+      const double lat = (double)m2d_ceil_div64(per_cu, conc) * step;
       double cost = 8.0 + cps * (thr > lat ? thr : lat);
       // (the second launch is gone for splits <= 16 on a stream with tickets, m2d_splitk_fixup, but pricing the split
       // cheaper - 2 or 0 us instead of 6 - moved neither C3 nor C2: the slab term decides)

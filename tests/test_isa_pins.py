@@ -1,0 +1,130 @@
+"""Build-time pins on the GEMM engine's code objects (no GPU needed: hipcc cross-compiles, tools/isa_info.py reads
+the gfx950 bundle out of music2dance_amd/lib/obj/gemm_engine.o).
+
+Round-4 verdict item 6: the K loop's schedule is fragile - source edits that did not touch it moved the plain GEMM by
+7 % twice, and an occupancy step lost through a few more VGPRs or SGPRs is invisible until somebody
+profiles. What the hot instantiations must keep is pinned here, so that a compiler bump or an innocent edit turns the
+build red instead of costing an afternoon on the GPU box:
+  * register budgets that decide how many workgroups a CU holds (512 VGPRs and 800 SGPRs per SIMD, LDS in 1280-byte
+    granules: four 32 KB workgroups per CU);
+  * no scratch, no VGPR spills in the kernels the step runs;
+  * the MFMA count of the loop body = one 16-deep chunk of the tile;
+  * no `s_waitcnt vmcnt(0)` between the first and the last MFMA of the LDS-direct loops (the drain belongs behind them).
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_info  # noqa: E402
+
+OBJ = os.path.join(ROOT, "music2dance_amd", "lib", "obj", "gemm_engine.o")
+pytestmark = pytest.mark.skipif(not os.path.exists(OBJ) or isa_info._tool("llvm-objdump") is None,
+                                reason="needs the built objects (python -m music2dance_amd.build) and llvm-objdump")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import shutil
+    co = isa_info.code_object("gemm_engine")
+    tab = isa_info.kernel_table(co)
+    yield co, tab
+    shutil.rmtree(os.path.dirname(co), ignore_errors=True)
+
+
+def _find(tab, text):
+    hits = [n for n in tab if text in n]
+    assert len(hits) == 1, (text, hits)
+    return hits[0], tab[hits[0]]
+
+
+def _loop(co, row):
+    body, st = isa_info.hot_loop(isa_info.disassemble(co, row["symbol"]))
+    assert st, "no loop with MFMAs found"
+    return st
+
+
+# kernel (substring of the demangled name) -> (max VGPRs, max SGPRs, LDS bytes, MFMAs per loop body)
+LDS_DIRECT = {
+    # 128 x 128, four waves: 16-byte epilogue / sub-pixel epilogue at <= 96 VGPRs (five waves per SIMD were the design
+    # point; the LDS granule makes it four workgroups - still: do not grow)
+    "m2d_gemm_dl_kernel<128, 128, 1, 4>": (96, 106, 32768, 32),
+    "m2d_gemm_dl_kernel<128, 128, 2, 4>": (96, 106, 32768, 32),
+    # eight waves: 8 waves per SIMD = <= 64 VGPRs AND <= 96 SGPRs (7 waves at 106: only three workgroups per CU)
+    "m2d_gemm_dl_kernel<128, 128, 1, 8>": (64, 96, 32768, 16),
+    "m2d_gemm_dl_kernel<128, 128, 2, 8>": (64, 96, 32768, 16),
+    "m2d_gemm_dl_kernel<64, 128, 1, 4>": (72, 106, 24576, 16),
+    "m2d_gemm_dl_kernel<32, 128, 1, 4>": (48, 106, 20480, 8),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LDS_DIRECT))
+def test_lds_direct_kernels_keep_their_budgets_and_their_loop(engine, name):
+    co, tab = engine
+    vg, sg, lds, mfma = LDS_DIRECT[name]
+    full, row = _find(tab, name)
+    assert row["vgpr"] <= vg, "%s: %d VGPRs > %d" % (full, row["vgpr"], vg)
+    assert row["sgpr"] <= sg, "%s: %d SGPRs > %d" % (full, row["sgpr"], sg)
+    assert row["lds"] == lds, "%s: %d bytes of LDS" % (full, row["lds"])
+    assert row["scratch"] == 0 and row["vgpr_spill"] == 0, "%s spills: %r" % (full, row)
+    st = _loop(co, row)
+    assert st["mfma"] == mfma, st
+    assert st["vmcnt0_inside_mfma_span"] == 0, st
+    assert st["ds_write"] == 0 and st["lds_dma"] > 0, st          # staged by LDS-DMA, no register pass
+    assert st["barriers"] == 1, st
+
+
+REGISTER_STAGED = {
+    # the weight-gradient kernels (A = dy, K-contiguous): four workgroups per CU need <= 128 VGPRs
+    "m2d_gemm_kernel<128, 128, true, false, false, true>": (128, 32),
+    "m2d_gemm_kernel<128, 128, true, false, false, false>": (128, 32),
+    "m2d_gemm_kernel<64, 128, true, false, false, false>": (96, 16),
+    "m2d_gemm_kernel<64, 128, true, false, true, false>": (102, 16),   # masked dy (TemporalBlock conv2)
+}
+
+
+@pytest.mark.parametrize("name", sorted(REGISTER_STAGED))
+def test_register_staged_kernels_keep_their_budgets(engine, name):
+    co, tab = engine
+    vg, mfma = REGISTER_STAGED[name]
+    full, row = _find(tab, name)
+    assert row["vgpr"] <= vg, "%s: %d VGPRs > %d" % (full, row["vgpr"], vg)
+    assert row["scratch"] == 0 and row["vgpr_spill"] == 0, "%s spills: %r" % (full, row)
+    st = _loop(co, row)
+    assert st["mfma"] == mfma, st
+
+
+def test_tap_vectorised_forward_keeps_its_budget(engine):
+    co, tab = engine
+    for name, vg in (("m2d_conv_k4_kernel<128, 128, true>", 96), ("m2d_conv_k4_kernel<64, 128, true>", 72)):
+        full, row = _find(tab, name)
+        assert row["vgpr"] <= vg and row["lds"] <= 32768, (full, row)
+        assert row["scratch"] == 0 and row["vgpr_spill"] == 0, (full, row)
+
+
+def test_no_engine_kernel_of_the_step_uses_scratch(engine):
+    """Known exceptions (never on the step's path at the BASELINE configs): the one-element-epilogue variants of the masked
+    32-row / 64-row register-staging kernels and of the tap-vectorised forward keep a few dwords of scratch."""
+    _, tab = engine
+    allowed = ("m2d_gemm_kernel<32, 128, true, false, true, true>", "m2d_gemm_kernel<32, 128, false, false, true, true>",
+               "m2d_gemm_kernel<32, 128, false, false, true, false>", "m2d_gemm_kernel<64, 128, false, false, true, true>",
+               "m2d_gemm_kernel<64, 128, true, true, true, false>", "m2d_gemm_kernel<128, 128, false, false, true, true>",
+               "m2d_conv_k4_kernel<128, 128, false>",
+               # (68 bytes reserved for SGPR spills around the one-element epilogue; no scratch instruction in the kernel)
+               "m2d_gemm_kernel<128, 128, false, false, false, false>")
+    bad = {n: (r["scratch"], r["vgpr_spill"]) for n, r in tab.items()
+           if (r["scratch"] or r["vgpr_spill"]) and not any(a in n for a in allowed)}
+    assert not bad, bad
+
+
+def test_no_hot_loop_touches_scratch(engine):
+    co, tab = engine
+    for n, r in tab.items():
+        if "m2d_gemm" not in n and "m2d_conv_k4" not in n:
+            continue
+        if "splitk_reduce" in n or "m2d_conv_k4_kernel<128, 128, false>" in n:
+            continue   # (the tap-vectorised forward with the one-element epilogue: 7 VGPRs spilled since round 3; never on the step's path)
+        _, st = isa_info.hot_loop(isa_info.disassemble(co, r["symbol"]))
+        assert st and st["scratch_ops"] == 0, (n, st)
