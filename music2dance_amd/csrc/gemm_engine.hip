@@ -1610,11 +1610,16 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
   // whatever the tile height: measured 1.46 us per chunk for a lone 128-row workgroup, 1.2-1.39 us for 64-row ones
   // (two per CU: the audio critic's 32 -> 64 weight gradient ran 73 splits = 2 workgroups per CU at 730 us, 256 splits
   // at 623), 1.2 us for 32-row ones. The old floor, tc + 0.55, priced a 64-row step at 1.11 us and a 32-row one at 0.88,
-  // so plans with two or three workgroups per CU looked as good as plans that fill the CU. M2D_PLAN_MODEL=4: old floor,
-  // old split cap (A/B lever).
-  static const bool model5 = [] { const char* e = getenv("M2D_PLAN_MODEL"); return !(e && e[0] == '4'); }();
+  // so plans with two or three workgroups per CU looked as good as plans that fill the CU. With the new floor (and splits
+  // up to 256) the launches measured one by one get faster - engine 0.583 -> 0.588 of peak, the pose critic 61 -> 64.5
+  // TFLOP/s, the 32 -> 64 weight gradient 692 -> 653 us (profiles/r05_planmodel_shapes_diff.txt) - but the STEP, whose
+  // streams overlap, gets slower: 12.00 -> 12.10 ms, five alternating pairs (profiles/r05_ab_planmodel.txt): under
+  // overlap a launch that leaves CUs idle costs little (another stream's workgroups take them), while extra splits cost
+  // slab traffic and fix-up work for everybody. So the round-4 floor stays the default; M2D_PLAN_MODEL=5 selects the new one.
+  static const bool model5 = [] { const char* e = getenv("M2D_PLAN_MODEL"); return e && e[0] == '5'; }();
+  static const double slab_mul = [] { const char* e = getenv("M2D_SLAB_COST"); return e ? atof(e) : 1.0; }();   // A/B lever
   const double lchunk[3] = {1.50, 1.35, 1.20};
-  const long long max_splits = model5 ? 512 : 128;
+  const long long max_splits = model5 ? 256 : 128;
   PlanCand all[40];
   int na = 0;
   for (int b = 0; b < 3; ++b) {
@@ -1647,7 +1652,7 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
       double cost = 8.0 + cps * (thr > lat ? thr : lat);
       // (the second launch is gone for splits <= 16 on a stream with tickets, m2d_splitk_fixup, but pricing the split
       // cheaper - 2 or 0 us instead of 6 - moved neither C3 nor C2: the slab term decides)
-      if (sp > 1) cost += 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
+      if (sp > 1) cost += 6.0 + slab_mul * (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
       all[na].bm = bms[b];
       all[na].splits = (int)sp;
       all[na].cost = cost;
