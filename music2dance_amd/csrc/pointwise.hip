@@ -219,36 +219,128 @@ __global__ void __launch_bounds__(256) m2d_affine_cols_kernel(const float* x, co
 
 // ---------------------------------------------------------------- multi-tensor Adam (+ packed conv-weight images)
 // One launch steps up to M2D_ADAM_BATCH tensors (their records travel in the kernel arguments, like torch's
-// multi_tensor_apply): a workgroup owns 2 048 consecutive elements of one tensor; 28 algorithmic bytes per element
-// (read p, g, m, v; write p, m, v) + 8 per element of a conv weight whose packed images are refreshed on the way.
+// multi_tensor_apply). 28 algorithmic bytes per element (read p, g, m, v; write p, m, v) + 8 per element of a conv weight
+// whose packed images are refreshed on the way. Round 5 (the round-4 kernel moved 309 MB in 121-141 us = 0.28-0.32 of
+// HBM peak: one dword per lane and access, and the two packed images written as 4-byte stores a whole row apart):
+//   plain tensors    a workgroup owns 4 096 consecutive elements, 16 bytes per lane and access;
+//   packed weights   a workgroup owns a tile of 8 output channels x 256 (ci, kk) positions: the four streams are read and
+//                    written as 16-byte runs along (ci, kk), the updated tile is kept in LDS and leaves once more as the
+//                    forward image (ci, kk, co) - 8 consecutive co per run - and as the backward image (co, kk, ci) - the
+//                    tile's ~256 / ks consecutive ci per run.
+// The arithmetic and its order are unchanged (bit-equal to torch.optim.Adam(foreach=False), tests/test_optim.py).
 #define M2D_ADAM_BATCH 48
-#define M2D_ADAM_CHUNK 2048
+#define M2D_ADAM_CHUNK 4096
+#define M2D_ADAM_TCO 8
+#define M2D_ADAM_TJ 256
+#define M2D_ADAM_VEC 1   // reserved bit 0: every pointer 16-byte aligned
+#define M2D_ADAM_TILE 2  // reserved bit 1: tile mode (packed images, cin * ks a multiple of 4, aligned)
 struct M2dAdamBatch {
   M2dAdamItem it[M2D_ADAM_BATCH];
   int first_block[M2D_ADAM_BATCH + 1];
   int n;
 };
 
+__device__ __forceinline__ void m2d_adam_one(float g, float& m, float& v, float& p, float omb1, float beta2, float omb2,
+                                             float bc2_sqrt, float eps, float lr_over_bc1) {
+  m = m + omb1 * (g - m);
+  v = beta2 * v + omb2 * g * g;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - lr_over_bc1 * (m / denom);
+}
+
 __global__ void __launch_bounds__(256) m2d_adam_multi_kernel(const M2dAdamBatch b, float lr_over_bc1, float beta1, float beta2,
                                                              float eps, float bc2_sqrt, const float* skip) {
   // (any non-zero BIT pattern counts: the word may be an unsigned flag, e.g. m2d_async_fault_word(); read past the
-  // caches - it can live in mapped host memory and be raised by a kernel that ran just before)
+  // caches - it can be raised by a kernel that ran just before)
   if (skip && __hip_atomic_load((const unsigned*)skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  __shared__ float P[M2D_ADAM_TCO][M2D_ADAM_TJ + 4];
   int k = 0;
   while (k + 1 < b.n && (int)blockIdx.x >= b.first_block[k + 1]) ++k;   // wave-uniform
   const M2dAdamItem& t = b.it[k];
-  const long long base = (long long)((int)blockIdx.x - b.first_block[k]) * M2D_ADAM_CHUNK;
+  const int lb = (int)blockIdx.x - b.first_block[k];
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  const int tid = threadIdx.x;
+  if (t.reserved & M2D_ADAM_TILE) {
+    const int J = t.cin * t.ks;
+    const int tiles_j = (J + M2D_ADAM_TJ - 1) / M2D_ADAM_TJ;
+    const int tco = lb / tiles_j, tj = lb - tco * tiles_j;
+    const int co0 = tco * M2D_ADAM_TCO, j0 = tj * M2D_ADAM_TJ;
 #pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int sidx = tid + 256 * e, r = sidx >> 6, c4 = sidx & 63;
+      const int co = co0 + r, j = j0 + 4 * c4;
+      if (co < t.cout && j < J) {   // (J % 4 == 0: the four lanes are inside together)
+        const long long i = (long long)co * J + j;
+        const float4 g = *reinterpret_cast<const float4*>(t.grad + i);
+        float4 m = *reinterpret_cast<const float4*>(t.exp_avg + i), v = *reinterpret_cast<const float4*>(t.exp_avg_sq + i);
+        float4 p = *reinterpret_cast<const float4*>(t.param + i);
+        m2d_adam_one(g.x, m.x, v.x, p.x, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+        m2d_adam_one(g.y, m.y, v.y, p.y, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+        m2d_adam_one(g.z, m.z, v.z, p.z, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+        m2d_adam_one(g.w, m.w, v.w, p.w, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+        *reinterpret_cast<float4*>(t.exp_avg + i) = m;
+        *reinterpret_cast<float4*>(t.exp_avg_sq + i) = v;
+        *reinterpret_cast<float4*>(t.param + i) = p;
+        P[r][4 * c4] = p.x; P[r][4 * c4 + 1] = p.y; P[r][4 * c4 + 2] = p.z; P[r][4 * c4 + 3] = p.w;
+      }
+    }
+    __syncthreads();
+    if (t.pack_fwd) {  // (ci, kk, co): element (co, j) at j * cout + co - 8 consecutive co per run
+      const int co_l = tid & (M2D_ADAM_TCO - 1), co = co0 + co_l;
+#pragma unroll
+      for (int e = 0; e < M2D_ADAM_TJ / 32; ++e) {
+        const int jj = (tid >> 3) + 32 * e, j = j0 + jj;
+        if (co < t.cout && j < J) t.pack_fwd[(long long)j * t.cout + co] = P[co_l][jj];
+      }
+    }
+    if (t.pack_bwd) {  // (co, kk, ci): element (co, j = ci * ks + kk) at (co * ks + kk) * cin + ci - consecutive ci per run
+      const int r = tid >> 5, u = tid & 31, co = co0 + r;
+      const int ci_first = j0 / t.ks;
+      const int j_end = (j0 + M2D_ADAM_TJ < J) ? j0 + M2D_ADAM_TJ : J;
+      const int nci = (j_end - 1) / t.ks - ci_first + 1;
+      if (co < t.cout)
+        for (int idx = u; idx < nci * t.ks; idx += 32) {
+          const int kk = idx / nci, ci = ci_first + (idx - kk * nci);
+          const int j = ci * t.ks + kk;
+          if (j >= j0 && j < j_end) t.pack_bwd[((long long)co * t.ks + kk) * t.cin + ci] = P[r][j - j0];
+        }
+    }
+    return;
+  }
+  const long long base = (long long)lb * M2D_ADAM_CHUNK;
+  if (t.reserved & M2D_ADAM_VEC) {
+#pragma unroll
+    for (int e = 0; e < M2D_ADAM_CHUNK / 1024; ++e) {
+      const long long i = base + 4LL * (tid + 256 * e);
+      if (i + 3 < t.numel) {
+        const float4 g = *reinterpret_cast<const float4*>(t.grad + i);
+        float4 m = *reinterpret_cast<const float4*>(t.exp_avg + i), v = *reinterpret_cast<const float4*>(t.exp_avg_sq + i);
+        float4 p = *reinterpret_cast<const float4*>(t.param + i);
+        m2d_adam_one(g.x, m.x, v.x, p.x, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+        m2d_adam_one(g.y, m.y, v.y, p.y, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+        m2d_adam_one(g.z, m.z, v.z, p.z, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+        m2d_adam_one(g.w, m.w, v.w, p.w, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+        *reinterpret_cast<float4*>(t.exp_avg + i) = m;
+        *reinterpret_cast<float4*>(t.exp_avg_sq + i) = v;
+        *reinterpret_cast<float4*>(t.param + i) = p;
+      } else {
+        for (long long q = i; q < t.numel && q < i + 4; ++q) {
+          float m = t.exp_avg[q], v = t.exp_avg_sq[q], p = t.param[q];
+          m2d_adam_one(t.grad[q], m, v, p, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
+          t.exp_avg[q] = m; t.exp_avg_sq[q] = v; t.param[q] = p;
+        }
+      }
+    }
+    return;
+  }
+  // unaligned tensors / packed weights whose rows are not multiples of 4 (the pose critic's 69-channel first layer):
+  // one element per lane and access, the packed images as scattered stores
+#pragma unroll 4
   for (int e = 0; e < M2D_ADAM_CHUNK / 256; ++e) {
-    const long long i = base + e * 256 + threadIdx.x;
+    const long long i = base + e * 256 + tid;
     if (i >= t.numel) break;
-    const float g = t.grad[i];
     float m = t.exp_avg[i], v = t.exp_avg_sq[i], p = t.param[i];
-    m = m + omb1 * (g - m);
-    v = beta2 * v + omb2 * g * g;
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p = p - lr_over_bc1 * (m / denom);
+    m2d_adam_one(t.grad[i], m, v, p, omb1, beta2, omb2, bc2_sqrt, eps, lr_over_bc1);
     t.exp_avg[i] = m;
     t.exp_avg_sq[i] = v;
     t.param[i] = p;
@@ -671,9 +763,17 @@ int m2d_adam_multi(const M2dAdamItem* items, int n, float lr, float beta1, float
     int blocks = 0;
     for (; i0 < n && b.n < M2D_ADAM_BATCH; ++i0) {
       if (items[i0].numel == 0) continue;
-      b.it[b.n] = items[i0];
+      M2dAdamItem& t = b.it[b.n];
+      t = items[i0];
+      const bool al = ((((uintptr_t)t.param | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15u) == 0);
+      const bool packed = t.pack_fwd || t.pack_bwd;
+      const bool tile = packed && al && ((t.cin * t.ks) % 4) == 0;
+      t.reserved = tile ? M2D_ADAM_TILE : ((al && !packed) ? M2D_ADAM_VEC : 0);
       b.first_block[b.n] = blocks;
-      blocks += (int)((items[i0].numel + M2D_ADAM_CHUNK - 1) / M2D_ADAM_CHUNK);
+      if (tile)
+        blocks += ((t.cout + M2D_ADAM_TCO - 1) / M2D_ADAM_TCO) * ((t.cin * t.ks + M2D_ADAM_TJ - 1) / M2D_ADAM_TJ);
+      else
+        blocks += (int)((t.numel + M2D_ADAM_CHUNK - 1) / M2D_ADAM_CHUNK);
       ++b.n;
     }
     b.first_block[b.n] = blocks;

@@ -96,3 +96,35 @@ def test_packed_conv_images_are_rewritten_by_the_step():
         opt.step()
         torch.cuda.synchronize()
         assert torch.equal(held, w.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 32, 25), (100, 36, 7), (128, 69, 25), (128, 128, 7), (512, 256, 25), (20, 16, 3)])
+def test_packed_images_after_the_step_for_every_tile_shape(shape):
+    """Round 5: the step of a conv weight with live packed images goes through 8 x 256 LDS tiles (rows that are not a
+    multiple of 4 floats long: the one-element path). Parameters and moments bit-equal to torch.optim.Adam(foreach=False),
+    both images equal to a fresh pack of the updated weight - over three steps, with output-channel counts that are not
+    multiples of 8 and rows that end inside a tile."""
+    dev = torch.device("cuda:0")
+    K = kernels.impl()
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
+    w_ref = w.detach().clone().requires_grad_(True)
+    opt, opt_ref = Adam([w], lr=1e-3), torch.optim.Adam([w_ref], lr=1e-3, foreach=False)
+    with K.weight_cache():
+        K.packed_weights(w)
+        for _ in range(3):
+            gr = torch.randn(shape, generator=g).to(dev)
+            w.grad, w_ref.grad = gr.clone(), gr.clone()
+            opt.step()
+            opt_ref.step()
+            K.invalidate_packed([w])
+            wf, wb = K.packed_weights(w)
+            assert torch.allclose(w.detach(), w_ref.detach(), rtol=2e-6, atol=2e-7)
+            assert torch.equal(wf, w.detach().permute(1, 2, 0).contiguous())
+            assert torch.equal(wb, w.detach().permute(0, 2, 1).contiguous())
+    st, st_ref = opt.state[w], opt_ref.state[w_ref]
+    # (moments: relative to the tensor's largest element; 1 - beta2 is formed in fp32 here and in fp64 by torch: 1.3e-5)
+    for key, tol in (("exp_avg", 1e-6), ("exp_avg_sq", 3e-5)):
+        a, b = st[key], st_ref[key]
+        assert (a - b).abs().max().item() <= tol * b.abs().max().item(), key
