@@ -116,6 +116,12 @@ int m2d_conv1d_bwd_data_res(const float* dy, const float* w, const float* w_pack
 int m2d_conv1d_bwd_weight_from(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int L,
                                int Cout, int ks, int stride, int pad, const float* dy_mask, float dy_mask_slope,
                                int bias_from_sample, void* ws, size_t ws_bytes, void* stream);
+/* Round 5. Advance BatchNorm running buffers once more with batch statistics (raw fp64 sums, as m2d_bn_stats / a conv's
+ * epilogue deliver them) they were already advanced with: what a second training-mode forward of the same batch through
+ * the same weights leaves behind, without the forward (phase3/train.py:195 + :222: the loop body that holds a generator
+ * iteration runs the generator twice on one batch; its audio path is the same both times). tmp: 2 C floats. */
+int m2d_bn_update_running(const double* sums, double count, float* running_mean, float* running_var, float* tmp, int C,
+                          float eps, float momentum, void* stream);
 /* Round 5. m2d_conv1d_bwd_data over a batch whose two halves pass through the SAME activation masks: `out_mask` holds
  * mask_batch samples (B / 2 <= mask_batch <= B); sample n >= mask_batch of dx is masked by mask sample n - mask_batch.
  * The audio branch of the phase-3 critic (phase3/archis/default.py:312-319) is evaluated on the same audio for the

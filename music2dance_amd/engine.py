@@ -140,7 +140,7 @@ class WganGpEngine:
         if self._gen_stream is not None:
             self._gen_params_ready = torch.cuda.current_stream().record_event()
 
-    def _generator_forward_nograd(self, fn, inputs, device=None):
+    def _generator_forward_nograd(self, fn, inputs, device=None, grad=False):
         """The generator forward of a critic iteration (no autograd graph: the reference builds one and
         drops it). It reads the generator's weights and the batch, nothing the critic's optimizer
         touches, so it need not wait for the previous critic iteration: when the caller passes
@@ -151,8 +151,11 @@ class WganGpEngine:
         `inputs_ready` the forward runs in line."""
         ready = self._inputs_ready
         dev = device if device is not None else inputs[0].device
+        # grad: this forward's audio path is kept (with its autograd graph) for the generator iteration of the same
+        # loop body (Phase3Engine.reuse_audio_path); everything else about it is as without
+        mode = torch.enable_grad if grad else torch.no_grad
         if ready is None or not self.pipeline_generator or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
-            with torch.no_grad():
+            with mode():
                 return fn()
         main = torch.cuda.current_stream(dev)
         if self._gen_stream is None:
@@ -174,7 +177,7 @@ class WganGpEngine:
         if self._main_mark is not None:
             # at most one iteration ahead: not before the main stream has taken delivery of the previous result
             gs.wait_event(self._main_mark)
-        with torch.cuda.stream(gs), torch.no_grad():
+        with torch.cuda.stream(gs), mode():
             out = fn()
             done = gs.record_event()
         for t in inputs:
@@ -267,6 +270,14 @@ class Phase3Engine(WganGpEngine):
         self.output_size = int(cfg.get("output_size", 69))
         self.ablated = bool(ablated)
         self.early_pair_pass = os.environ.get("M2D_EARLY_PAIR", "1") != "0"
+        # The loop body that holds a generator iteration runs the generator TWICE on one batch (phase3/train.py:195 for the
+        # critic iteration, :222 for the generator iteration, fresh noise): encoder and audio GRU do not see the noise, so
+        # the second pass's audio path equals the first's. With this on, the first pass of such a body keeps it (autograd
+        # graph included) and the generator iteration runs only noise GRU + decoder on top, replaying the encoder's
+        # BatchNorm running-statistics update with the same sums (SequenceGenerator.forward_keeping_audio_path).
+        # M2D_REUSE_AUDIO_PATH=0: both passes in full, as the reference executes them.
+        self.reuse_audio_path = (os.environ.get("M2D_REUSE_AUDIO_PATH", "1") != "0"
+                                 and hasattr(gen, "forward_keeping_audio_path"))
         if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
             self.manual_critic = CriticStep(critic, self.gamma, lp=False)
 
@@ -286,7 +297,16 @@ class Phase3Engine(WganGpEngine):
         noise / alpha: None = drawn from the host generator where the reference draws them."""
         B, T = self._shapes(real)
         # the reference builds and drops this graph (phase3/train.py:195)
-        fake_rows = self._generator_forward_nograd(lambda: self.gen(audio_slices, [T] * B, noise), (audio_slices,))
+        keep = (self.reuse_audio_path and finish_inside and self.gen.training
+                and self.total_iterations % self.n_critic_steps == 0
+                and not (real.is_cuda and torch.cuda.is_current_stream_capturing()))
+        if keep:
+            fake_rows = self._generator_forward_nograd(
+                lambda: self.gen.forward_keeping_audio_path(audio_slices, [T] * B, noise).detach(), (audio_slices,), grad=True)
+        else:
+            if hasattr(self.gen, "drop_kept_audio_path"):
+                self.gen.drop_kept_audio_path()
+            fake_rows = self._generator_forward_nograd(lambda: self.gen(audio_slices, [T] * B, noise), (audio_slices,))
         if finish_inside:
             self._finish_critic_step()
         # only after the deferred step has consumed the previous iteration's gradients
@@ -335,7 +355,10 @@ class Phase3Engine(WganGpEngine):
     def _generator_body(self, real, audio, audio_slices, noise):
         B, T = self._shapes(real)
         self.optim_gen.zero_grad(set_to_none=True)
-        fake_rows = self.gen(audio_slices, [T] * B, noise)
+        if self.reuse_audio_path and self.gen.kept_audio_path():
+            fake_rows = self.gen.forward_from_kept_audio_path(noise)   # (the critic iteration of this body kept it)
+        else:
+            fake_rows = self.gen(audio_slices, [T] * B, noise)
         real_rows = real.reshape(B * T, self.output_size)
         err_l1 = ops.l1_mean(real_rows, fake_rows)
         fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1)

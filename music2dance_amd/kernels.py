@@ -733,6 +733,17 @@ class HipKernels:
         _lib.check(rc, "m2d_bn_fwd_sums")
         return y, save_mean, save_invstd
 
+    def bn_update_running(self, sums, count, running_mean, running_var, eps, momentum):
+        """running buffers advanced once more with batch sums they were already advanced with (include/m2d.h)"""
+        dev = _chk(running_mean, running_var)
+        C = running_mean.numel()
+        self._sums_ok(sums, C, dev)
+        tmp = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+        with _on(dev):
+            rc = _lib.lib().m2d_bn_update_running(_ptr(sums), float(count), _ptr(running_mean), _ptr(running_var),
+                                                  _ptr(tmp), C, eps, momentum, _stream(dev))
+        _lib.check(rc, "m2d_bn_update_running")
+
     def bn_bwd_stats(self, dy, x, gamma, beta, save_mean, save_invstd, act=0, slope=0.0):
         """(2C,) float64: sum dz and sum dz * xhat, dz = dy * act'(bn(x))."""
         dev = _chk(dy, x, gamma, beta, save_mean, save_invstd)

@@ -450,6 +450,10 @@ def set_sync_batchnorm(on=True, group=None):
     return _sync_bn["on"]
 
 
+def sync_batchnorm_active():
+    return bool(_sync_bn["on"])
+
+
 def _sync_world():
     if not _sync_bn["on"]:
         return 1

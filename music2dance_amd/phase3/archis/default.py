@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import kernels, ops
 from ...layers import (GRU, BatchNorm1d, Conv1d, Linear, WindowView, batched_bn_counters, head_activation,
                        lengths_tensor, to_device_async)
 from ...utils import initialize_weights
@@ -43,7 +43,14 @@ def _conv_bn(conv, bn, x, act, slope=0.0, into=None):
     else:
         out = conv(x, with_stats=stats)
     y, sums = out if stats else (out, None)
+    if _BN_SUMS_LOG[0] is not None:
+        # (SequenceGenerator.audio_path(keep=True): the batch statistics every BatchNorm of the audio path was advanced
+        # with - None when this one computed its own: the path then cannot be replayed)
+        _BN_SUMS_LOG[0].append((bn, sums if (stats and not ops.sync_batchnorm_active()) else None, y.numel() // y.shape[1]))
     return bn(y, act=act, slope=slope, sums=sums, out=into)
+
+
+_BN_SUMS_LOG = [None]
 
 
 def _head(module, conv, x, in_act=None):
@@ -310,8 +317,61 @@ class SequenceGenerator(nn.Module):
         else:
             h = self.audio_rnn(code, lengths_tensor(ls, frames, code.device))[:, :max(ls)]
             n = self.noise_gen(noise)
+        if self._keep_audio_path:
+            self._kept_audio = (h, self._kept_audio[1] if self._kept_audio else None)
         latent = torch.cat((h, n), -1)
         return self.decoder(latent.reshape(-1, self.decoder.latent_size))
+
+    # -- the audio path of a forward, kept for a second forward of the SAME batch through the SAME weights --------------
+    # The reference's loop body that holds a generator iteration runs the generator twice on one batch: once for the
+    # critic iteration (phase3/train.py:195, graph built and dropped) and once for the generator iteration (:222), with
+    # fresh noise. Encoder and audio GRU do not see the noise: their activations are the same both times. forward(...,
+    # keep_audio_path=True) keeps the audio GRU's output (with its autograd graph) and the batch statistics every
+    # BatchNorm of the encoder was advanced with; forward_from_kept_audio_path(noise) is then the second forward:
+    # noise GRU + decoder on the kept output, the encoder's running statistics advanced once more with the SAME sums
+    # (m2d_bn_update_running: exactly what the second pass would leave), the step counters bumped as forward() does.
+    _keep_audio_path = False
+    _kept_audio = None
+
+    def forward_keeping_audio_path(self, x, lengths, noise=None):
+        """forward(x, lengths, noise) that keeps what forward_from_kept_audio_path needs (call with grad enabled).
+        -> rows; self.kept_audio_path() tells whether the second forward may use it."""
+        self._kept_audio = None
+        log = []
+        _BN_SUMS_LOG[0] = log
+        self._keep_audio_path = True
+        try:
+            rows = self.forward(x, lengths, noise)
+        finally:
+            _BN_SUMS_LOG[0] = None
+            self._keep_audio_path = False
+        enc_bns = [m for m in self.audio_enc.modules() if isinstance(m, nn.BatchNorm1d)]
+        mine = [e for e in log if any(e[0] is m for m in enc_bns)]
+        ok = (self._kept_audio is not None and len(mine) == len(enc_bns) and all(e[1] is not None for e in mine)
+              and len({id(e[0]) for e in mine}) == len(enc_bns))
+        self._kept_audio = (self._kept_audio[0], mine) if ok else None
+        return rows
+
+    def kept_audio_path(self):
+        return self._kept_audio is not None
+
+    def drop_kept_audio_path(self):
+        self._kept_audio = None
+
+    def forward_from_kept_audio_path(self, noise=None):
+        """The second forward of the batch forward_keeping_audio_path saw (same weights in between): -> rows."""
+        h, sums_log = self._kept_audio
+        self._kept_audio = None
+        with batched_bn_counters(self):   # every BatchNorm's step counter, the encoder's included: as forward() does
+            if self.training:
+                with torch.no_grad():
+                    for bn, sums, count in sums_log:
+                        kernels.impl().bn_update_running(sums, float(count), bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+            if noise is None:
+                noise = to_device_async(torch.randn(list(h.size()[:-1]) + [self.noise_size]), h.device)
+            n = self.noise_gen(noise)
+            latent = torch.cat((h, n), -1)
+            return self.decoder(latent.reshape(-1, self.decoder.latent_size))
 
 
 # --------------------------------------------------------------------------------------- critics

@@ -197,6 +197,12 @@ class FakeKernels:
             y = y + residual
         return self._into(out, y), mean, invstd
 
+    def bn_update_running(self, sums, count, running_mean, running_var, eps, momentum):
+        mean64 = sums[0::2] / count
+        var64 = (sums[1::2] / count - mean64 * mean64).clamp_min(0.0)
+        running_mean.mul_(1 - momentum).add_(momentum * mean64.float())
+        running_var.mul_(1 - momentum).add_(momentum * var64.float() * (count / (count - 1) if count > 1 else 1.0))
+
     def _bn_dz(self, dy, x, gamma, beta, save_mean, save_invstd, act, slope):
         shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
         xh = (x - save_mean.view(shape)) * save_invstd.view(shape)

@@ -1,0 +1,81 @@
+"""Round 5: the loop body that holds a generator iteration runs the generator twice on one batch (phase3/train.py:195 and
+:222). Phase3Engine keeps the first pass's audio path (encoder + audio GRU, autograd graph included) and runs the second
+pass as noise GRU + decoder on top, replaying the encoder's BatchNorm running-statistics update with the same sums. This
+must change NOTHING: losses, every generator gradient, every BatchNorm buffer and step counter, the parameters after the
+optimizer steps - against the engine with M2D_REUSE_AUDIO_PATH=0 semantics (both passes in full)."""
+import pytest
+import torch
+
+from music2dance_amd import kernels
+from music2dance_amd.engine import Phase3Engine
+from music2dance_amd.phase3.archis.default import AblatedSequenceDiscriminator, SequenceDiscriminator, SequenceGenerator
+from tests.golden import patterns as P
+
+
+@pytest.fixture(params=["cpu-fake", pytest.param("hip", marks=pytest.mark.gpu)])
+def dev(request):
+    if request.param == "hip":
+        assert kernels.impl().name == "hip"
+        yield torch.device("cuda:0")
+        return
+    from tests.fake_backend import FakeKernels
+    prev = kernels.set_impl(FakeKernels())
+    yield torch.device("cpu")
+    kernels.set_impl(prev)
+
+
+def _run(dev, enc, ablated, reuse, steps=4, B=2, T=120):
+    torch.manual_seed(0)
+    gen = SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, enc, "id", "cpu")
+    cls = AblatedSequenceDiscriminator if ablated else SequenceDiscriminator
+    critic = cls(69, 128, 100, T, init_ker=25, activ="id", device="cpu")
+    gen.to(dev), critic.to(dev)
+    cfg = {"lr_gen": 2e-4, "lr_critic": 2e-4, "n_critic_steps": 2, "gamma": 10, "beta": 1, "eta": 0.5}
+    eng = Phase3Engine(gen, critic, cfg, ablated=ablated, data_parallel=False)
+    eng.reuse_audio_path = reuse
+    real, aud = P.poses(B, T, seed=41).to(dev), P.audio(B, T, seed=42).to(dev)
+    sl = P.slices(aud.cpu()).to(dev)
+    torch.manual_seed(5)
+    used, outs = 0, []
+    orig = gen.forward_from_kept_audio_path
+
+    def counted(noise=None):
+        nonlocal used
+        used += 1
+        return orig(noise)
+
+    gen.forward_from_kept_audio_path = counted
+    grads = None
+    for i in range(steps):
+        out = eng.train_step(real, aud, sl)
+        outs.append({k: float(v) for k, v in out.items()})
+        if "loss_gen" in out:
+            grads = {n: p.grad.detach().clone() for n, p in gen.named_parameters() if p.grad is not None}
+    eng.flush()
+    return outs, grads, {k: v.detach().clone() for k, v in gen.state_dict().items()}, used
+
+
+@pytest.mark.parametrize("enc,ablated", [("default", False), ("wavegan", False), ("unet", True)])
+def test_second_generator_pass_from_the_kept_audio_path_changes_nothing(dev, enc, ablated):
+    a_out, a_g, a_sd, a_used = _run(dev, enc, ablated, True)
+    b_out, b_g, b_sd, b_used = _run(dev, enc, ablated, False)
+    assert a_used == 2 and b_used == 0, (a_used, b_used)      # generator iterations on steps 2 and 4 took the short pass
+    exact = dev.type == "cpu"
+    for x, y in zip(a_out, b_out):
+        assert x.keys() == y.keys()
+        for k in x:
+            assert abs(x[k] - y[k]) <= (0.0 if exact else 1e-6 + 1e-5 * abs(y[k])), (k, x[k], y[k])
+    assert a_g.keys() == b_g.keys()
+    for k in a_g:
+        if exact:
+            assert torch.equal(a_g[k], b_g[k]), k
+        else:   # (the backward of the kept path runs on the stream its forward ran on: same kernels, same plans)
+            assert (a_g[k] - b_g[k]).abs().max().item() <= 1e-5 * b_g[k].abs().max().item() + 1e-9, k
+    for k in a_sd:
+        if "num_batches_tracked" in k:
+            assert int(a_sd[k]) == int(b_sd[k]), k
+        elif "running" in k:
+            # the replayed update uses the SAME fp64 sums the first update used: equal to the last bit
+            assert torch.equal(a_sd[k], b_sd[k]) if exact else torch.allclose(a_sd[k], b_sd[k], rtol=1e-6, atol=1e-8), k
+        else:
+            assert torch.allclose(a_sd[k], b_sd[k], rtol=0 if exact else 1e-5, atol=0 if exact else 1e-7), k
