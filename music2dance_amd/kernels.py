@@ -282,6 +282,7 @@ class HipKernels:
             packed[key] = (weakref.ref(w, _drop), w._version, stream, wf, wb)
         return wf, wb
 
+    _SEPARATE_BIAS = os.environ.get("M2D_SEPARATE_BIAS", "1") != "0"
     _K4 = os.environ.get("M2D_K4", "1") != "0"  # A/B lever: 0 = stride-4 forwards through the generic engine
     _K4_OK = {}
 
@@ -422,7 +423,17 @@ class HipKernels:
         B2, Cout, Lout = dy.shape
         assert B == B2 and Lout == conv_out_len(L, ks, stride, pad)
         dw = torch.empty((Cout, Cin, ks), dtype=torch.float32, device=dev)
-        db = torch.empty((Cout,), dtype=torch.float32, device=dev) if with_bias else None
+        # The library takes the bias gradient from the same launch as one all-ones column of the x operand. Where
+        # Cin * ks is a multiple of the 128-column tile that column costs a whole extra N tile (the encoder's k4 layers:
+        # 129 columns = 2 tiles for 128, 257 = 3 for 256 ...), and for short outputs (K = (l, n) order: both operands
+        # row-fast) it also keeps the launch off the LDS-direct kernel (measured in the step: the 128 -> 256 encoder
+        # layer's weight gradient 501 us with the column, 190-220 us without). There the bias gradient is one
+        # channel-sum pass over dy instead (M2D_SEPARATE_BIAS=0: always the column) - for short outputs and for up to four
+        # column tiles; measured not to pay on the critic's layers (profiles/r05_separate_bias_shapes_diff.txt: the pose
+        # critic's 896 + 1 columns 95.5 -> 89.2 us + a 22 us pass, the audio critic's 3 200 + 1 columns 567 -> 604 us).
+        sep_bias = (with_bias and self._SEPARATE_BIAS and (Cin * ks) % 128 == 0 and (Lout < 16 or Cin * ks <= 512)
+                    and not self._thin(Cin, ks, stride) and _bn_scratch(dev, Cout) is not None)
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev) if (with_bias and not sep_bias) else None
         h = _lib.lib()
         ws = _ws(_ws_bytes('m2d_conv1d_workspace_bytes', 2, B, Cin, L, Cout, ks, stride, pad), dev)
         nws = 0 if ws is None else ws.numel() * 4
@@ -435,6 +446,9 @@ class HipKernels:
                 rc = h.m2d_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, L, Cout, ks, stride, pad,
                                              _ptr(dy_mask), dy_mask_slope, _ptr(ws), nws, _stream(dev))
         _lib.check(rc, "m2d_conv1d_bwd_weight")
+        if sep_bias:
+            f = int(bias_from_sample)
+            db = self.channel_sums(dy[f:] if f else dy, None if dy_mask is None else (dy_mask[f:] if f else dy_mask), dy_mask_slope)
         return (dw, db) if with_bias else dw
 
     # ---------------------------------------------------------------- conv over the windows of a padded track
