@@ -300,6 +300,57 @@ def build_p3(fx, enc, activ, ablated, T, dev):
     return fill(gen, fx, "gen", 5000).to(dev), fill(critic, fx, "critic", 6000).to(dev)
 
 
+def unet_flips(acts, sd0, slices):
+    """acts: the post-LeakyReLU outputs of the U-Net encoder's ten BatchNorm layers as the product computed them (forward
+    order). Replays the encoder with the oracle in fp32 and in fp64 from the same state and input, and returns the number
+    of elements whose LeakyReLU branch or max-pool winner differs between the product and the fp32 oracle. Asserts that
+    each of them is a rounding flip: in fp64 the pre-activation (or the gap between the two pooled neighbours) is within
+    1e-5 of the layer's scale - a wrong value would flip elements that are nowhere near the kink."""
+    import torch.nn.functional as F
+    from oracle import m2d_oracle as O
+    rec = {}
+
+    def replay(dtype):
+        out = []
+        orig = F.leaky_relu
+
+        def spy(x, slope=0.01, inplace=False):
+            y = orig(x, slope)
+            out.append(y.detach())
+            return y
+
+        F.leaky_relu = spy
+        try:
+            sd = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+            x = slices.reshape(-1, 1, slices.shape[-1]).to(dtype)
+            with torch.no_grad():
+                O.p3_unet_encoder(sd, "audio_enc.model.", x, "id", True)
+        finally:
+            F.leaky_relu = orig
+        return out
+
+    o32, o64 = replay(torch.float32), replay(torch.float64)
+    assert len(acts) == len(o32) == len(o64) == 10, (len(acts), len(o32))
+    total = 0
+    for i, (a, b, c) in enumerate(zip(acts, o32, o64)):
+        assert a.shape == b.shape
+        scale = c.abs().max().item()
+        d = (a > 0) != (b > 0)
+        if d.any():
+            # LeakyReLU(0.2): |y| >= 0.2 |pre-activation|
+            assert (c[d].abs().max().item() <= 1e-5 * scale), "layer %d: a LeakyReLU sign differs away from the kink" % i
+        total += int(d.sum())
+        if 3 <= i <= 5:   # convblock1..3 feed MaxPool1d(2, 2)
+            L = a.shape[-1] // 2 * 2
+            wa, wb = a[..., 0:L:2] >= a[..., 1:L:2], b[..., 0:L:2] >= b[..., 1:L:2]
+            dp = wa != wb
+            if dp.any():
+                gap = (c[..., 0:L:2] - c[..., 1:L:2]).abs()
+                assert gap[dp].max().item() <= 1e-5 * scale, "layer %d: a max-pool winner differs away from a tie" % i
+            total += int(dp.sum())
+    return total
+
+
 @pytest.mark.parametrize("case", P3_CASES, ids=lambda c: p3_name(*c[:4]))
 def test_p3(dev, case):
     enc, activ, ablated, T, B = case
@@ -312,7 +363,19 @@ def test_p3(dev, case):
     real_c = real.permute(0, 2, 1).contiguous()
     audio_c = aud.unsqueeze(1)
     gen.train()
+    flips = None
+    if enc == "unet":
+        # (before the forward touches the BatchNorm buffers)
+        sd0 = {k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+        acts, hooks = [], []
+        for m in gen.audio_enc.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):   # (the fused LeakyReLU is applied inside: the output's sign is the pre-activation's)
+                hooks.append(m.register_forward_hook(lambda mod, a, out: acts.append(out.detach().cpu())))
     rows = gen(sl, [T] * B, nz)
+    if enc == "unet":
+        for h in hooks:
+            h.remove()
+        flips = unet_flips(acts, sd0, sl.cpu())
     close(rows, fx["gen_train"])
     sums_close({k: v for k, v in gen.state_dict().items() if "running" in k or "tracked" in k}, fx["gen_bn_after"])
     gen.eval()
@@ -345,7 +408,17 @@ def test_p3(dev, case):
     # Observed over builds of the same arithmetic (epilogue forms, staging variants): 6e-4, 7.5e-4, 1.0e-3, 1.45e-3,
     # 3.8e-3 - discrete outcomes, not a drift. Hence 5e-3 here (the bound of the full-size generator check) and 2e-3
     # for the encoders without pooling.
-    norms_close(grad_norms(gen), fx["gen_grad_norms"], rtol=5e-3 if enc == "unet" else 2e-3, what="generator gradient norms")
+    # Round 5 (verdict item 4a): the bound now FOLLOWS the flips instead of covering them. unet_flips() compares the sign
+    # pattern of every LeakyReLU and the argmax of every max-pool of THIS forward with the same forward evaluated by the
+    # oracle in fp32 (= the reference's arithmetic, what the fixture's gradients were made with), and checks in fp64 that
+    # every element that differs sits within rounding of the kink (a wrong value would flip elements far from it). No
+    # flips: 6e-4 (the spread of summation orders); each flip adds 4e-4 of room, up to the 5e-3 of the full-size check
+    # (measured: 9 flips -> 5.1e-4 and 22 flips -> 1.25e-3 on the CPU stand-in; the HIP figures are printed in the summary).
+    if enc == "unet":
+        note(os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + " LeakyReLU / max-pool flips against the fp32 oracle (count)", flips)
+        norms_close(grad_norms(gen), fx["gen_grad_norms"], rtol=min(6e-4 + 4e-4 * flips, 5e-3), what="generator gradient norms")
+    else:
+        norms_close(grad_norms(gen), fx["gen_grad_norms"], rtol=2e-3, what="generator gradient norms")
 
 
 @pytest.mark.parametrize("case", [("default", "id", False), ("wavegan", "id", False), ("unet", "id", True)],
