@@ -46,6 +46,11 @@ int m2d_prof_dump(char* buf, int cap);
  * the best few are timed once per operand shape, on the caller's operands, and the fastest is cached.
  * Number of shapes timed so far: */
 int m2d_plan_cache_size(void);
+/* Round 5: which cost model ranks the GEMM engine's launch plans (tile height, split-K factor). 4 (default): the
+ * round-4 model; 5: chunk-step floor by tile height and up to 256 splits - faster launch by launch, slower where the
+ * streams of a loop body overlap. Process-wide; M2D_PLAN_MODEL=4|5 sets the initial value. */
+int m2d_plan_model_set(int model);
+int m2d_plan_model_get(void);
 
 /* ---- conv1d: nn.Conv1d forward and both halves of its backward -------------------------
  * reference: phase3/archis/default.py:64-70 (DefaultAudioEncoder), :90-97,216 (U-Net),

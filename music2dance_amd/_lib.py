@@ -32,6 +32,8 @@ SIGNATURES = {
     "m2d_prof_end": (_I, [_c.POINTER(_c.c_double), _I]),
     "m2d_prof_dump": (_I, [_c.c_char_p, _I]),
     "m2d_plan_cache_size": (_I, []),
+    "m2d_plan_model_set": (_I, [_I]),
+    "m2d_plan_model_get": (_I, []),
     "m2d_conv1d_fwd": (_I, [_F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _I, _f, _F, _F, _f, _F, _F, _S, _F]),
     "m2d_conv1d_bwd_data": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _f, _F, _S, _F]),
     "m2d_conv1d_pack_weights": (_I, [_F, _F, _F, _I, _I, _I, _F]),

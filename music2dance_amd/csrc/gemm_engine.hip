@@ -1595,6 +1595,18 @@ struct PlanCand {
 };
 
 #define M2D_FUSE_MAX_SPLITS 16
+// which cost model ranks the plans (m2d_plan_model_set; M2D_PLAN_MODEL overrides the default once at load): 4 = the
+// round-4 model (default: best where a loop body's streams overlap - the two-branch phase-3 critic), 5 = chunk-step floor
+// by tile height + splits up to 256 (best where launches run one after the other: phase 2, the pose-only critic)
+#include <atomic>
+static std::atomic<int> g_plan_model{[] { const char* e = getenv("M2D_PLAN_MODEL"); return (e && e[0] == '5') ? 5 : 4; }()};
+extern "C" int m2d_plan_model_set(int model) {
+  if (model != 4 && model != 5) M2D_FAIL(M2D_ERR_ARG, "m2d_plan_model_set: 4 or 5");
+  g_plan_model.store(model, std::memory_order_relaxed);
+  return M2D_OK;
+}
+extern "C" int m2d_plan_model_get(void) { return g_plan_model.load(std::memory_order_relaxed); }
+
 static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty,
                            PlanCand* out) {
   const int ph = phases > 1 ? phases : 1;
@@ -1615,8 +1627,10 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
   // TFLOP/s, the 32 -> 64 weight gradient 692 -> 653 us (profiles/r05_planmodel_shapes_diff.txt) - but the STEP, whose
   // streams overlap, gets slower: 12.00 -> 12.10 ms, five alternating pairs (profiles/r05_ab_planmodel.txt): under
   // overlap a launch that leaves CUs idle costs little (another stream's workgroups take them), while extra splits cost
-  // slab traffic and fix-up work for everybody. So the round-4 floor stays the default; M2D_PLAN_MODEL=5 selects the new one.
-  static const bool model5 = [] { const char* e = getenv("M2D_PLAN_MODEL"); return e && e[0] == '5'; }();
+  // slab traffic and fix-up work for everybody. Where nothing overlaps the launches it is the other way round: phase 2
+  // 2.199 -> 2.172 ms, the U-Net / pose-only-critic config 14.88 -> 14.72 ms. So the model is a setting
+  // (m2d_plan_model_set): the engines of a two-branch critic keep 4, the others select 5.
+  const bool model5 = g_plan_model.load(std::memory_order_relaxed) == 5;
   static const double slab_mul = [] { const char* e = getenv("M2D_SLAB_COST"); return e ? atof(e) : 1.0; }();   // A/B lever
   const double lchunk[3] = {1.50, 1.35, 1.20};
   const long long max_splits = model5 ? 256 : 128;

@@ -280,6 +280,9 @@ class Phase3Engine(WganGpEngine):
                                  and hasattr(gen, "forward_keeping_audio_path"))
         if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
             self.manual_critic = CriticStep(critic, self.gamma, lp=False)
+        if next(critic.parameters()).is_cuda and hasattr(kernels, "set_plan_model"):
+            # the pose-only critic has no second branch to overlap its launches with (kernels.set_plan_model)
+            kernels.set_plan_model(5 if self.ablated else 4)
 
     def _shapes(self, real):
         B = real.size(0)
@@ -523,6 +526,8 @@ class Phase2Engine(WganGpEngine):
         self.host_noise = True  # draw noise on the host generator (matches the CPU reference)
         if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
             self.manual_critic = CriticStep(critic, self.gamma, lp=True)
+        if next(critic.parameters()).is_cuda and hasattr(kernels, "set_plan_model"):
+            kernels.set_plan_model(5)
 
     def _noise(self, B, T, device):
         if self.host_noise:

@@ -198,6 +198,17 @@ class private_scratch:
         return False
 
 
+def set_plan_model(model):
+    """Which cost model ranks the GEMM engine's launch plans (include/m2d.h: m2d_plan_model_set): 4 where the streams of
+    a loop body overlap (two-branch phase-3 critic), 5 where launches run one after the other (phase 2, pose-only critic).
+    Process-wide; an explicit M2D_PLAN_MODEL in the environment wins. Cached workspace sizes follow the plans: dropped."""
+    if "M2D_PLAN_MODEL" in os.environ or not hasattr(_lib.lib(), "m2d_plan_model_set"):
+        return
+    if _lib.lib().m2d_plan_model_get() != int(model):
+        _lib.check(_lib.lib().m2d_plan_model_set(int(model)), "m2d_plan_model_set")
+        _WS_BYTES.clear()
+
+
 def reset_scratch():
     """Re-zero every zero-kept scratch buffer of the streams' own (not the graphs' private ones). A launch that was
     aborted mid-way (device fault, a persistent kernel's timeout) can leave arrival counters or accumulators non-zero,
