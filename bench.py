@@ -399,6 +399,10 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
+    # launch-plan cost model (kernels.set_plan_model): 5 where the loop body has no second critic branch to overlap its
+    # launches with (phase 2, the pose-only critic of configs[4]); set once, before the first launch of the process
+    if args.phase == 2 or (args.phase == 3 and args.ablated):
+        kernels.set_plan_model(5)
     if args.phase == 3:
         if args.frames != 120 and not args.ablated:
             sys.exit("the audio critic only accepts 76 800-sample (120-frame) audio: use --ablated with --frames %d"

@@ -1629,7 +1629,8 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
   // overlap a launch that leaves CUs idle costs little (another stream's workgroups take them), while extra splits cost
   // slab traffic and fix-up work for everybody. Where nothing overlaps the launches it is the other way round: phase 2
   // 2.199 -> 2.172 ms, the U-Net / pose-only-critic config 14.88 -> 14.72 ms. So the model is a setting
-  // (m2d_plan_model_set): the engines of a two-branch critic keep 4, the others select 5.
+  // (m2d_plan_model_set, once per process before its first launch): the two-branch step keeps 4, bench.py's c2 / c5 presets
+  // and the phase-2 train script select 5.
   const bool model5 = g_plan_model.load(std::memory_order_relaxed) == 5;
   static const double slab_mul = [] { const char* e = getenv("M2D_SLAB_COST"); return e ? atof(e) : 1.0; }();   // A/B lever
   const double lchunk[3] = {1.50, 1.35, 1.20};

@@ -46,7 +46,11 @@ def _capture(graph, body, dev, keep, pool=None):
     cap = torch.cuda.Stream(device=dev)
     scratch = kernels.private_scratch(dev)
     keep.append((cap, scratch))
-    with scratch, torch.cuda.graph(graph, pool=pool, stream=cap):
+    # capture_error_mode="thread_local": with the default ("global") ANY thread's HIP call that is illegal during a
+    # capture fails - and RCCL's process-group watchdog thread polls the events of pending collectives all the time: one
+    # run in five of the data-parallel graph test died with "operation not permitted when stream is capturing" raised in
+    # that thread (round 5, tests/test_gpu_dp.py looped). Only this thread captures; the others are none of its business.
+    with scratch, torch.cuda.graph(graph, pool=pool, stream=cap, capture_error_mode="thread_local"):
         return body()
 
 
@@ -280,9 +284,6 @@ class Phase3Engine(WganGpEngine):
                                  and hasattr(gen, "forward_keeping_audio_path"))
         if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
             self.manual_critic = CriticStep(critic, self.gamma, lp=False)
-        if next(critic.parameters()).is_cuda and hasattr(kernels, "set_plan_model"):
-            # the pose-only critic has no second branch to overlap its launches with (kernels.set_plan_model)
-            kernels.set_plan_model(5 if self.ablated else 4)
 
     def _shapes(self, real):
         B = real.size(0)
@@ -526,8 +527,6 @@ class Phase2Engine(WganGpEngine):
         self.host_noise = True  # draw noise on the host generator (matches the CPU reference)
         if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
             self.manual_critic = CriticStep(critic, self.gamma, lp=True)
-        if next(critic.parameters()).is_cuda and hasattr(kernels, "set_plan_model"):
-            kernels.set_plan_model(5)
 
     def _noise(self, B, T, device):
         if self.host_noise:

@@ -201,7 +201,10 @@ class private_scratch:
 def set_plan_model(model):
     """Which cost model ranks the GEMM engine's launch plans (include/m2d.h: m2d_plan_model_set): 4 where the streams of
     a loop body overlap (two-branch phase-3 critic), 5 where launches run one after the other (phase 2, pose-only critic).
-    Process-wide; an explicit M2D_PLAN_MODEL in the environment wins. Cached workspace sizes follow the plans: dropped."""
+    PROCESS-WIDE, and plans decide summation orders: a program sets it once, before its first launch (bench.py does for
+    its c2 / c5 presets, the phase-2 train script does) - the engines do not touch it (round 5: an engine that switched it
+    in its constructor changed the arithmetic of whatever ran next in the process). An explicit M2D_PLAN_MODEL in the
+    environment wins. Cached workspace sizes follow the plans: dropped."""
     if "M2D_PLAN_MODEL" in os.environ or not hasattr(_lib.lib(), "m2d_plan_model_set"):
         return
     if _lib.lib().m2d_plan_model_get() != int(model):

@@ -63,6 +63,9 @@ def main(argv=None):
                             cfg["nblocks_gen"], cfg["n_cells"], device)
     critic = SequenceDiscriminator(cfg["output_size"], cfg["channels"], stick_length, cfg["init_kernel"],
                                    cfg["nblocks_critic"], device)
+    if next(critic.parameters()).is_cuda:
+        from .. import kernels
+        kernels.set_plan_model(5)   # no second critic branch to overlap with: the launch-by-launch cost model
     engine = Phase2Engine(gen, critic, cfg, sync_bn=opts.sync_bn)
     torch.manual_seed(rank)  # identical weights (seed 0 above), rank-distinct noise / alpha draws
     engine.host_noise = False  # phase2/train.py:139-140 draws the noise on the device
