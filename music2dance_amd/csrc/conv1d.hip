@@ -552,6 +552,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     p.O.residual = residual;
     p.O.mask_last = 1;
     p.O.quad = s == 4 ? 1 : 0;  // M = 4 Cin
+    p.plan_kind = M2D_PLAN_BWD_DATA;
     // reported work: the real taps (as the polyphase form counts them), not the padded K
     for (int r = 0; r < s; ++r) {
       const int taps = r < ks ? (ks - r + s - 1) / s : 0;
@@ -576,6 +577,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
   // dx[n, ci, s*q + r - pad] = sum_{t, co} wb[ci, r + s*t, co] * dy[n, co, q - t] per output phase r:
   // K = (t, co), hi = t (taps(r) of them, resolved on the device), lo = co.
   p.bwd_data = 1;
+  p.plan_kind = stride > 1 ? M2D_PLAN_BWD_DATA : M2D_PLAN_GENERAL;
   p.phases = stride;
   p.ph_ks = ks;
   p.ph_cout = Cout;
@@ -749,6 +751,7 @@ static int conv1d_bwd_weight_impl(const float* x, const float* dy, float* dw, fl
     // positions l whose every tap l*s - pad + kk, kk in [0, ks), lies in [0, L)
     b.k_safe_lo = (pad + stride - 1) / stride;
     b.k_safe_hi = (L - ks + pad) >= 0 ? (L - ks + pad) / stride + 1 : 0;
+    p.plan_kind = M2D_PLAN_BWD_WEIGHT;
   } else {
     // short outputs (the encoders' deep layers, full-length kernels): K = (l, n), hi = position,
     // lo = sample, so no chunk is mostly padding; dy is read row-fast (lanes along co, Lout apart)
@@ -839,8 +842,9 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
   }
   // sized for the launch with the bias column (one more column), which is never smaller
   const int nch = Lout >= M2D_BK ? m2d_chunks(B, Lout) : m2d_chunks(Lout, B);
-  const size_t a = m2d_gemm_plan(Cout, Cin * ks, nch, 1, true).ws_bytes;
-  const size_t c = m2d_gemm_plan(Cout, Cin * ks + 1, nch, 1, true).ws_bytes;
+  const int kind = Lout >= M2D_BK ? M2D_PLAN_BWD_WEIGHT : M2D_PLAN_GENERAL;
+  const size_t a = m2d_gemm_plan(Cout, Cin * ks, nch, 1, true, 1.0, kind).ws_bytes;
+  const size_t c = m2d_gemm_plan(Cout, Cin * ks + 1, nch, 1, true, 1.0, kind).ws_bytes;
   return a > c ? a : c;
 }
 

@@ -144,6 +144,7 @@ struct M2dGemmParams {
   int nhi, kdiv;
   int lo_outer;        // chunk order: 0 = (hi, lo block), 1 = (lo block, hi)
   float small_tile_penalty;  // launch-plan hint (see m2d_gemm_plan); 0 = none
+  int plan_kind;             // launch family for the plan's cost model: M2D_PLAN_* (0 = the general model)
   // conv backward-data mode (bwd_data != 0): the kernel derives, per output phase
   // r = blockIdx.z of the stride-`phases` lattice, the tap count, the K extent and the
   // q-range [qmin, qmax] of output positions j = phases*q + r - ph_pad inside [0, ph_L).
@@ -176,7 +177,11 @@ struct M2dGemmPlan {
 };
 
 static inline int m2d_chunks(int nhi, int kdiv) { return nhi * ((kdiv + M2D_BK - 1) / M2D_BK); }
-M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty = 1.0);
+#define M2D_PLAN_GENERAL 0
+#define M2D_PLAN_BWD_WEIGHT 1  // K-streaming weight gradient: dy K-fast, K = (sample, position)
+#define M2D_PLAN_BWD_DATA 2    // strided backward-data (polyphase or sub-pixel form)
+M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty = 1.0,
+                          int kind = M2D_PLAN_GENERAL);
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what);
 // the same for the tap-vectorised stride-4 forward conv (p.k4_ng > 0; operands as documented at the kernel)

@@ -1607,8 +1607,39 @@ extern "C" int m2d_plan_model_set(int model) {
 }
 extern "C" int m2d_plan_model_get(void) { return g_plan_model.load(std::memory_order_relaxed); }
 
+// Round 5, the rounds model (plan kinds 1 and 2, M2D_PLAN_ROUNDS=0 switches it off): the two launch families whose
+// plans the round-4 model got wrong by 8-13 % when swept one by one (tools/plan_sweep.py, 1 900 timed (shape, plan) points
+// on MI355X, profiles/r05d_plan_sweep_*.txt) - the K-streaming weight gradients (a handful of output tiles, K = B * Lout in
+// the hundreds of thousands) and the strided backward-data launches. What the old formula lacks, in the order it matters:
+//  * workgroups run in ROUNDS: a CU holds R = 4 / 7 / 8 of the 128- / 64- / 32-row kernels (LDS, §3.1e), all workgroups of
+//    a launch have the same K range, so the first 256 R of them finish together and the rest start on an empty chip:
+//    1 200 128-row workgroups are a full round plus 176 lone ones at the lone-workgroup step (the 128 -> 256 backward-data
+//    launch: 602 us, as 2 400 64-row workgroups 535 us);
+//  * a chunk step of n co-resident workgroups costs a n + c, not max(a n, floor): two 128-row workgroups per CU (what a
+//    "512 workgroups fill the chip" plan gives) run at 2.46 us per step = 80 % of the matrix pipe, four at 4.4 us = 89 %;
+//  * splits up to 256 (7 tiles x 256 = one full round of the 64-row kernel: the 32 -> 64 weight gradient 695 -> 615 us).
+// Parameters: least squares on the sweep (rms 6 % on the weight gradients; every pick within 2 % of the measured best).
+struct RoundsModel {
+  double a[3], c[3], f[3], P, s0, s1;
+};
+static const int kRoundsResident[3] = {4, 7, 8};
+static const RoundsModel kRoundsBwdW = {{0.859, 0.467, 0.309}, {0.608, 0.343, 0.126}, {1.452, 0.961, 0.748}, 8.3, 5.4, 0.196};
+static const RoundsModel kRoundsBwdD = {{0.919, 0.419, 0.301}, {0.404, 0.468, 0.065}, {0.510, 1.307, 0.656}, 12.3, 1.2, 0.126};
+static double rounds_cost(const RoundsModel& m, int b, long long W, double cps, long long sp, int M, int N) {
+  const int R = kRoundsResident[b];
+  auto step = [&](double n) {
+    const double v = m.a[b] * n + m.c[b];
+    return v > m.f[b] ? v : m.f[b];
+  };
+  const long long full = W / (256LL * R), rem = W - full * 256LL * R;
+  double tot = (double)full * (cps * step((double)R) + m.P);
+  if (rem > 0) tot += cps * step((double)m2d_ceil_div64(rem, 256)) + m.P;
+  if (sp > 1) tot += m.s0 * (sp > 16 ? 1.0 : 0.3) + m.s1 * (double)sp * (double)M * (double)N * 4.0 / 1.0e6;
+  return 6.0 + tot;
+}
+
 static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty,
-                           PlanCand* out) {
+                           PlanCand* out, int kind = 0) {
   const int ph = phases > 1 ? phases : 1;
   const bool can_split = allow_split && phases <= 1;
   const long long nt = m2d_ceil_div(N, 128);
@@ -1634,7 +1665,9 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
   const bool model5 = g_plan_model.load(std::memory_order_relaxed) == 5;
   static const double slab_mul = [] { const char* e = getenv("M2D_SLAB_COST"); return e ? atof(e) : 1.0; }();   // A/B lever
   const double lchunk[3] = {1.50, 1.35, 1.20};
-  const long long max_splits = model5 ? 256 : 128;
+  static const bool rounds_on = [] { const char* e = getenv("M2D_PLAN_ROUNDS"); return !(e && e[0] == '0'); }();
+  const RoundsModel* rm = !rounds_on ? nullptr : kind == M2D_PLAN_BWD_WEIGHT ? &kRoundsBwdW : kind == M2D_PLAN_BWD_DATA ? &kRoundsBwdD : nullptr;
+  const long long max_splits = (model5 || rm) ? 256 : 128;
   PlanCand all[40];
   int na = 0;
   for (int b = 0; b < 3; ++b) {
@@ -1668,6 +1701,12 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
       // (the second launch is gone for splits <= 16 on a stream with tickets, m2d_splitk_fixup, but pricing the split
       // cheaper - 2 or 0 us instead of 6 - moved neither C3 nor C2: the slab term decides)
       if (sp > 1) cost += 6.0 + slab_mul * (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
+      if (rm) cost = rounds_cost(*rm, b, tiles * sp, cps, sp, M, N);
+      // weight gradients keep the tallest tile that fits M: swept alone, 64-row tiles with twice the splits are 1-3 % faster
+      // on the 64 -> 128 and 128 -> 256 layers, but they spend more CU time per flop (1.5x the LDS fill) and the step's other
+      // streams pay for it: 11.60 ms without the rounds model, 11.68 with 64-row picks, 11.52-11.56 with this rule
+      // (profiles/r05d_ab_rounds.txt)
+      if (rm && kind == M2D_PLAN_BWD_WEIGHT && bms[b] < 128 && M >= 128) cost *= 2.0;
       all[na].bm = bms[b];
       all[na].splits = (int)sp;
       all[na].cost = cost;
@@ -1687,10 +1726,20 @@ static int plan_candidates(int M, int N, int nchunks, int phases, bool allow_spl
   return n;
 }
 
+#ifdef M2D_TUNING
+// tuning builds: what the last launch was planned from and with (tools/plan_sweep.py dumps it, tools/plan_fit.py fits
+// the rounds model on the dump)
+static int g_last_plan[9];
+extern "C" int m2d_debug_last_plan(int* out) {
+  memcpy(out, g_last_plan, sizeof(g_last_plan));
+  return M2D_OK;
+}
+#endif
+
 // The model's first choice; ws_bytes covers every candidate the launcher may time.
-M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty) {
+M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_split, double small_tile_penalty, int kind) {
   PlanCand c[M2D_MAX_CAND];
-  const int n = plan_candidates(M, N, nchunks, phases, allow_split, small_tile_penalty, c);
+  const int n = plan_candidates(M, N, nchunks, phases, allow_split, small_tile_penalty, c, kind);
   M2dGemmPlan pl;
   pl.bm = n ? c[0].bm : 128;
   pl.splits = n ? c[0].splits : 1;
@@ -1901,7 +1950,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
   const int nchunks = m2d_chunks(nhi_max, p.kdiv);
   if (p.O.row_part) allow_split = false;  // the statistics come out of the tile epilogue
   PlanCand cand[M2D_MAX_CAND];
-  int nc = plan_candidates(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, allow_split, p.small_tile_penalty, cand);
+  int nc = plan_candidates(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, allow_split, p.small_tile_penalty, cand, p.plan_kind);
   {
     // a split plan needs its slabs: drop the ones the workspace cannot hold
     int k = 0;
@@ -1922,7 +1971,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
 #ifdef M2D_TUNING
   const char* forced = getenv("M2D_PLAN");
   if (forced) {
-    const M2dGemmPlan fp = m2d_gemm_plan(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, allow_split, p.small_tile_penalty);
+    const M2dGemmPlan fp = m2d_gemm_plan(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, allow_split, p.small_tile_penalty, p.plan_kind);
     bm = fp.bm;
     splits = fp.splits;
     if (splits > 1 && (!ws || ws_bytes < (size_t)splits * p.M * p.N * sizeof(float)))
@@ -1975,6 +2024,13 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
       g_plan_cache[key] = std::make_pair(bm, splits);
     }
   }
+#ifdef M2D_TUNING
+  {
+    const int lp[9] = {p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, (int)allow_split, (int)(p.small_tile_penalty * 100.f), bm, splits,
+                       p.plan_kind};
+    memcpy(g_last_plan, lp, sizeof(lp));
+  }
+#endif
   decide_fused(p, bm, splits, ws, ws_bytes, stream);
   decide_wide(p, splits, ws);
   double flops = p.work_flops > 0.0 ? p.work_flops : 2.0 * p.M * (double)p.N * p.K;
