@@ -126,14 +126,14 @@ __global__ void __launch_bounds__(256) m2d_pack_weights_kernel(const float* __re
 }
 
 // Sub-pixel image of a strided backward-data conv: wsp[(t * Cout + co) * (Cin * s) + ci * s + r] = w[co][ci][r + s * t]
-// (zero for taps >= ks): K-major, rows (ci, phase r) contiguous
+// (zero for taps >= ks): K-major, rows (ci, phase r) contiguous; phase_major: row = r * Cin + ci (m2d_gemm_dl_tall_kernel)
 __global__ void __launch_bounds__(256) m2d_pack_weights_subpixel_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                                                          int Cout, int Cin, int ks, int s, int nt) {
+                                                                          int Cout, int Cin, int ks, int s, int nt, int phase_major) {
   const size_t total = (size_t)nt * Cout * Cin * s;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int m = (int)(idx % (size_t)(Cin * s));
     const size_t k = idx / (size_t)(Cin * s);
-    const int ci = m / s, r = m - ci * s;
+    const int ci = phase_major ? m % Cin : m / s, r = phase_major ? m / Cin : m - ci * s;
     const int co = (int)(k % Cout), t = (int)(k / Cout);
     const int tap = r + s * t;
     out[idx] = tap < ks ? w[((size_t)co * Cin + ci) * ks + tap] : 0.f;
@@ -147,6 +147,13 @@ static inline bool bwd_subpixel(int Cin, int Cout, int ks, int stride) {
   static const bool on = [] { const char* e = getenv("M2D_SUBPIXEL"); return !(e && e[0] == '0'); }();
   static const int max_rows = [] { const char* e = getenv("M2D_SUBPIXEL_MAXROWS"); return e ? atoi(e) : 128; }();  // A/B lever
   return on && stride > 1 && Cin * stride <= max_rows && Cin * stride >= 64 && Cout >= 16 && ks > stride;
+}
+// ... and without the phantom taps of the last slot where the tile is exactly the four phases of 32 channels (the audio
+// critic's 32 -> 64 layer, the WaveGAN encoder's): M2D_SUBPIXEL_TALL=0 keeps the (ci, r) order
+static inline bool subpixel_tall(int Cin, int Cout, int ks, int stride) {
+  static const bool on = [] { const char* e = getenv("M2D_SUBPIXEL_TALL"); return !(e && e[0] == '0'); }();
+  const int nt = (ks + stride - 1) / stride;
+  return on && Cin == 32 && stride == 4 && ks - stride * (nt - 1) == 1 && nt >= 2;
 }
 static inline size_t subpixel_bytes(int Cout, int Cin, int ks, int stride) {
   return ((((size_t)((ks + stride - 1) / stride) * Cout * Cin * stride) * sizeof(float)) + 255) & ~(size_t)255;
@@ -486,6 +493,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
   if (bwd_subpixel(Cin, Cout, ks, stride)) {
     // dx[n, ci, s q + r - pad] = sum_{t, co} w[co, ci, r + s t] dy[n, co, q - t]: rows (ci, r), K = (t, co), columns (n, q)
     const int s = stride, nt = (ks + s - 1) / s;
+    const bool tall = subpixel_tall(Cin, Cout, ks, s) && !dy_mask;  // (a masked dy runs on the register-staging kernel)
     const size_t pb = subpixel_bytes(Cout, Cin, ks, s);
     if (!ws || ws_bytes < pb) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_bwd_data: workspace too small for the sub-pixel weights");
     {
@@ -493,7 +501,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
       unsigned blocks = (unsigned)((total + 255) / 256);
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(m2d_pack_weights_subpixel_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)ws,
-                         Cout, Cin, ks, s, nt);
+                         Cout, Cin, ks, s, nt, tall ? 1 : 0);
     }
     const float* wsp = (const float*)ws;
     ws = (char*)ws + pb;
@@ -553,6 +561,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     p.O.mask_last = 1;
     p.O.quad = s == 4 ? 1 : 0;  // M = 4 Cin
     p.plan_kind = M2D_PLAN_BWD_DATA;
+    p.tall_last_rb = tall ? ks - s * (nt - 1) : 0;
     // reported work: the real taps (as the polyphase form counts them), not the padded K
     for (int r = 0; r < s; ++r) {
       const int taps = r < ks ? (ks - r + s - 1) / s : 0;

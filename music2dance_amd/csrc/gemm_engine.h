@@ -145,6 +145,8 @@ struct M2dGemmParams {
   int lo_outer;        // chunk order: 0 = (hi, lo block), 1 = (lo block, hi)
   float small_tile_penalty;  // launch-plan hint (see m2d_gemm_plan); 0 = none
   int plan_kind;             // launch family for the plan's cost model: M2D_PLAN_* (0 = the general model)
+  int tall_last_rb;          // > 0: phase-major sub-pixel backward-data (m2d_gemm_dl_tall_kernel): rows 32 r + ci, the last
+                             // tap slot exists for the first tall_last_rb phases only (1 for k25 / stride 4)
   // conv backward-data mode (bwd_data != 0): the kernel derives, per output phase
   // r = blockIdx.z of the stride-`phases` lattice, the tap count, the K extent and the
   // q-range [qmin, qmax] of output positions j = phases*q + r - ph_pad inside [0, ph_L).

@@ -1196,6 +1196,166 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 8 : 2) m2d_gemm_dl_kernel(c
   M2D_STAMP_AT(3);
 }
 
+// ---- sub-pixel backward-data without phantom taps (O.quad == 2, p.tall_last_rb) -------------------------------------
+// The sub-pixel form of a stride-4 k25 backward-data has 7 tap slots per phase and 25 taps: slot 6 exists for phase 0
+// only, so with rows (ci, r) 3 of every 4 rows of the slot-6 chunks multiply zeros - a seventh of K at a quarter of
+// the work, 10.7 % of the launch's MFMAs (DESIGN.md 3.1d "what is left" (2)). Here the 128 rows of the tile are ordered
+// phase-major, row = 32 r + ci: the four 32-row MFMA blocks ARE the four phases, and a slot-6 chunk issues the MFMAs of
+// block 0 only. For that every wave owns all four row blocks of 32 columns (TM = 4, TN = 1 instead of 2 x 2: five
+// fragment reads per four MFMAs instead of four) - and then register i of the four accumulators of a lane is one
+// (ci, position) at r = 0..3: the 16-byte store of the quad epilogue comes straight out of the registers.
+// K order (lo_outer): co block outer, tap slot inner - a slot-6 chunk every nhi chunks; two inner loops (a wave-uniform
+// branch around the MFMAs would keep every accumulator live across it: 700 spilled registers in the k4 kernel's first form).
+template <int RB>
+__device__ __forceinline__ void m2d_chunk_mma_tall(const float* stage, int wn, int l31, int lh, f32x16 (&acc)[4]) {
+  const float* as = stage + l31;
+  const float* bs = stage + M2D_BK * 128 + wn * 32 + l31;
+  float fa[M2D_BK / 2][RB], fb[M2D_BK / 2];
+#pragma unroll
+  for (int kk = 0; kk < M2D_BK / 2; ++kk) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) fa[kk][i] = as[(2 * kk + lh) * 128 + i * 32];
+    fb[kk] = bs[(2 * kk + lh) * 128];
+  }
+#pragma unroll
+  for (int kk = 0; kk < M2D_BK / 2; ++kk)
+#pragma unroll
+    for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk], acc[i], 0, 0, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, RB + 1, 0);
+#pragma unroll
+  for (int kk = 0; kk < M2D_BK / 2; ++kk) {
+    __builtin_amdgcn_sched_group_barrier(0x008, RB, 0);
+    if (kk < M2D_BK / 2 - 2) __builtin_amdgcn_sched_group_barrier(0x100, RB > 1 ? 3 : 2, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) m2d_gemm_dl_tall_kernel(const M2dGemmParams p) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int STAGE = M2D_BK * (BM + BN);
+  __shared__ float smem[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = tid >> 6;
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+  M2D_STAMP_AT(0);
+  const M2dOperand& A = p.A;
+  const M2dOperand& B = p.B;
+  const M2dOutMap& O = p.O;
+  const int N = p.N;
+  int bx, by;
+  m2d_tile_of(p.tile_map, bx, by);
+  const int m0 = by * BM;
+  const int n0 = bx * BN;
+  TileMap<false, BM, false, 256> ta;
+  TileMap<false, BN, false, 256> tb;
+  ta.prep_dl(A, m0, tid);
+  tb.prep_dl(B, n0, tid);
+  const __amdgpu_buffer_rsrc_t ra = m2d_rsrc(A.base, A.nbytes);
+  const __amdgpu_buffer_rsrc_t rb = m2d_rsrc(B.base, B.nbytes);
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int nhi = p.nhi;
+  const int cph = (p.kdiv + M2D_BK - 1) / M2D_BK;   // co blocks
+  ChunkCursor cc;
+  cc.kdiv = p.kdiv;
+  cc.nhi = nhi;
+  cc.lo_outer = 1;
+  cc.seek(0, cph);
+  cc.a_lo = A.k_safe_lo; cc.a_hi = A.k_safe_hi;
+  cc.b_lo = B.k_safe_lo; cc.b_hi = B.k_safe_hi;
+  ta.template load_lds<false, BM>(A, ra, cc.hi, cc.lo0, cc.extent(), smem, tid);
+  tb.template load_lds<false, BN>(B, rb, cc.hi, cc.lo0, cc.extent(), smem + M2D_BK * BM, tid);
+  cc.next();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  M2D_STAMP_AT(1);
+  int cur = 0;
+  // the chunk after the one being multiplied streams into the other stage (the chunk after the last one loads zeros)
+  auto stage_next = [&]() {
+    float* nxt = smem + (cur ^ 1) * STAGE;
+    if (cc.uniform()) {
+      ta.template load_lds<true, BM>(A, ra, cc.hi, cc.lo0, cc.kdiv, nxt, tid);
+      tb.template load_lds<true, BN>(B, rb, cc.hi, cc.lo0, cc.kdiv, nxt + M2D_BK * BM, tid);
+    } else {
+      ta.template load_lds<false, BM>(A, ra, cc.hi, cc.lo0, cc.extent(), nxt, tid);
+      tb.template load_lds<false, BN>(B, rb, cc.hi, cc.lo0, cc.extent(), nxt + M2D_BK * BM, tid);
+    }
+  };
+  auto step_done = [&]() {
+    cc.next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  };
+  for (int blk = 0; blk < cph; ++blk) {
+    for (int t = 0; t < nhi - 1; ++t) {   // slots every phase has
+      stage_next();
+      m2d_chunk_mma_tall<4>(smem + cur * STAGE, wn, l31, lh, acc);
+      step_done();
+    }
+    stage_next();                          // the last slot: phase 0 only
+    m2d_chunk_mma_tall<1>(smem + cur * STAGE, wn, l31, lh, acc);
+    step_done();
+  }
+  M2D_STAMP_AT(2);
+  // epilogue: register g of the four accumulators = (ci, position) at r = 0..3
+  {
+    const int col = n0 + wn * 32 + l31;
+    if (col < N) {
+      int chi, clo;
+      m2d_divmod(col, O.cdiv, O.cdiv_inv, chi, clo);
+      const int caddr = chi * O.c_hi_stride + clo * O.c_lo_stride + O.c_off;
+      const int pos = clo * O.c_pos_mul + O.c_pos_off;
+      const bool whole = pos >= 0 && pos + 3 < O.c_lim;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int ci = (m0 >> 2) + (g & 3) + 8 * (g >> 2) + 4 * lh;
+        const int addr = ci * O.m_stride + caddr;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[e][g];
+        if (whole) {
+          // (signed: a quad that starts left of the row - addr < 0 for the first positions of sample 0 - must not wrap)
+          const int maddr = (O.mask_wrap && addr >= (int)O.mask_wrap) ? addr - (int)O.mask_wrap : addr;
+          if (O.residual) {
+            const m2d_f32x4u rr = *reinterpret_cast<const m2d_f32x4u*>(O.residual + addr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+          }
+          if (O.mask) {
+            const m2d_f32x4u mm = *reinterpret_cast<const m2d_f32x4u*>(O.mask + maddr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= (mm[e] > 0.f ? 1.f : O.mask_slope);
+          }
+          m2d_f32x4u o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = v[e];
+          *reinterpret_cast<m2d_f32x4u*>(O.out + addr) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if ((unsigned)(pos + e) >= (unsigned)O.c_lim) continue;
+            float x = v[e];
+            const int me = (O.mask_wrap && addr + e >= (int)O.mask_wrap) ? addr + e - (int)O.mask_wrap : addr + e;
+            if (O.residual) x += O.residual[addr + e];
+            if (O.mask) x *= (O.mask[me] > 0.f ? 1.f : O.mask_slope);
+            O.out[addr + e] = x;
+          }
+        }
+      }
+    }
+  }
+#ifdef M2D_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  M2D_STAMP_AT(3);
+}
+
 // LDS byte address of a pointer into a __shared__ array, and a 16-byte LDS read the compiler does not see as a memory
 // access (see m2d_conv_k4_kernel)
 typedef float m2d_f32x4 __attribute__((ext_vector_type(4)));
@@ -1797,6 +1957,10 @@ static int launch_maps(const M2dGemmParams& p, bool akf, bool bkf, dim3 grid, hi
   {
     if (dl_enabled() && dl_eligible(p, akf, bkf)) {
       if constexpr (BM == 128) {
+        if (p.tall_last_rb) {
+          hipLaunchKernelGGL(m2d_gemm_dl_tall_kernel, grid, dim3(256), 0, stream, p);
+          return 0;
+        }
         // eight waves per workgroup on the same tile (M2dTiling); the one-element epilogue does not fit the 64 VGPRs of
         // eight waves per SIMD without scratch: those launches (strided backward-data) keep four waves
         if (dl8_enabled() && (p.O.wide || (p.O.quad && p.splits <= 1))) {
@@ -2023,6 +2187,13 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
       lk.lock();
       g_plan_cache[key] = std::make_pair(bm, splits);
     }
+  }
+  if (p.tall_last_rb) {  // the phase-major sub-pixel launch: whole 128-row tiles, whole K
+    if (p.tall_last_rb != 1 || p.M % 128 != 0 || !p.lo_outer || p.O.bias_mode || p.O.act || !p.O.mask_last || !dl_enabled() ||
+        !dl_eligible(p, a_kfast, b_kfast))
+      M2D_FAIL(M2D_ERR_ARG, "%s: bad phase-major sub-pixel launch", what);
+    bm = 128;
+    splits = 1;
   }
 #ifdef M2D_TUNING
   {

@@ -348,6 +348,13 @@ class Phase3Engine(WganGpEngine):
             with ops.no_input_grad_for(audio_c):
                 err_critic.backward()
             audio_c.requires_grad_(False)
+            if getattr(self.critic, "_stick_stream", None) is not None:
+                # the pose branch's gradients were allocated on the critic's side stream; the optimizer reads them on
+                # this one (autograd has made it wait for them, but the allocator does not know about the read)
+                cur = torch.cuda.current_stream(real.device)
+                for p in self.critic.stick_d.parameters():
+                    if p.grad is not None:
+                        p.grad.record_stream(cur)
         return {"loss_critic": err_critic.detach(), "gp": gp.detach(), "w_dist": (err_fake - err_real).detach()}
 
     def generator_iteration(self, real, audio, audio_slices):

@@ -18,11 +18,18 @@ _COPY_STREAMS = {}
 
 
 def copy_stream(device):
-    """The per-device stream host -> device staging runs on."""
+    """The per-device stream host -> device staging runs on. It comes from torch's HIGH-priority stream pool, where
+    nothing else of this package allocates: torch hands out its 32 pooled streams per priority round-robin, so the 33rd
+    `torch.cuda.Stream()` of a process IS the first one again - same queue, same caching-allocator pool. A copy from
+    pageable memory is written by the HOST once ITS stream has drained, i.e. it is not ordered against readers on other
+    streams: with the copy stream aliasing a module's side stream, a gradient allocated on that side stream, read on the
+    main stream (optimizer / clone) and freed could be handed to the next staging copy and overwritten while the main
+    stream's read was still queued (seen in the test suite, which builds dozens of engines per process: the first 32
+    entries of a pose-branch bias gradient held the next batch's interpolation weights)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     cs = _COPY_STREAMS.get(idx)
     if cs is None:
-        cs = _COPY_STREAMS[idx] = torch.cuda.Stream(device=device)
+        cs = _COPY_STREAMS[idx] = torch.cuda.Stream(device=device, priority=-1)
     return cs
 
 

@@ -115,7 +115,12 @@ def _critic_loss_grads(critic, x_real, x_fake, audio, alpha):
                 loss.backward()
     finally:
         L.torch.rand = orig
-    return loss.detach(), [p.grad.detach().clone() for p in critic.parameters()]
+    grads = [p.grad.detach().clone() for p in critic.parameters()]
+    # the pose branch's gradients were allocated on the critic's side stream and the clones read them on this one: keep
+    # the originals until the clones have run (the next call's zero_grad(set_to_none=True) returns them to the side
+    # stream's pool, where a host-written staging copy could land before this stream got to the clone)
+    torch.cuda.current_stream().synchronize()
+    return loss.detach(), grads
 
 
 def test_critic_gradient_shard_identity(models, batch):
@@ -133,12 +138,29 @@ def test_critic_gradient_shard_identity(models, batch):
     l2, g2 = _critic_loss_grads(critic, x_real[h:].contiguous(), x_fake[h:].contiguous(), a[h:].contiguous(), alpha[h:])
     assert abs(loss.item() - 0.5 * (l1.item() + l2.item())) < 1e-4 * max(1.0, abs(loss.item()))
     worst = 0.0
-    for f, p, q in zip(full, g1, g2):
-        worst = max(worst, rel_l2(f, 0.5 * (p + q)))
+    report = []
+    for (name, _), f, p, q in zip(critic.named_parameters(), full, g1, g2):
+        e = rel_l2(f, 0.5 * (p + q))
+        worst = max(worst, e)
+        report.append("%s %.2e" % (name, e))
     flat_full = torch.cat([f.reshape(-1) for f in full])
     flat_mean = torch.cat([(0.5 * (p + q)).reshape(-1) for p, q in zip(g1, g2)])
-    assert rel_l2(flat_full, flat_mean) < 1e-3  # the whole gradient
-    assert worst < 1e-2, worst                   # every tensor (small audio-branch biases see single flips)
+    whole = rel_l2(flat_full, flat_mean)
+    if whole >= 1e-3 or worst >= 1e-2:
+        # which of the three passes is off? (each is deterministic: a second evaluation must reproduce it bit for bit)
+        again = [_critic_loss_grads(critic, x_real, x_fake, a, alpha)[1],
+                 _critic_loss_grads(critic, x_real[:h].contiguous(), x_fake[:h].contiguous(), a[:h].contiguous(), alpha[:h])[1],
+                 _critic_loss_grads(critic, x_real[h:].contiguous(), x_fake[h:].contiguous(), a[h:].contiguous(), alpha[h:])[1]]
+        for tag, first, second in zip(("full", "half 1", "half 2"), (full, g1, g2), again):
+            for (name, _), u, v in zip(critic.named_parameters(), first, second):
+                if not torch.equal(u, v):
+                    idx = (u != v).reshape(-1).nonzero().reshape(-1)
+                    report.append("NOT REPRODUCED %s %s: %.2e; %d of %d elements differ, first at %s: first pass %s, second pass %s" % (
+                        tag, name, rel_l2(u, v), idx.numel(), u.numel(), idx[:6].tolist(),
+                        u.reshape(-1)[idx[:6]].tolist(), v.reshape(-1)[idx[:6]].tolist()))
+        print("shard identity report:\n  " + "\n  ".join(report))
+    assert whole < 1e-3, (whole, report)  # the whole gradient
+    assert worst < 1e-2, (worst, report)  # every tensor (small audio-branch biases see single flips)
 
 
 def test_generator_eval_shard_identity(models, batch):

@@ -96,6 +96,19 @@ def test_register_staged_kernels_keep_their_budgets(engine, name):
     assert st["mfma"] == mfma, st
 
 
+def test_phase_major_sub_pixel_kernel_keeps_its_budget_and_skips_the_phantom_blocks(engine):
+    """m2d_gemm_dl_tall_kernel: four workgroups per CU (<= 128 VGPRs, 32 KB), no scratch, and per co block 32 MFMAs per
+    wave for a tap slot every phase has + 8 for the last slot (phase 0 only): the hot loop is the co-block loop, whose
+    body holds one inner loop of full chunks (32 MFMAs) and the one partial chunk (8)."""
+    co, tab = engine
+    full, row = _find(tab, "m2d_gemm_dl_tall_kernel")
+    assert row["vgpr"] <= 96 and row["lds"] == 32768, (full, row)
+    assert row["scratch"] == 0 and row["vgpr_spill"] == 0, (full, row)
+    st = _loop(co, row)
+    assert st["mfma"] == 40, st
+    assert st["ds_write"] == 0 and st["lds_dma"] > 0 and st["scratch_ops"] == 0, st
+
+
 def test_tap_vectorised_forward_keeps_its_budget(engine):
     co, tab = engine
     for name, vg in (("m2d_conv_k4_kernel<128, 128, true>", 96), ("m2d_conv_k4_kernel<64, 128, true>", 72)):
