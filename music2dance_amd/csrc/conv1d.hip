@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(256) m2d_pack_weights_subpixel_kernel(const fl
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int m = (int)(idx % (size_t)(Cin * s));
     const size_t k = idx / (size_t)(Cin * s);
-    const int ci = phase_major ? m % Cin : m / s, r = phase_major ? m / Cin : m - ci * s;
+    // phase-major: tiles of 128 rows = 32 channels x s phases, row = 128 tile + 32 r + (ci % 32)
+    const int ci = phase_major ? (m / (32 * s)) * 32 + m % 32 : m / s, r = phase_major ? (m % (32 * s)) / 32 : m - ci * s;
     const int co = (int)(k % Cout), t = (int)(k / Cout);
     const int tap = r + s * t;
     out[idx] = tap < ks ? w[((size_t)co * Cin + ci) * ks + tap] : 0.f;
@@ -143,9 +144,12 @@ __global__ void __launch_bounds__(256) m2d_pack_weights_subpixel_kernel(const fl
 // Strided backward-data in its sub-pixel form when the layer has few input channels: rows (ci, phase), one GEMM for all
 // phases (M = Cin * s instead of s GEMMs with M = Cin). Measured need: the 32-channel audio layer ran 32-row tiles at
 // 67 TFLOP/s, the worst large launch of the step. Cost: ceil(ks / s) * s tap slots instead of ks (k25 / s4: 28, + 12 %).
-static inline bool bwd_subpixel(int Cin, int Cout, int ks, int stride) {
+static inline bool subpixel_tall(int Cin, int Cout, int ks, int stride);
+static inline bool bwd_subpixel(int Cin, int Cout, int ks, int stride, bool masked_dy = false) {
   static const bool on = [] { const char* e = getenv("M2D_SUBPIXEL"); return !(e && e[0] == '0'); }();
   static const int max_rows = [] { const char* e = getenv("M2D_SUBPIXEL_MAXROWS"); return e ? atoi(e) : 128; }();  // A/B lever
+  static const int tall_max_cin = [] { const char* e = getenv("M2D_SUBPIXEL_TALL_MAXCIN"); return e ? atoi(e) : 64; }();  // A/B lever (measured: 64 -> 128 layer 658 -> 587 us, the 128- and 256-channel layers lose 7 - 12 %)
+  if (on && !masked_dy && Cin > 32 && Cin <= tall_max_cin && subpixel_tall(Cin, Cout, ks, stride)) return true;
   return on && stride > 1 && Cin * stride <= max_rows && Cin * stride >= 64 && Cout >= 16 && ks > stride;
 }
 // ... and without the phantom taps of the last slot where the tile is exactly the four phases of 32 channels (the audio
@@ -153,7 +157,7 @@ static inline bool bwd_subpixel(int Cin, int Cout, int ks, int stride) {
 static inline bool subpixel_tall(int Cin, int Cout, int ks, int stride) {
   static const bool on = [] { const char* e = getenv("M2D_SUBPIXEL_TALL"); return !(e && e[0] == '0'); }();
   const int nt = (ks + stride - 1) / stride;
-  return on && Cin == 32 && stride == 4 && ks - stride * (nt - 1) == 1 && nt >= 2;
+  return on && Cin % 32 == 0 && stride == 4 && ks - stride * (nt - 1) == 1 && nt >= 2;
 }
 static inline size_t subpixel_bytes(int Cout, int Cin, int ks, int stride) {
   return ((((size_t)((ks + stride - 1) / stride) * Cout * Cin * stride) * sizeof(float)) + 255) & ~(size_t)255;
@@ -490,7 +494,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     p.O.mask_last = 1;
     return m2d_gemm_launch(p, true, false, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_bwd_data");
   }
-  if (bwd_subpixel(Cin, Cout, ks, stride)) {
+  if (bwd_subpixel(Cin, Cout, ks, stride, dy_mask != nullptr)) {
     // dx[n, ci, s q + r - pad] = sum_{t, co} w[co, ci, r + s t] dy[n, co, q - t]: rows (ci, r), K = (t, co), columns (n, q)
     const int s = stride, nt = (ks + s - 1) / s;
     const bool tall = subpixel_tall(Cin, Cout, ks, s) && !dy_mask;  // (a masked dy runs on the register-staging kernel)

@@ -8,8 +8,8 @@ if len(sys.argv) > 1:
     K = kernels.impl()
     dev = "cuda:0"
     torch.manual_seed(0)
-    for b in (64, 128):
-        cin, L, cout, ks, s, p = 32, 19200, 64, 25, 4, 11
+    for b, cin, L, cout in ((64, 32, 19200, 64), (128, 32, 19200, 64), (128, 64, 4800, 128), (128, 128, 1200, 256), (128, 256, 300, 512)):
+        ks, s, p = 25, 4, 11
         Lout = (L + 2 * p - ks) // s + 1
         w = torch.randn(cout, cin, ks, device=dev) / 28.0
         dy = torch.randn(b, cout, Lout, device=dev)
@@ -29,8 +29,8 @@ if len(sys.argv) > 1:
         ref = ref * (mm > 0).double()
         err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
         gf = 2.0 * b * Lout * cout * cin * ks / 1e6  # MFLOP: / us = TFLOP/s
-        print("rows %3d  %7.1f us  %6.1f TF   max rel err %.2e" % (b, us, gf / us, err))
+        print("Cin %3d rows %3d  %7.1f us  %6.1f TF   max rel err %.2e" % (cin, b, us, gf / us, err))
 else:
-    for v in ("0", "1", "0", "1"):
-        print("== M2D_SUBPIXEL_TALL=" + v, flush=True)
-        subprocess.run([sys.executable, __file__, "run"], env=dict(os.environ, M2D_SUBPIXEL_TALL=v))
+    for v, mc in (("0", "32"), ("1", "32"), ("1", "256"), ("0", "32"), ("1", "32"), ("1", "256")):
+        print("== M2D_SUBPIXEL_TALL=%s M2D_SUBPIXEL_TALL_MAXCIN=%s" % (v, mc), flush=True)
+        subprocess.run([sys.executable, __file__, "run"], env=dict(os.environ, M2D_SUBPIXEL_TALL=v, M2D_SUBPIXEL_TALL_MAXCIN=mc))
