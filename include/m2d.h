@@ -182,6 +182,10 @@ size_t m2d_gemm_workspace_bytes(int mode, int M, int N, int K);
  * 4 bytes per output tile (64 KB covers every shape of the reference). zeroed == NULL unregisters. Launches of one
  * stream run in order, so streams must not share a buffer. Without it: the two-launch form, no state between calls. */
 int m2d_stream_scratch_set(void* stream, void* zeroed, size_t bytes);
+/* A HIP stream of the library's own (hipStreamCreateWithFlags, non-blocking), never destroyed: the host side wraps it
+ * (torch.cuda.ExternalStream) for its host -> device staging copies - a stream that no framework stream pool can hand out
+ * a second time (no reference counterpart: launch plumbing). */
+int m2d_stream_create(void** stream);
 
 /* ---- BatchNorm1d (train/eval forward, train backward) + per-channel sums -----------------
  * reference: phase3/archis/default.py:65,68,91,94,118-127,154,179-180,217. */

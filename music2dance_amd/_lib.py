@@ -60,6 +60,7 @@ SIGNATURES = {
     "m2d_gemm_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "m2d_bn_workspace_bytes": (_S, [_I]),
     "m2d_stream_scratch_set": (_I, [_F, _F, _S]),
+    "m2d_stream_create": (_I, [ctypes.POINTER(ctypes.c_void_p)]),
     "m2d_bn_scratch_bytes": (_S, [_I]),
     "m2d_bn_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _I, _f, _F, _F, _S, _F, _F]),
     "m2d_bn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _F, _S, _F, _F]),

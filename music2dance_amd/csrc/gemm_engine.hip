@@ -2002,6 +2002,14 @@ unsigned* m2d_stream_scratch_get(hipStream_t stream, size_t* bytes) {
   return it->second.first;
 }
 
+extern "C" int m2d_stream_create(void** stream) {
+  if (!stream) M2D_FAIL(M2D_ERR_ARG, "m2d_stream_create: null argument");
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) M2D_FAIL(M2D_ERR_HIP, "m2d_stream_create: hipStreamCreateWithFlags failed");
+  *stream = (void*)s;
+  return M2D_OK;
+}
+
 extern "C" int m2d_stream_scratch_set(void* stream, void* zeroed, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   if (!zeroed || bytes == 0) g_scratch.erase((hipStream_t)stream);

@@ -18,18 +18,25 @@ _COPY_STREAMS = {}
 
 
 def copy_stream(device):
-    """The per-device stream host -> device staging runs on. It comes from torch's HIGH-priority stream pool, where
-    nothing else of this package allocates: torch hands out its 32 pooled streams per priority round-robin, so the 33rd
-    `torch.cuda.Stream()` of a process IS the first one again - same queue, same caching-allocator pool. A copy from
-    pageable memory is written by the HOST once ITS stream has drained, i.e. it is not ordered against readers on other
-    streams: with the copy stream aliasing a module's side stream, a gradient allocated on that side stream, read on the
-    main stream (optimizer / clone) and freed could be handed to the next staging copy and overwritten while the main
-    stream's read was still queued (seen in the test suite, which builds dozens of engines per process: the first 32
-    entries of a pose-branch bias gradient held the next batch's interpolation weights)."""
+    """The per-device stream host -> device staging runs on: a HIP stream of the library's own (m2d_stream_create),
+    wrapped as a torch ExternalStream - NOT one of torch's pooled streams. torch hands out its 32 pooled streams per
+    priority round-robin, so the 33rd `torch.cuda.Stream()` of a process IS the first one again: same queue, same
+    caching-allocator pool. A copy from pageable memory is written by the HOST once ITS stream has drained, i.e. it is not
+    ordered against readers on other streams; with the copy stream aliasing a module's side stream, a gradient allocated on
+    that side stream, read on the main stream (optimizer / clone) and freed could be handed to the next staging copy and
+    overwritten while the main stream's read was still queued (seen in the test suite, which builds dozens of engines per
+    process: the first 32 entries of a pose-branch bias gradient held the next batch's interpolation weights).
+    (A pooled HIGH-priority stream avoids the aliasing too, but costs the phase-3 step 2 ms: 11.35 -> 13.49 per body.)"""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     cs = _COPY_STREAMS.get(idx)
     if cs is None:
-        cs = _COPY_STREAMS[idx] = torch.cuda.Stream(device=device, priority=-1)
+        import ctypes
+
+        from . import _lib
+        raw = ctypes.c_void_p()
+        with torch.cuda.device(idx):
+            _lib.check(_lib.lib().m2d_stream_create(ctypes.byref(raw)), "m2d_stream_create")
+        cs = _COPY_STREAMS[idx] = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
     return cs
 
 
