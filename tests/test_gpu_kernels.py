@@ -914,3 +914,35 @@ def test_backward_data_with_a_shared_mask_equals_the_repeated_mask(cin, cout, ks
             want = k.conv1d_bwd_data(dy, w, L, s, p, out_mask=full, out_mask_slope=slope)
             got = k.conv1d_bwd_data(dy, w, L, s, p, out_mask=mask, out_mask_slope=slope)
         assert torch.equal(got, want), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("cin,cout,L", [(32, 64, 384), (32, 64, 19200), (64, 128, 4800), (64, 48, 260)])
+@pytest.mark.parametrize("B", [3, 64])
+def test_phase_major_sub_pixel_backward_data(cin, cout, L, B):
+    """m2d_gemm_dl_tall_kernel (round 5): the k25 / stride-4 backward-data of a 32- or 64-channel layer in its phase-major
+    sub-pixel form, the last tap slot multiplied for phase 0 only - against fp64 autograd, against the form it replaces (a
+    dy mask of ones sends the same problem through the register-staging kernel with the (ci, r) / polyphase layout), with
+    an output mask, a residual and ragged row ends (L = 260: the last quad of a row hangs over its end)."""
+    if B == 64 and L > 4800:
+        pytest.skip("the full-length case at B = 3 only")
+    k = K()
+    ks, s, p = 25, 4, 11
+    g = torch.Generator().manual_seed(11)
+    Lout = (L + 2 * p - ks) // s + 1
+    dy = torch.randn(B, cout, Lout, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, ks, generator=g) / math.sqrt(cin * ks)).to(DEV)
+    mask = torch.randn(B, cin, L, generator=g).to(DEV)
+    res = torch.randn(B, cin, L, generator=g).to(DEV)
+    ref = torch.nn.grad.conv1d_input((B, cin, L), w.double(), dy.double(), stride=s, padding=p)
+    with k.weight_cache():
+        got = k.conv1d_bwd_data(dy, w, L, s, p)
+        old = k.conv1d_bwd_data(dy, w, L, s, p, dy_mask=torch.ones_like(dy), dy_mask_slope=0.0)
+        got_m = k.conv1d_bwd_data(dy, w, L, s, p, out_mask=mask, out_mask_slope=0.2)
+        got_r = k.conv1d_bwd_data(dy, w, L, s, p, out_mask=mask, out_mask_slope=0.0, residual=res)
+    scale = ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() < 2e-6 * scale
+    assert (got - old).abs().max().item() < 2e-6 * scale
+    m02 = torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, 0.2)).double()
+    assert (got_m.double() - ref * m02).abs().max().item() < 2e-6 * scale
+    want_r = (ref + res.double()) * (mask > 0).double()
+    assert (got_r.double() - want_r).abs().max().item() < 2e-6 * max(scale, want_r.abs().max().item())
