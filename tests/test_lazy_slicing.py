@@ -44,10 +44,17 @@ def test_generator_reads_windows_in_place(enc):
         rows.square().mean().backward()
         outs.append(rows.detach().clone())
         grads.append([p.grad.clone() for p in gen.parameters() if p.grad is not None])
-    assert torch.equal(outs[0], outs[1])
+    # Same kernels on the same values either way; the per-channel sums behind the BatchNorm statistics and the encoder's
+    # bias gradients end in fp64 atomics whose order is not fixed, so a sum can differ in its last fp64 bits and - once in
+    # a few hundred runs of this test, seen on cold boxes - round to the neighbouring fp32 value: equal to a few ulps, and
+    # bit-equal everywhere else.
+    def close(a, b):
+        return torch.equal(a, b) or (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-30)
+    assert close(outs[0], outs[1]), (outs[0] - outs[1]).abs().max()
     assert len(grads[0]) == len(grads[1])
-    for a, b in zip(*grads):
-        assert torch.equal(a, b)
+    names = [n for n, p in gen.named_parameters() if p.grad is not None]
+    off = [(n, (a - b).abs().max().item(), b.abs().max().item()) for n, a, b in zip(names, *grads) if not close(a, b)]
+    assert not off, off
 
 
 def test_draw_tape_replays_the_eager_host_draws_in_order():
