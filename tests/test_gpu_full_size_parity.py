@@ -45,11 +45,16 @@ def _close(name, got, want, atol, rtol=0.0):
     assert err <= bound, "%s: max abs err %.3e > %.3e" % (name, err, bound)
 
 
-def _norms_close(tag, module, ref_grads, rtol=2e-3, floor=2e-5, ertol=2e-3, hard=3e-2):
+WORST = {}  # printed by tests/conftest.py with every run
+
+
+def _norms_close(tag, module, ref_grads, rtol=2e-3, floor=2e-5, ertol=2e-3, hard=3e-2, record=None):
     """ref_grads: {state_dict key: gradient tensor} from the oracle (absent = no gradient). Per tensor, ALL of
       * the L2 norm within `rtol`;
       * element-wise, relative to the tensor's largest element m = max |g_ref|: no element off by more than
-        `hard` * m, and at most max(2, 2 % of the elements) off by more than `ertol` * m. A permuted, shifted or
+        `hard` * m, and at most max(2, 0.2 % of the elements) off by more than `ertol` * m (round 5: was 2 %, which tensors
+        of fewer than 1 000 elements keep - 3 of a 256-element BatchNorm weight is 1.2 %; the worst large tensor of the
+        three full-size cases has 0.035 % - the run prints the figure). A permuted, shifted or
         sign-flipped gradient of the right size passes a norm check; it cannot pass this one.
     Why not simply every element within ertol: two fp32 evaluations of a ReLU net do not share all activation
     masks. A pre-activation within rounding of zero (a handful per layer among the 3 M of a B = 64 pose branch) is
@@ -63,7 +68,7 @@ def _norms_close(tag, module, ref_grads, rtol=2e-3, floor=2e-5, ertol=2e-3, hard
     module's - moves by 3e-3 of the module's largest element)."""
     gmax = max([g.double().norm().item() for g in ref_grads.values() if g is not None] + [1e-30])
     emax = max([g.double().abs().max().item() for g in ref_grads.values() if g is not None] + [1e-30])
-    worst, worst_e = 0.0, 0.0
+    worst, worst_e, worst_frac = 0.0, 0.0, 0.0
     for name, p in module.named_parameters():
         rg = ref_grads.get(name)
         if rg is None:
@@ -83,8 +88,14 @@ def _norms_close(tag, module, ref_grads, rtol=2e-3, floor=2e-5, ertol=2e-3, hard
         assert err <= hard * scale + 250 * floor * emax, \
             "%s.%s: max |grad - oracle| %.3e > %.1e x max |oracle| %.3e" % (tag, name, err, hard, scale)
         n_off = int((diff > ertol * scale + 25 * floor * emax).sum())
-        assert n_off <= max(2, int(0.02 * diff.numel())), \
+        assert n_off <= max(2, int((0.002 if diff.numel() >= 1000 else 0.02) * diff.numel())), \
             "%s.%s: %d of %d elements off by more than %.1e x max |oracle|" % (tag, name, n_off, diff.numel(), ertol)
+        if diff.numel() >= 1000:  # (a fraction of a 100-element bias is not a fraction)
+            worst_frac = max(worst_frac, n_off / diff.numel())
+    if record:
+        WORST["%s %s: per-tensor gradient norm (worst relative error)" % (record, tag)] = worst
+        WORST["%s %s: gradient element (worst error relative to the tensor's largest)" % (record, tag)] = worst_e
+        WORST["%s %s: share of a tensor's elements beyond %.0e x its largest (worst tensor; bound 2e-3)" % (record, tag, ertol)] = worst_frac
     return worst, worst_e
 
 
@@ -153,10 +164,10 @@ def test_phase3_iteration_matches_oracle_at_full_size(enc, B, T, ablated):
     real_d, audio_d, slices_d = real.to(dev), audio.to(dev), slices.to(dev)
     with kernels.impl().weight_cache():
         out_c = eng._critic_body(real_d, audio_d, slices_d, noise_c.to(dev), alpha.to(dev), True)
-        d_norm_worst = _norms_close("critic", critic, o_dgrads)
+        d_norm_worst = _norms_close("critic", critic, o_dgrads, record="full size %s B=%d T=%d" % (enc, B, T))
         out_g = eng._generator_body(real_d, audio_d, slices_d, noise_g.to(dev))
         # the generator's gradients also travel through BatchNorm backward passes (differences of large sums) and BPTT
-        g_norm_worst = _norms_close("gen", gen, o_ggrads, ertol=5e-3)
+        g_norm_worst = _norms_close("gen", gen, o_ggrads, ertol=5e-3, record="full size %s B=%d T=%d" % (enc, B, T))
     _close("loss_critic", out_c["loss_critic"], o_err_c, 1e-4, 1e-5)
     _close("gp", out_c["gp"], o_gp, 1e-4)
     _close("w_dist", out_c["w_dist"], o_sfake.mean() - o_sreal.mean(), 1e-4)
