@@ -520,7 +520,8 @@ int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, double* sc
 // per-wave partials + the scratch of the two-stage row sum (256 groups x 32 rows x fp64 pair)
 // measured (B = 64): REP = 4 -> 80 us plain / 122 us masked against 78 / 106 us for one group per wave: kept at 1
 #define THIN_FWD_REP 1
-static int thin_fwd_gridx(int Lout) { return m2d_ceil_div(Lout, 256 * THIN_FWD_REP); }
+static int thin_fwd_nt() { static const int v = [] { const char* e = getenv("M2D_THIN_NT"); return e ? atoi(e) : 1; }(); return v; }   // tiles of 32 positions per wave: 1 (default; the masked forward 104 -> 84 us, the plain one unchanged at 73) or 2
+static int thin_fwd_gridx(int Lout) { return m2d_ceil_div(Lout, 128 * thin_fwd_nt() * THIN_FWD_REP); }
 static size_t thin_fwd_stats_part(int B, int Lout) { return (size_t)B * thin_fwd_gridx(Lout) * 4 * THIN_FWD_REP * 64 * sizeof(float); }
 size_t m2d_thin_fwd_stats_ws(int B, int Lout) { return thin_fwd_stats_part(B, Lout) + (size_t)256 * 32 * 2 * sizeof(double); }
 
@@ -542,7 +543,8 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
-  hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2, THIN_FWD_REP>), dim3(thin_fwd_gridx(Lout), B), dim3(256), 0, stream, a);
+  if (thin_fwd_nt() == 1) hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 1, THIN_FWD_REP>), dim3(thin_fwd_gridx(Lout), B), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2, THIN_FWD_REP>), dim3(thin_fwd_gridx(Lout), B), dim3(256), 0, stream, a);
   M2D_CHECK_LAUNCH("thin_fwd_mfma_kernel");
   if (stats)
     return m2d_rowsums_reduce(a.stats, B * thin_fwd_gridx(Lout) * 4 * THIN_FWD_REP, 32, stats,
