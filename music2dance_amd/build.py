@@ -13,7 +13,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libm2d_hip.so")
-SOURCES = ["m2d_runtime.hip", "gemm_engine.hip", "conv1d.hip", "conv1d_thin.hip", "bn.hip", "gru.hip", "pointwise.hip"]
+SOURCES = ["m2d_runtime.hip", "gemm_engine.hip", "conv1d.hip", "tcn.hip", "conv1d_thin.hip", "bn.hip", "gru.hip", "pointwise.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"] + os.environ.get("M2D_EXTRA_FLAGS", "").split()
 

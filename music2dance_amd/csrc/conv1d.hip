@@ -11,6 +11,7 @@
 // an operand / the result by (mask > 0 ? 1 : slope), i.e. by the derivative of the fused
 // ReLU / LeakyReLU, so the first- and second-order chains need no extra HBM pass.
 #include "gemm_engine.h"
+#include "tcn.h"
 
 static inline int conv_out_len(int L, int ks, int stride, int pad) {
   const int span = L + 2 * pad - ks;
@@ -251,6 +252,28 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
     w_packed = (const float*)ws;
     ws = (char*)ws + pb;
     ws_bytes -= pb;
+  }
+  if (!wv && !stats) {
+    // the pose critic's TemporalBlock convolutions (stride 1, "same" padding, 128 output channels): csrc/tcn.hip
+    const int nt = m2d_tcn_conv_tile(B, Cin, L, Cout, ks, stride, pad);
+    if (nt > 0) {
+      M2dTcnConv t;
+      memset(&t, 0, sizeof(t));
+      t.x = x;
+      t.wimg = w_packed;
+      t.bias = bias;
+      t.out = y;
+      t.out_mask = out_mask;
+      t.out_mask_slope = out_mask_slope;
+      t.residual = residual;
+      t.sum_out = sum_out;
+      t.act = act;
+      t.slope = slope;
+      t.B = B;
+      t.Cin = Cin;
+      t.L = L;
+      return m2d_tcn_conv_launch(t, ks, nt, (hipStream_t)stream, "m2d_conv1d_fwd");
+    }
   }
   M2dGemmParams p;
   fill_fwd(p, x, w, w_packed, y, B, Cin, L, Cout, ks, stride, pad, Lout, wv);
@@ -587,6 +610,29 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     ws = (char*)ws + pb;
     ws_bytes -= pb;
   }
+  if (stride == 1 && Lout == L && !mask_wrap) {
+    // dx[n, ci, j] = sum_{t', co} wb[co, ks - 1 - t', ci] dy[n, co, j - pad + t']: the "same" convolution of dy with the
+    // flipped taps of the (Cout, ks, Cin) image - the TemporalBlock kernel with the roles of the channels swapped
+    const int nt = m2d_tcn_conv_tile(B, Cout, L, Cin, ks, stride, pad);
+    if (nt > 0) {
+      M2dTcnConv t;
+      memset(&t, 0, sizeof(t));
+      t.x = dy;
+      t.x_mask = dy_mask;
+      t.x_mask_slope = dy_mask_slope;
+      t.wimg = w_packed;
+      t.out = dx;
+      t.out_mask = out_mask;
+      t.out_mask_slope = out_mask_slope;
+      t.residual = residual;
+      t.mask_last = 1;
+      t.tap_rev = 1;
+      t.B = B;
+      t.Cin = Cout;
+      t.L = L;
+      return m2d_tcn_conv_launch(t, ks, nt, (hipStream_t)stream, "m2d_conv1d_bwd_data");
+    }
+  }
   // dx[n, ci, s*q + r - pad] = sum_{t, co} wb[ci, r + s*t, co] * dy[n, co, q - t] per output phase r:
   // K = (t, co), hi = t (taps(r) of them, resolved on the device), lo = co.
   p.bwd_data = 1;
@@ -724,6 +770,22 @@ static int conv1d_bwd_weight_impl(const float* x, const float* dy, float* dw, fl
                                ws_bytes, wv, (hipStream_t)stream);
   if (wv && (Cin != 1 || Lout < M2D_BK))
     M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_bwd_weight_windows: single-channel convs with >= %d output positions only", M2D_BK);
+  if (!wv && Lout == L && m2d_tcn_wgrad_applicable(B, Cin, L, Cout, ks, stride, pad)) {
+    // the pose critic's TemporalBlock convolutions: csrc/tcn.hip
+    M2dTcnWgrad t;
+    memset(&t, 0, sizeof(t));
+    t.x = x;
+    t.dy = dy;
+    t.dy_mask = dy_mask;
+    t.dy_mask_slope = dy_mask_slope;
+    t.dw = dw;
+    t.dbias = dbias;
+    t.bias_from = bias_from_sample;
+    t.B = B;
+    t.Cin = Cin;
+    t.L = L;
+    return m2d_tcn_wgrad_launch(t, ks, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_bwd_weight");
+  }
   M2dGemmParams p;
   memset(&p, 0, sizeof(p));
   p.M = Cout;
@@ -858,7 +920,8 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
   const int kind = Lout >= M2D_BK ? M2D_PLAN_BWD_WEIGHT : M2D_PLAN_GENERAL;
   const size_t a = m2d_gemm_plan(Cout, Cin * ks, nch, 1, true, 1.0, kind).ws_bytes;
   const size_t c = m2d_gemm_plan(Cout, Cin * ks + 1, nch, 1, true, 1.0, kind).ws_bytes;
-  return a > c ? a : c;
+  const size_t t = (Lout == L && m2d_tcn_wgrad_applicable(B, Cin, L, Cout, ks, stride, pad)) ? m2d_tcn_wgrad_ws_bytes(B, Cin, L, ks) : 0;
+  return (a > c ? a : c) > t ? (a > c ? a : c) : t;
 }
 
 // Dense row-major GEMMs behind nn.Linear (phase3/archis/default.py:153,161,176-177,256-257;

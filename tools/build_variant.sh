@@ -5,7 +5,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/music2dance_amd/lib_$TAG
 mkdir -p $OUT
 pids=""
-for f in m2d_runtime gemm_engine conv1d conv1d_thin bn gru pointwise; do
+for f in m2d_runtime gemm_engine conv1d tcn conv1d_thin bn gru pointwise; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c $ROOT/music2dance_amd/csrc/$f.hip -o $OUT/$f.o &
   pids="$pids $!"
 done
