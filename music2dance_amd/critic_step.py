@@ -83,6 +83,7 @@ class CriticStep:
         # (M2D_MERGE_AUDIO_BWD=0: two B-row chains, the round-4 schedule)
         self.merge_audio_chains = os.environ.get("M2D_MERGE_AUDIO_BWD", "1") != "0"
         self._side = None
+        self.join_pairs = None   # diagnostics (engine.timed_wait): how long the pose branch waited for the generator forward
 
     # ------------------------------------------------------------------ helpers
     def _constants(self, B, dev, dtype=torch.float32):
@@ -176,7 +177,11 @@ class CriticStep:
         side, cur = self._fork(dev)
         if fake_ready is not None:
             first = side if side is not None else torch.cuda.current_stream(dev)
-            first.wait_event(fake_ready)
+            if self.join_pairs is not None:
+                from .engine import timed_wait
+                timed_wait(first, fake_ready, self.join_pairs)
+            else:
+                first.wait_event(fake_ready)
             fake_rows.record_stream(first)
         with self._On(side):
             X = torch.empty((R, C, T), dtype=dt, device=dev)

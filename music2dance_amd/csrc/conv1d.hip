@@ -158,7 +158,8 @@ static inline bool bwd_subpixel(int Cin, int Cout, int ks, int stride, bool mask
 static inline bool subpixel_tall(int Cin, int Cout, int ks, int stride) {
   static const bool on = [] { const char* e = getenv("M2D_SUBPIXEL_TALL"); return !(e && e[0] == '0'); }();
   const int nt = (ks + stride - 1) / stride;
-  return on && Cin % 32 == 0 && stride == 4 && ks - stride * (nt - 1) == 1 && nt >= 2;
+  // (the phase-major image is readable by m2d_gemm_dl_tall_kernel only: with M2D_DL=0 the (ci, r) order stays - ADVICE r5)
+  return on && m2d_dl_enabled() && Cin % 32 == 0 && stride == 4 && ks - stride * (nt - 1) == 1 && nt >= 2;
 }
 static inline size_t subpixel_bytes(int Cout, int Cin, int ks, int stride) {
   return ((((size_t)((ks + stride - 1) / stride) * Cout * Cin * stride) * sizeof(float)) + 255) & ~(size_t)255;
@@ -610,7 +611,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
     ws = (char*)ws + pb;
     ws_bytes -= pb;
   }
-  if (stride == 1 && Lout == L && !mask_wrap) {
+  if (stride == 1 && Lout == L && (mask_wrap % 4u) == 0) {
     // dx[n, ci, j] = sum_{t', co} wb[co, ks - 1 - t', ci] dy[n, co, j - pad + t']: the "same" convolution of dy with the
     // flipped taps of the (Cout, ks, Cin) image - the TemporalBlock kernel with the roles of the channels swapped
     const int nt = m2d_tcn_conv_tile(B, Cout, L, Cin, ks, stride, pad);
@@ -624,6 +625,7 @@ static int conv1d_bwd_data_impl(const float* dy, const float* w, const float* w_
       t.out = dx;
       t.out_mask = out_mask;
       t.out_mask_slope = out_mask_slope;
+      t.out_mask_wrap = mask_wrap;
       t.residual = residual;
       t.mask_last = 1;
       t.tap_rev = 1;

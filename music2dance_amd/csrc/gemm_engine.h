@@ -186,6 +186,8 @@ M2dGemmPlan m2d_gemm_plan(int M, int N, int nchunks, int phases, bool allow_spli
                           int kind = M2D_PLAN_GENERAL);
 int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_split, void* ws,
                     size_t ws_bytes, hipStream_t stream, const char* what);
+// whether the LDS-direct kernels are in use (M2D_DL=0 turns them off: A/B lever)
+bool m2d_dl_enabled();
 // the same for the tap-vectorised stride-4 forward conv (p.k4_ng > 0; operands as documented at the kernel)
 int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_bytes, hipStream_t stream,
                        const char* what);

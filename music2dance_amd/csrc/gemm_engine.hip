@@ -1937,6 +1937,8 @@ static bool dl_enabled() {
   static const bool on = [] { const char* e = getenv("M2D_DL"); return !(e && e[0] == '0'); }();
   return on;
 }
+// (for callers that pick a weight packing only the LDS-direct kernels can read: conv1d.hip's phase-major sub-pixel form)
+bool m2d_dl_enabled() { return dl_enabled(); }
 
 // THE gate of the LDS-direct kernel: TileMap::load_lds implements row-fast operands with the one-level row / k maps
 // only - no operand mask, no bias ("ones") row, no window views (rdiv2 / kdiv2). A new operand feature must be refused
@@ -2150,7 +2152,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
       M2D_FAIL(M2D_ERR_WORKSPACE, "%s: forced plan needs more workspace", what);
   } else
 #endif
-  if (autotune_enabled() && nc > 1) {
+  if (autotune_enabled() && nc > 1 && !p.tall_last_rb) {   // (the phase-major launch has ONE plan: nothing to time)
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
     std::vector<int> key;

@@ -34,6 +34,8 @@ struct M2dTcnConv {
   int act;               // 0 none, 1 ReLU, 2 LeakyReLU(slope)
   int mask_last;         // 0: out = mask * act(conv + bias) + residual; 1: out = mask * (conv + residual)
   int tap_rev;           // 1: tap t reads image tap ks - 1 - t (backward-data over the (Cout, ks, Cin) image)
+  unsigned out_mask_wrap; // > 0: out_mask holds only the first out_mask_wrap elements and repeats behind them (ONE wrap:
+                         // m2d_conv1d_bwd_data_shared_mask, the two halves of a batch behind the same activation masks)
   int B, Cin, L;
 };
 

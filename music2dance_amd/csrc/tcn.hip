@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
     emk[i] = tcn_f32x4{1.f, 1.f, 1.f, 1.f};
     ers[i] = tcn_f32x4{0.f, 0.f, 0.f, 0.f};
     if (eoff[i] != 0xffffffffu) {
-      if (p.out_mask) emk[i] = *reinterpret_cast<const tcn_f32x4*>(p.out_mask + eoff[i]);
+      if (p.out_mask) emk[i] = *reinterpret_cast<const tcn_f32x4*>(p.out_mask + ((p.out_mask_wrap && eoff[i] >= p.out_mask_wrap) ? eoff[i] - p.out_mask_wrap : eoff[i]));
       if (p.residual) ers[i] = *reinterpret_cast<const tcn_f32x4*>(p.residual + eoff[i]);
     }
   }

@@ -70,6 +70,10 @@ class GradExchange:
         self._hooks = []
         self._suspended = 0
         self.launched_in_backward = 0  # diagnostics: buckets whose all-reduce left before start()
+        # diagnostics: how long the consuming stream (GPU) / the host (CPU backends) waited in finish() - the part of an
+        # exchange that did NOT hide under the backward pass / the next generator forward. Event pairs, read by
+        # wait_stats() once the device has caught up; bounded.
+        self._wait_pairs = []
         # one more float at the end of the LAST bucket: "a recurrent launch of this rank gave up" (kernels.fault_fetch
         # fills it in before the bucket leaves). Summed / averaged with the gradients it is > 0 on EVERY rank as soon as
         # one rank raised it: the flag all ranks' optimizers take as their step's `skip` word (fault_flag), so that the
@@ -231,11 +235,27 @@ class GradExchange:
         if not self.active or self._pending is None:
             return
         works, had = self._pending
+        device = self.params[0].device
+        cur = torch.cuda.current_stream(device) if device.type == "cuda" else None
+        capturing = cur is not None and torch.cuda.is_current_stream_capturing()
+        if cur is not None and not capturing:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+        else:
+            import time
+            t0 = time.perf_counter()
         for w in works:
             w.wait()
-        device = self.params[0].device
         if self._stream is not None:
-            torch.cuda.current_stream(device).wait_stream(self._stream)
+            cur.wait_stream(self._stream)
+        if cur is not None and not capturing:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(cur)   # e0 -> e1 on the consuming stream holds nothing but the waits
+            self._wait_pairs.append((e0, e1))
+        elif cur is None:
+            self._wait_pairs.append(1e3 * (time.perf_counter() - t0))
+        if len(self._wait_pairs) > 512:
+            del self._wait_pairs[:256]
         inv = 1.0 / self.world
         for flat, views, bucket, has in zip(self._flat, self._views, self.buckets, had):
             if not self._avg_in_collective and self.world > 1:
@@ -248,6 +268,21 @@ class GradExchange:
     def exchange(self):
         self.start()
         self.finish()
+
+    def wait_stats(self, reset=False):
+        """-> {"exchanges", "wait_ms_mean", "wait_ms_max"}: time finish() blocked its stream (host, on CPU backends) per
+        exchange since the last reset. Call with the device idle (event times are read); unfinished pairs are skipped."""
+        vals = []
+        for p in self._wait_pairs:
+            if isinstance(p, float):
+                vals.append(p)
+            elif p[1].query():
+                vals.append(p[0].elapsed_time(p[1]))
+        if reset:
+            self._wait_pairs = []
+        if not vals:
+            return {"exchanges": 0, "wait_ms_mean": None, "wait_ms_max": None}
+        return {"exchanges": len(vals), "wait_ms_mean": round(sum(vals) / len(vals), 4), "wait_ms_max": round(max(vals), 4)}
 
 
 def init_from_env(backend=None):

@@ -54,6 +54,21 @@ def _capture(graph, body, dev, keep, pool=None):
         return body()
 
 
+
+def timed_wait(stream, event, pairs):
+    """stream.wait_event(event), bracketed by two timing events on `stream` (nothing else between them): the pair goes to
+    `pairs` (bounded) - how long the stream sat waiting. Not under graph capture."""
+    if pairs is None or torch.cuda.is_current_stream_capturing():
+        stream.wait_event(event)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    stream.wait_event(event)
+    e1.record(stream)
+    pairs.append((e0, e1))
+    if len(pairs) > 512:
+        del pairs[:256]
+
 class WganGpEngine:
     """Common machinery: optimisers, n_critic gating, data-parallel gradient exchange (the critic's
     optimiser step is taken at the start of the next iteration, once its all-reduce has landed),
@@ -112,6 +127,13 @@ class WganGpEngine:
         self._gen_params_ready = None
         self._main_mark = None
         self._fake_pending = None
+        # diagnostics: how long the consumer of a pipelined generator forward waited for it (event pairs on the waiting
+        # stream; join_stats()). With data parallelism this and GradExchange.wait_stats() are what an efficiency loss
+        # at N > 1 GPUs is attributable to.
+        self._join_pairs = []
+        self._arm_keep = False     # set by train_step for the body that holds a generator iteration
+        self._gen_epoch = 0        # bumped by every generator optimizer step (fused steps do not move version counters)
+        self._kept_key = None
 
     # -- critic optimiser step, possibly deferred so its all-reduce overlaps the next G forward
     def _finish_critic_step(self):
@@ -140,6 +162,7 @@ class WganGpEngine:
         if self.x_gen is not None:
             self.x_gen.exchange()
         self.optim_gen.step()
+        self._gen_epoch += 1
         kernels.impl().invalidate_packed(self._gen_params)
         if self._gen_stream is not None:
             self._gen_params_ready = torch.cuda.current_stream().record_event()
@@ -195,9 +218,19 @@ class WganGpEngine:
             return
         assert pend[0] is out
         main = torch.cuda.current_stream(out.device)
-        main.wait_event(pend[1])
+        timed_wait(main, pend[1], self._join_pairs)
         self._main_mark = main.record_event()
         out.record_stream(main)
+
+    def join_stats(self, reset=False):
+        """-> {"joins", "wait_ms_mean", "wait_ms_max"}: time the consuming stream waited for a generator forward that ran
+        on the generator stream. Call with the device idle."""
+        vals = [a.elapsed_time(b) for a, b in self._join_pairs if b.query()]
+        if reset:
+            del self._join_pairs[:]
+        if not vals:
+            return {"joins": 0, "wait_ms_mean": None, "wait_ms_max": None}
+        return {"joins": len(vals), "wait_ms_mean": round(sum(vals) / len(vals), 4), "wait_ms_max": round(max(vals), 4)}
 
     def _hand_over_generator_forward(self, out):
         """As _join_generator_forward, but the main stream does not wait: -> the completion event (or None) for the
@@ -254,11 +287,20 @@ class WganGpEngine:
         self.total_iterations += 1
         self._inputs_ready = inputs_ready
         self._check_async()
-        # weights only change in the optimizer steps, which drop the packed conv-weight images
-        with kernels.impl().weight_cache(keep=self._keep_packs):
-            out = self.critic_iteration(*batch)
-            if self.total_iterations % self.n_critic_steps == 0:
-                out.update(self.generator_iteration(*batch))
+        with_gen = self.total_iterations % self.n_critic_steps == 0
+        # this body's critic iteration may keep the generator's audio path for the generator iteration that follows IN
+        # THIS CALL (Phase3Engine.reuse_audio_path): armed here and nowhere else - callers that drive critic_iteration /
+        # generator_iteration themselves never keep anything (inferring it from total_iterations made every
+        # stand-alone critic iteration keep a graph that a later generator iteration on ANOTHER batch would consume)
+        self._arm_keep = with_gen
+        try:
+            # weights only change in the optimizer steps, which drop the packed conv-weight images
+            with kernels.impl().weight_cache(keep=self._keep_packs):
+                out = self.critic_iteration(*batch)
+                if with_gen:
+                    out.update(self.generator_iteration(*batch))
+        finally:
+            self._arm_keep = False
         self.last = out
         self.last_full.update(out)
         return out
@@ -284,11 +326,20 @@ class Phase3Engine(WganGpEngine):
                                  and hasattr(gen, "forward_keeping_audio_path"))
         if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
             self.manual_critic = CriticStep(critic, self.gamma, lp=False)
+            self.manual_critic.join_pairs = self._join_pairs
 
     def _shapes(self, real):
         B = real.size(0)
         T = real.numel() // (B * self.output_size)
         return B, T
+
+    def _audio_path_key(self, audio_slices):
+        """Identity of (batch, generator weights) a kept audio path is valid for: the batch tensor's storage, layout and
+        version counter; the generator's optimizer-step count and the version counters of its parameters and float
+        buffers (load_state_dict and manual edits move those; the fused optimizer step moves the count)."""
+        vers = sum(t._version for t in list(self.gen.parameters()) + [b for b in self.gen.buffers() if b.is_floating_point()])
+        return (audio_slices.data_ptr(), tuple(audio_slices.shape), tuple(audio_slices.stride()), audio_slices._version,
+                self._gen_epoch, vers)
 
     def critic_iteration(self, real, audio, audio_slices):
         """real (B, T, 69) [any view of B*T*69], audio (B, samples), audio_slices (B, T, window)."""
@@ -301,12 +352,17 @@ class Phase3Engine(WganGpEngine):
         noise / alpha: None = drawn from the host generator where the reference draws them."""
         B, T = self._shapes(real)
         # the reference builds and drops this graph (phase3/train.py:195)
-        keep = (self.reuse_audio_path and finish_inside and self.gen.training
-                and self.total_iterations % self.n_critic_steps == 0
+        keep = (self.reuse_audio_path and finish_inside and self.gen.training and self._arm_keep
                 and not (real.is_cuda and torch.cuda.is_current_stream_capturing()))
+        self._kept_key = None
         if keep:
             fake_rows = self._generator_forward_nograd(
                 lambda: self.gen.forward_keeping_audio_path(audio_slices, [T] * B, noise).detach(), (audio_slices,), grad=True)
+            # what the kept path belongs to: THIS batch tensor as it is now, THESE generator weights
+            self._kept_key = self._audio_path_key(audio_slices)
+            # the forward may have run on the generator stream (one body ahead): its completion event orders the main
+            # stream's reads of the kept tensors in the generator iteration (forward_from_kept_audio_path)
+            self._kept_done = self._fake_pending[1] if self._fake_pending is not None else None
         else:
             if hasattr(self.gen, "drop_kept_audio_path"):
                 self.gen.drop_kept_audio_path()
@@ -366,10 +422,17 @@ class Phase3Engine(WganGpEngine):
     def _generator_body(self, real, audio, audio_slices, noise):
         B, T = self._shapes(real)
         self.optim_gen.zero_grad(set_to_none=True)
-        if self.reuse_audio_path and self.gen.kept_audio_path():
-            fake_rows = self.gen.forward_from_kept_audio_path(noise)   # (the critic iteration of this body kept it)
+        use_kept = (self.reuse_audio_path and self.gen.kept_audio_path() and self.gen.training
+                    and self._kept_key is not None and self._kept_key == self._audio_path_key(audio_slices))
+        self._kept_key = None
+        if use_kept:
+            # (the critic iteration of this body kept it: same batch tensor, same weights - checked, not assumed)
+            fake_rows = self.gen.forward_from_kept_audio_path(noise, after=getattr(self, "_kept_done", None))
         else:
+            if hasattr(self.gen, "drop_kept_audio_path"):
+                self.gen.drop_kept_audio_path()
             fake_rows = self.gen(audio_slices, [T] * B, noise)
+        self._kept_done = None
         real_rows = real.reshape(B * T, self.output_size)
         err_l1 = ops.l1_mean(real_rows, fake_rows)
         fake = fake_rows.view(B, T, self.output_size).permute(0, 2, 1)
@@ -534,6 +597,7 @@ class Phase2Engine(WganGpEngine):
         self.host_noise = True  # draw noise on the host generator (matches the CPU reference)
         if os.environ.get("M2D_MANUAL_CRITIC", "1") != "0" and CriticStep.supports(critic):
             self.manual_critic = CriticStep(critic, self.gamma, lp=True)
+            self.manual_critic.join_pairs = self._join_pairs
 
     def _noise(self, B, T, device):
         if self.host_noise:

@@ -692,9 +692,13 @@ class HipKernels:
         L = x.shape[2] if x.dim() == 3 else 1
         out = torch.empty((C,), dtype=torch.float32, device=dev)
         h = _lib.lib()
+        scratch = _bn_scratch(dev, C)
+        # no zero-kept scratch (C wider than the fixed one, or a capture that was not given one): the stateless
+        # three-launch form needs its workspace (passing none made the call fail with "workspace too small")
+        ws = None if scratch is not None else _ws(_ws_bytes('m2d_bn_workspace_bytes', C), dev)
         with _on(dev):
-            rc = h.m2d_channel_sums(_ptr(x), _ptr(mask), slope, _ptr(out), B, C, L, 0, 0, _ptr(_bn_scratch(dev, C)),
-                                    _stream(dev))
+            rc = h.m2d_channel_sums(_ptr(x), _ptr(mask), slope, _ptr(out), B, C, L, _ptr(ws),
+                                    0 if ws is None else ws.numel() * 4, _ptr(scratch), _stream(dev))
         _lib.check(rc, "m2d_channel_sums")
         return out
 

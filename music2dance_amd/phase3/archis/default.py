@@ -358,10 +358,21 @@ class SequenceGenerator(nn.Module):
     def drop_kept_audio_path(self):
         self._kept_audio = None
 
-    def forward_from_kept_audio_path(self, noise=None):
-        """The second forward of the batch forward_keeping_audio_path saw (same weights in between): -> rows."""
+    def forward_from_kept_audio_path(self, noise=None, after=None):
+        """The second forward of the batch forward_keeping_audio_path saw (same weights in between): -> rows.
+        after: the completion event of that first forward when it ran on another stream (the engine's generator stream,
+        one loop body ahead): the current stream waits for it and takes the kept tensors over explicitly - they live in
+        the other stream's allocator pool (the ordering used to rest on transitive waits)."""
         h, sums_log = self._kept_audio
         self._kept_audio = None
+        if h.is_cuda:
+            cur = torch.cuda.current_stream(h.device)
+            if after is not None:
+                cur.wait_event(after)
+            h.record_stream(cur)
+            for _, sums, _ in sums_log:
+                if torch.is_tensor(sums) and sums.is_cuda:
+                    sums.record_stream(cur)
         with batched_bn_counters(self):   # every BatchNorm's step counter, the encoder's included: as forward() does
             if self.training:
                 with torch.no_grad():

@@ -24,7 +24,7 @@ def dev(request):
     kernels.set_impl(prev)
 
 
-def _run(dev, enc, ablated, reuse, steps=4, B=2, T=120):
+def _run(dev, enc, ablated, reuse, steps=4, B=2, T=120, pipelined=False):
     torch.manual_seed(0)
     gen = SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, enc, "id", "cpu")
     cls = AblatedSequenceDiscriminator if ablated else SequenceDiscriminator
@@ -39,15 +39,21 @@ def _run(dev, enc, ablated, reuse, steps=4, B=2, T=120):
     used, outs = 0, []
     orig = gen.forward_from_kept_audio_path
 
-    def counted(noise=None):
+    def counted(noise=None, after=None):
         nonlocal used
         used += 1
-        return orig(noise)
+        return orig(noise, after=after)
 
     gen.forward_from_kept_audio_path = counted
     grads = None
+    # pipelined: the production configuration (bench.py, the train scripts) - the batch is announced complete by an event,
+    # so the critic iterations' generator forward, the keeping one included, runs on the engine's second stream
+    ready = None
+    if pipelined:
+        torch.cuda.synchronize(dev)
+        ready = torch.cuda.current_stream(dev).record_event()
     for i in range(steps):
-        out = eng.train_step(real, aud, sl)
+        out = eng.train_step(real, aud, sl, inputs_ready=ready)
         outs.append({k: float(v) for k, v in out.items()})
         if "loss_gen" in out:
             grads = {n: p.grad.detach().clone() for n, p in gen.named_parameters() if p.grad is not None}
@@ -79,3 +85,59 @@ def test_second_generator_pass_from_the_kept_audio_path_changes_nothing(dev, enc
             assert torch.equal(a_sd[k], b_sd[k]) if exact else torch.allclose(a_sd[k], b_sd[k], rtol=1e-6, atol=1e-8), k
         else:
             assert torch.allclose(a_sd[k], b_sd[k], rtol=0 if exact else 1e-5, atol=0 if exact else 1e-7), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("enc,ablated", [("default", False), ("unet", True)])
+def test_kept_audio_path_on_the_generator_stream_changes_nothing(enc, ablated):
+    """the same equivalence in the PRODUCTION configuration - train_step(..., inputs_ready=event) runs the keeping
+    forward on the generator stream one body ahead; the kept output and the BatchNorm sums then live in that stream's
+    allocator pool and are read on the main stream (the hand-over is explicit: completion event + record_stream)."""
+    assert kernels.impl().name == "hip"
+    dev = torch.device("cuda:0")
+    a_out, a_g, a_sd, a_used = _run(dev, enc, ablated, True, steps=6, pipelined=True)
+    b_out, b_g, b_sd, b_used = _run(dev, enc, ablated, False, steps=6, pipelined=True)
+    assert a_used == 3 and b_used == 0, (a_used, b_used)
+    for x, y in zip(a_out, b_out):
+        for k in x:
+            assert abs(x[k] - y[k]) <= 1e-6 + 1e-5 * abs(y[k]), (k, x[k], y[k])
+    for k in a_g:
+        assert (a_g[k] - b_g[k]).abs().max().item() <= 1e-5 * b_g[k].abs().max().item() + 1e-9, k
+    for k in a_sd:
+        if "num_batches_tracked" in k:
+            assert int(a_sd[k]) == int(b_sd[k]), k
+        else:
+            assert torch.allclose(a_sd[k], b_sd[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_a_kept_audio_path_is_only_consumed_for_the_batch_and_weights_it_was_made_from(dev):
+    """callers that drive critic_iteration / generator_iteration themselves keep nothing (the keep is armed by
+    train_step only), and a kept path is dropped when the generator iteration sees another batch tensor."""
+    torch.manual_seed(0)
+    T, B = 120, 2
+    gen = SequenceGenerator(P.WINDOW, 250, 250, 256, 69, 10, 2, 3, "default", "id", "cpu")
+    critic = SequenceDiscriminator(69, 128, 100, T, init_ker=25, activ="id", device="cpu")
+    gen.to(dev), critic.to(dev)
+    cfg = {"lr_gen": 2e-4, "lr_critic": 2e-4, "n_critic_steps": 2, "gamma": 10, "beta": 1, "eta": 0.5}
+    eng = Phase3Engine(gen, critic, cfg, ablated=False, data_parallel=False)
+    real, aud = P.poses(B, T, seed=41).to(dev), P.audio(B, T, seed=42).to(dev)
+    sl = P.slices(aud.cpu()).to(dev)
+    aud2 = P.audio(B, T, seed=43).to(dev)
+    sl2 = P.slices(aud2.cpu()).to(dev)
+    used = []
+    orig = gen.forward_from_kept_audio_path
+    gen.forward_from_kept_audio_path = lambda noise=None, after=None: (used.append(1), orig(noise, after=after))[1]
+    with kernels.impl().weight_cache():
+        eng.critic_iteration(real, aud, sl)          # total_iterations == 0: round 5 kept a graph here
+        assert not gen.kept_audio_path()
+        eng.generator_iteration(real, aud2, sl2)
+    assert not used
+    # inside train_step the path is kept - and refused when the batch tensor is not the one it was made from
+    eng.total_iterations = 1
+    eng._arm_keep = True
+    with kernels.impl().weight_cache():
+        eng.critic_iteration(real, aud, sl)
+        assert gen.kept_audio_path()
+        eng.generator_iteration(real, aud2, sl2)     # another batch: full forward, the kept path is dropped
+    assert not used and not gen.kept_audio_path()
+    eng.flush()

@@ -506,3 +506,55 @@ def test_a_fault_on_one_rank_voids_the_optimizer_step_on_every_rank():
         assert torch.equal(p1, p0)                          # iteration 1: voided on both ranks
         assert not torch.equal(p2, p1)                      # iteration 2: stepped again
     assert all(torch.equal(torch.from_numpy(a[1]), torch.from_numpy(b[1])) for a, b in zip(res[0], res[1]))
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 6 (verdict item 8): what an efficiency loss at N > 1 GPUs will be attributable to is measured per rank - the time
+# the consuming stream / host sat in GradExchange.finish() and in the join with the pipelined generator forward - and both
+# exchanges leave all buckets but the last underneath their backward passes.
+def _wait_stats_worker(rank, world, port, q, B, T, alphas, noises, real, steps):
+    _setup(rank, world, port)
+    import music2dance_amd.losses as L
+    from music2dance_amd.engine import Phase2Engine
+    from music2dance_amd.dp import GradExchange
+    gen, critic = _make_p2()
+    eng = Phase2Engine(gen, critic, dict(CFG, n_critic_steps=2), data_parallel=True)
+    eng.x_gen = GradExchange(gen.parameters(), bucket_mb=0.004).overlap_backward()
+    eng.x_critic = GradExchange(critic.parameters(), bucket_mb=0.002).overlap_backward()
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    it = {"i": 0}
+    eng._noise = lambda b, t, d: noises[it["i"]][lo:hi]
+    L.torch.rand = lambda *a, **k: alphas[it["i"]][lo:hi].clone()
+    for i in range(steps):
+        it["i"] = i
+        eng.train_step(real[lo:hi])
+    eng.flush()
+    q.put((rank, {"x_critic": (len(eng.x_critic.buckets), eng.x_critic.launched_in_backward, eng.x_critic.wait_stats()),
+                  "x_gen": (len(eng.x_gen.buckets), eng.x_gen.launched_in_backward, eng.x_gen.wait_stats()),
+                  "join": eng.join_stats()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_and_join_waits_are_reported_per_rank():
+    B, T, steps = 4, 24, 6
+    g = torch.Generator().manual_seed(13)
+    alphas = [torch.rand(B, 1, generator=g) for _ in range(steps)]
+    noises = [torch.randn(B, T, 8, generator=g) for _ in range(steps)]
+    real = torch.rand(B, T, 69, generator=g)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wait_stats_worker, args=(r, world, port, q, B, T, alphas, noises, real, steps)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    for rank, d in res:
+        nb, inb, w = d["x_critic"]
+        # six critic exchanges (the first one teaches the expectations): five of them leave >= nb - 1 buckets early
+        assert nb >= 2 and inb >= (steps - 1) * (nb - 1), (rank, nb, inb)
+        assert w["exchanges"] == steps and w["wait_ms_mean"] is not None and w["wait_ms_max"] >= w["wait_ms_mean"] >= 0.0
+        nb, inb, w = d["x_gen"]
+        assert nb >= 3 and inb >= (steps // 2 - 1) * (nb - 1), (rank, nb, inb)
+        assert w["exchanges"] == steps // 2 and w["wait_ms_mean"] >= 0.0
+        assert set(d["join"]) == {"joins", "wait_ms_mean", "wait_ms_max"}   # (CPU: the forward runs in line, nothing to join)

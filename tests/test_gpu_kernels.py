@@ -326,7 +326,7 @@ def test_bn_eval_and_residual():
     assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv)
 
 
-@pytest.mark.parametrize("shape", [(4, 128, 120), (7, 5, 3), (64, 100, 1), (3, 32, 19200)],
+@pytest.mark.parametrize("shape", [(4, 128, 120), (7, 5, 3), (64, 100, 1), (3, 32, 19200), (2, 5000, 3)],   # (5 000 > the fixed scratch: stateless form)
                          ids=lambda c: "x".join(map(str, c)))
 def test_channel_sums(shape):
     x = gen(*shape, seed=1)
