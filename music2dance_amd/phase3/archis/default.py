@@ -311,6 +311,11 @@ class SequenceGenerator(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 n = self.noise_gen(noise)
+            # `noise` lives in the caller's (or the staging stream's) allocator pool and is read on the side stream - in the
+            # backward pass too, as a saved tensor of the recurrence. Without this the pool may hand its memory out again
+            # the moment autograd drops it, while the side stream's weight-gradient GEMM has not read it yet (round 6:
+            # tests/test_flip_audit.py found noise_gen.rnn.weight_ih_l0 wrong in 5 runs of 6 under a particular timing)
+            noise.record_stream(side)
             h = self.audio_rnn(code, lengths_tensor(ls, frames, code.device))[:, :max(ls)]
             cur.wait_stream(side)
             n.record_stream(cur)
