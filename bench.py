@@ -331,6 +331,26 @@ def other_configs(steps=16, warmup=8):
     return out
 
 
+def step_clock():
+    """The shader clock inside the step's largest launches, from the stamped build of the library (libm2d_hip_stamp.so:
+    per-workgroup s_memrealtime / s_memtime stamps around the K loop) - a child process (tools/step_clock.py) run before
+    this process touches the GPU. -> its JSON ({"shapes": [...], "clock_GHz_in_step"}) or {"failed": ...}."""
+    import subprocess
+    from music2dance_amd import build as m2d_build
+    lib = m2d_build.STAMP_LIB_PATH
+    if not os.path.exists(lib):
+        return {"failed": "no stamped library (python -m music2dance_amd.build)"}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_clock.py")], capture_output=True, text=True,
+                           env=dict(os.environ, M2D_LIB=lib), timeout=180)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"failed": "rc %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+        return json.loads(line[-1])
+    except Exception as e:
+        return {"failed": repr(e)}
+
+
 PRESETS = {  # BASELINE.json configs[0..4] at their per-GPU shapes
     # phase1/configs/b1l10s128.yaml (BASELINE words it "CPU": GPU-only here). Host-launch-bound when eager (2.8-3.2 ms
     # per body for 0.75 ms of kernels): the preset replays the captured graphs (Phase1Engine.enable_graphs, 0.86 ms)
@@ -493,10 +513,11 @@ def main():
     # this process makes its first GPU call - each has the device to itself (measured the other way round, with this
     # process's idle HIP context alive beside the child, the launch-bound c2 loop ran 13 % slower: 15.2 k vs 17.5 k
     # seq/s) - and none of it overlaps this workload's timed region.
-    others = None
+    others = clock = None
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_other_configs and args.phase == 3 and
             (args.enc_type, args.frames, args.ablated, args.batch) == ("default", 120, False, 64)):
         others = other_configs()
+        clock = step_clock()
 
     from music2dance_amd import dp, kernels, runner
     from music2dance_amd.engine import Phase3Engine, synthetic_phase3_batch
@@ -725,16 +746,73 @@ def main():
                 ga, gb = torch.randn(n, n, device=device), torch.randn(n, n, device=device)
                 K.gemm(2, ga, gb)
                 torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10):
-                    K.gemm(2, ga, gb)
-                e1.record()
-                torch.cuda.synchronize()
-                plain = 10 * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+                def timed(fn, reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return reps * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+                # (round 5 timed 10 launches behind the profiling pass: 116 against the probe's 137 for the same kernel - a
+                # window too short for the clock to settle; 200 back-to-back launches, ONE event pair, no profiler)
+                plain = timed(lambda: K.gemm(2, ga, gb), 200)
                 out["roofline"]["plain_gemm_4096_tflops"] = round(plain, 1)
                 out["roofline"]["frac_of_plain_gemm"] = round(ach / plain, 4)
+                out["roofline"]["plain_gemm_launches_timed"] = 200
+                # the same GEMM BETWEEN loop bodies of the step (8 bodies, one launch after each, each launch bracketed by
+                # its own event pair): what the engine's plain rate is at the clock / cache state the step leaves behind
+                try:
+                    evs = []
+                    engine.total_iterations = phase
+                    for _ in range(8):
+                        engine.train_step(*batch)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        K.gemm(2, ga, gb)
+                        e1.record()
+                        evs.append((e0, e1))
+                    engine.flush()
+                    torch.cuda.synchronize()
+                    ms = sorted(a.elapsed_time(b) for a, b in evs)
+                    out["roofline"]["plain_gemm_4096_tflops_between_steps"] = round(2.0 * n ** 3 / (ms[len(ms) // 2] * 1e-3) / 1e12, 1)
+                except Exception as e:
+                    out["roofline"]["plain_gemm_4096_tflops_between_steps"] = "failed: %r" % (e,)
+                # the stand-alone probe's best plain kernel (tools/probes/gemm_ceiling.hip "dl 128x128x16 dma16 frag1"),
+                # compiled into the library as a test-only entry point: same process, same 200 launches, and the shader
+                # clock it ran at (s_memtime / s_memrealtime over workgroup 0's lifetime)
+                try:
+                    import ctypes
+                    from music2dance_amd import _lib as m2d_lib
+                    h = m2d_lib.lib()
+                    gc_ = torch.empty(n, n, device=device)
+                    st = torch.cuda.current_stream(device).cuda_stream
+                    h.m2d_debug_probe_gemm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+                    run_probe = lambda: h.m2d_debug_probe_gemm(ga.data_ptr(), gb.data_ptr(), gc_.data_ptr(), n, n, n, st)
+                    run_probe()
+                    torch.cuda.synchronize()
+                    ref = K.gemm(2, ga, gb)
+                    err = float((gc_ - ref).abs().max() / ref.abs().max())
+                    out["roofline"]["probe_kernel_tflops"] = round(timed(run_probe, 200), 1)
+                    ck = (ctypes.c_ulonglong * 4)()
+                    h.m2d_debug_probe_clock(ck)
+                    out["roofline"]["probe_kernel_clock_GHz"] = round((ck[3] - ck[1]) / max(ck[2] - ck[0], 1) / 10.0, 3)
+                    out["roofline"]["probe_kernel_max_rel_diff_vs_engine"] = float("%.2e" % err)
+                    del gc_
+                except Exception as e:
+                    out["roofline"]["probe_kernel_tflops"] = "failed: %r" % (e,)
                 del ga, gb
+            if clock is not None:
+                out["roofline"]["clock_GHz_in_step"] = clock.get("clock_GHz_in_step")
+                out["roofline"]["clock_by_shape"] = clock.get("shapes", clock)
+                c = clock.get("clock_GHz_in_step")
+                if c:
+                    # the fp32-MFMA rate the chip can deliver AT THAT CLOCK (64 FLOP / clock / SIMD x 1024 SIMDs): `frac`
+                    # stays priced against the nominal 157.3 (2.4 GHz); this is how much of the gap is clock, not schedule
+                    out["roofline"]["peak_at_step_clock_tflops"] = round(PEAK_F32_MFMA_TFLOPS * c / 2.4, 1)
+                    out["roofline"]["frac_of_peak_at_step_clock"] = round(ach / (PEAK_F32_MFMA_TFLOPS * c / 2.4), 4)
             # the reference's own formulation executes REF_GFLOP_PER_SEQ_CYCLE per sequence consumed (SURVEY.md
             # 8(d), per workload); the engine skips work the reference discards, so this is an equivalent-work
             # rate over whole cycles, not a kernel rate

@@ -790,21 +790,25 @@ __device__ __forceinline__ bool m2d_splitk_fixup(const M2dGemmParams& p, int spl
   return true;
 }
 
-#ifdef M2D_STAMP  // diagnostic builds only (tools/probes/gemm_ceiling.hip): where does a workgroup of the LDS-direct kernel spend its time?
-__device__ unsigned long long m2d_stamp_buf[8192 * 4];
+#ifdef M2D_STAMP  // diagnostic builds only (tools/phase_stamps.py): where does a workgroup of the LDS-direct kernel spend its time?
+// per workgroup: entries 0..3 = s_memrealtime (100 MHz) at entry / loop entry / loop exit / end, 4..7 = s_memtime (the
+// shader clock's counter) at the same points: clock in GHz = d memtime / d realtime / 10 (round 6)
+__device__ unsigned long long m2d_stamp_buf[8192 * 8];
 #define M2D_STAMP_AT(i)                                                                                      \
   do {                                                                                                       \
-    if (threadIdx.x == 0)                                                                                    \
-      m2d_stamp_buf[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 8192 * 4 + (i)] =     \
-          __builtin_amdgcn_s_memrealtime();                                                                  \
+    if (threadIdx.x == 0) {                                                                                  \
+      unsigned long long* sb__ = m2d_stamp_buf + ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 8192 * 8; \
+      sb__[(i)] = __builtin_amdgcn_s_memrealtime();                                                          \
+      sb__[4 + (i)] = __builtin_amdgcn_s_memtime();                                                          \
+    }                                                                                                        \
   } while (0)
 extern "C" int m2d_debug_stamps_reset(void) {
   void* p = nullptr;
   if (hipGetSymbolAddress(&p, HIP_SYMBOL(m2d_stamp_buf)) != hipSuccess) return -2;
-  return hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -2;
+  return hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : -2;
 }
 extern "C" int m2d_debug_stamps(unsigned long long* out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(m2d_stamp_buf), (size_t)n * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(m2d_stamp_buf), (size_t)n * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }
 #else
 #define M2D_STAMP_AT(i) do { } while (0)

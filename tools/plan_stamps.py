@@ -9,7 +9,7 @@ from music2dance_amd import kernels, _lib
 K = kernels.impl()
 L = _lib.lib()
 dev = "cuda:0"
-buf = (ctypes.c_ulonglong * (8192 * 4))()
+buf = (ctypes.c_ulonglong * (8192 * 8))()
 CASES = {"tcn3b": (192, 128, 120, 128, 7, 1, 3), "tcn1b": (64, 128, 120, 128, 7, 1, 3), "stick1": (192, 69, 120, 128, 25, 1, 12),
          "l3": (64, 64, 4800, 128, 25, 4, 11), "l4": (64, 128, 1200, 256, 25, 4, 11), "l5": (64, 256, 300, 512, 25, 4, 11)}
 b_, cin, Lx, cout, ks, s_, p_ = CASES[os.environ.get("CASE", "tcn3b")]
@@ -28,7 +28,7 @@ def stamps(fn):
     L.m2d_debug_stamps_reset()
     fn(); torch.cuda.synchronize()
     L.m2d_debug_stamps(buf, 8192)
-    s = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4).astype(np.float64) * 0.01
+    s = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8)[:, :4].astype(np.float64) * 0.01
     s = s[(s[:, 0] > 0) & (s[:, 3] > 0)]
     if len(s) == 0: return "no stamps"
     t0 = s[:, 0].min()
