@@ -355,7 +355,10 @@ PRESETS = {  # BASELINE.json configs[0..4] at their per-GPU shapes
     # phase1/configs/b1l10s128.yaml (BASELINE words it "CPU": GPU-only here). Host-launch-bound when eager (2.8-3.2 ms
     # per body for 0.75 ms of kernels): the preset replays the captured graphs (Phase1Engine.enable_graphs, 0.86 ms)
     "c1": dict(phase=1, batch=64, frames=1, graphs="on"),
-    "c2": dict(phase=2, batch=32, frames=120),   # phase2/configs/default.yaml at batch 32
+    # phase2/configs/default.yaml at batch 32. Round 6: with the TemporalBlock kernels a loop body is 1.2 ms of GPU work
+    # and the eager loop is bound by the host's launch rate (16.4 k vs 19.7 k seq/s, three alternating pairs on one box):
+    # the preset replays the captured graphs, as the phase-2 train script now does on one GPU (--graphs off: eager)
+    "c2": dict(phase=2, batch=32, frames=120, graphs="on"),
     "c3": dict(enc_type="default", batch=64, frames=120, ablated=False),
     "c4": dict(enc_type="wavegan", batch=32, frames=120, ablated=False),  # global 256 on 8 GPUs
     "c5": dict(enc_type="unet", batch=16, frames=300, ablated=True),     # global 128 on 8 GPUs
@@ -492,7 +495,7 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel profile")
     ap.add_argument("--dump-shapes", default=None, metavar="CSV",
                     help="write the roofline pass's per-shape table (family, tag, dims, launches, ms, TF/s or GB/s)")
-    ap.add_argument("--graphs", default="off", choices=["on", "off"],
+    ap.add_argument("--graphs", default=None, choices=["on", "off"],
                     help="replay each loop body's forward/backward from a captured HIP graph (Phase3Engine.enable_graphs)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default workload only: do not run the c2 / c4 / c5 presets (child processes, after every timed "
@@ -504,7 +507,11 @@ def main():
     args = ap.parse_args()
     if args.config:
         for k, v in PRESETS[args.config].items():
+            if k == "graphs" and args.graphs is not None:
+                continue   # (an explicit --graphs on / off wins over the preset's)
             setattr(args, k, v)
+    if args.graphs is None:
+        args.graphs = "off"
     if args.same_device:
         os.environ["M2D_PERSISTENT_GRU"] = "0"  # ranks sharing one GPU: persistent kernels could starve each other
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

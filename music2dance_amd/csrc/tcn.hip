@@ -76,6 +76,11 @@ extern "C" int m2d_tcn_stamps(unsigned long long* out, int n) {
 #define TCN_STAMP_AT(i) do { } while (0)
 #endif
 
+template <int N>
+static __device__ __forceinline__ void tcn_wait_frag(float& a, float& b0, float& b1, float& b2, float& b3) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "n"(N));
+}
+
 template <int I, int N, class F>
 static __device__ __forceinline__ void tcn_static_for(F&& f) {
   if constexpr (I < N) {
@@ -112,11 +117,19 @@ static __device__ __forceinline__ void tcn_divmod(int n, int d, float inv, int& 
 // tile is read-only after the prologue and the weight ring is private to the wave (round 6: the per-chunk barrier of the
 // first version cost 13 % of the loop - 48.4 vs 42.1 us, tools/tcn_stamps.py). The fragment reads run AHEAD k-steps in
 // front of their MFMAs, across chunk boundaries.
+// Column blocks of 32 (v_mfma_f32_32x32x2_f32: NT = 96 / 64 / 32) or of 16 (v_mfma_f32_16x16x4_f32: NT = 48 / 16 - the
+// one-round tilings of the small launches: 3B * 120 = 11 520 columns at B = 32 are 240 tiles of 48, a B-row tangent's 3 840
+// are 240 of 16). With 16-wide blocks a wave's 32 output channels are two 16-row blocks and a k-step is 4 deep.
 template <int NT, int KS, int NS_>
 struct TcnConvCfg {
+  static constexpr int CB = (NT % 32 == 0) ? 32 : 16;       // columns per MFMA block
+  static constexpr int RB = 32 / CB;                         // row blocks per wave (32 output channels)
+  static constexpr int KD = CB == 32 ? 2 : 4;                // contraction depth of one MFMA
+  static constexpr int NSTEP = 8 / KD;                       // k-steps per chunk and K half (8 channels)
   static constexpr int PAD = (KS - 1) / 2;
-  static constexpr int LDX = NT + 2 * (KS - 1);
-  static constexpr int TN = NT / 32;
+  // Xs row pitch: tile + two halo runs; 16-wide blocks read channels k and k + 1 in one 32-lane bank group: pitch = 16 (mod 32)
+  static constexpr int LDX = CB == 32 ? NT + 2 * (KS - 1) : ((NT + 2 * (KS - 1) + 15) / 32) * 32 + 16;
+  static constexpr int TN = NT / CB;
   static constexpr int NS = NS_;               // weight stages (a power of two)
   static constexpr int STAGE = 16 * 128;       // floats
   static constexpr int LDE = NT + 4;           // epilogue image row (16-byte aligned rows)
@@ -124,7 +137,10 @@ struct TcnConvCfg {
 #define TCN_AHEAD 2
 #endif
   static constexpr int AHEAD = TCN_AHEAD;      // fragment reads run this many k-steps ahead of their MFMAs
-  static constexpr int NFRAG = 1 + TN;         // LDS reads per k-step and wave
+  static constexpr int NFRAG = RB + TN;        // LDS reads per k-step and wave
+  // fragment register sets: a ring over the k-steps; its length divides the KS * NSTEP steps of a channel block (the block
+  // loop is rolled: the slot of a step must not depend on the block)
+  static constexpr int RING = NSTEP == 4 ? 4 : KS;
   static size_t xs_floats(int Cin) { return ((size_t)((Cin + 15) / 16) * 16 * LDX + 63) & ~(size_t)63; }
   static size_t lds_bytes(int Cin) {
     const size_t loop = (xs_floats(Cin) + (size_t)NS * STAGE) * sizeof(float);
@@ -136,9 +152,11 @@ struct TcnConvCfg {
 template <int NT, int KS, bool XMASK, int NS_>
 __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p) {
   using Cfg = TcnConvCfg<NT, KS, NS_>;
-  constexpr int PAD = Cfg::PAD, LDX = Cfg::LDX, TN = Cfg::TN, NS = Cfg::NS, STAGE = Cfg::STAGE, LDE = Cfg::LDE;
-  constexpr int AHEAD = Cfg::AHEAD, NFRAG = Cfg::NFRAG;
-  static_assert(NS >= 4 && (NS & (NS - 1)) == 0 && TN >= 1 && TN <= 3 && AHEAD >= 1 && AHEAD <= 3 && NFRAG * AHEAD <= 15, "tile shape");
+  constexpr int PAD = Cfg::PAD, LDX = Cfg::LDX, TN = Cfg::TN, NS = Cfg::NS, LDE = Cfg::LDE;
+  constexpr int AHEAD = Cfg::AHEAD, NFRAG = Cfg::NFRAG, CB = Cfg::CB, RB = Cfg::RB, KD = Cfg::KD, NSTEP = Cfg::NSTEP, RING = Cfg::RING;
+  static_assert(NS >= 4 && (NS & (NS - 1)) == 0 && TN >= 1 && TN <= 3 && AHEAD >= 1 && AHEAD < RING && NFRAG * AHEAD <= 15 &&
+                (KS * NSTEP) % RING == 0, "tile shape");
+  typedef float acc_t __attribute__((ext_vector_type(CB == 32 ? 16 : 4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -146,6 +164,7 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave & 3, kh = wave >> 2;
   const int l31 = lane & 31, lh = lane >> 5;
+  const int lc = lane & (CB - 1), lk = lane / CB;   // a lane's column (or row) inside an MFMA block, its k inside the step
 
   const int L = p.L, Cin = p.Cin;
   const int ncb = (Cin + 15) >> 4;
@@ -166,7 +185,10 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
   // its own, As[wave][c % NS][8][32] - nobody else touches it, so the main loop needs no barrier at all.
   const __amdgpu_buffer_rsrc_t rw = tcn_rsrc(p.wimg, (unsigned)((size_t)Cin * KS * 128 * sizeof(float)));
   const int a_krow = kh * 8 + (lane >> 3);         // the chunk's channel this lane fetches
-  const unsigned a_voff = (unsigned)(((a_krow * KS) * 128 + wr * 32 + (lane & 7) * 4) * 4);
+  // (16-wide blocks: odd channel rows of the stage are stored rotated by 16 columns - lanes k and k + 1 of a fragment read
+  // then hit disjoint banks; the rotation is made HERE, on the source address: the LDS side of a DMA is lane-linear)
+  const int a_piece = CB == 32 ? (lane & 7) : ((lane & 7) ^ (4 * ((lane >> 3) & 1)));
+  const unsigned a_voff = (unsigned)(((a_krow * KS) * 128 + wr * 32 + a_piece * 4) * 4);
   const int nch = ncb * KS;
   float* Aw = As + wave * (NS * 256);
   auto issue_a = [&](int c, int cb, int t) {
@@ -217,43 +239,56 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
   });
 
   // ---- fragment addresses ---------------------------------------------------------------------------------------------
-  // A (weights): the wave's own ring, stage[k][m], k = 2 s + lh, m = l31
-  const unsigned a_base = tcn_lds_addr(Aw) + (unsigned)((lh * 32 + l31) * 4);
-  // B (activations): Xs[16 cb + 8 kh + 2 s + lh][colmap(32 jb + l31) + t]
+  // A (weights): the wave's own ring, stage[k][m]: k = KD s + lk, m = CB rb + lc (16-wide blocks: rotated on odd k, see above)
+  unsigned a_base[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = rb * CB + lc;
+    a_base[rb] = tcn_lds_addr(Aw) + (unsigned)((lk * 32 + (CB == 32 ? m : (m ^ (16 * (lk & 1))))) * 4);
+  }
+  // B (activations): Xs[16 cb + 8 kh + KD s + lk][colmap(CB jb + lc) + t]
   unsigned b_base[TN];
 #pragma unroll
   for (int jb = 0; jb < TN; ++jb) {
-    const int j = jb * 32 + l31;
-    b_base[jb] = tcn_lds_addr(Xs) + (unsigned)(((kh * 8 + lh) * LDX + j + (j >= j1 ? KS - 1 : 0)) * 4);
+    const int j = jb * CB + lc;
+    b_base[jb] = tcn_lds_addr(Xs) + (unsigned)(((kh * 8 + lk) * LDX + j + (j >= j1 ? KS - 1 : 0)) * 4);
   }
 
-  f32x16 acc[TN];
+  acc_t acc[RB][TN];
 #pragma unroll
-  for (int jb = 0; jb < TN; ++jb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[jb][r] = 0.f;
+    for (int jb = 0; jb < TN; ++jb)
+#pragma unroll
+      for (int r = 0; r < (CB == 32 ? 16 : 4); ++r) acc[rb][jb][r] = 0.f;
 
-  // fragment registers: a ring of 4 k-steps (one chunk's worth for this wave)
-  float fa[4], fb[4][TN];
+  // fragment registers: a ring of RING k-steps
+  float fa[RING][RB], fb[RING][TN];
   // reads of k-step S of tap T of the CURRENT channel block (T may run past KS - 1: the next block's first taps);
   // c0 = the chunk index of (cb, tap 0)
   auto issue_frag = [&](auto T_, auto S_, int c0, const unsigned (&bb)[TN]) {
     constexpr int T = decltype(T_)::value, S = decltype(S_)::value;
+    constexpr int SL = (T * NSTEP + S) % RING;
     constexpr int TT = T >= KS ? T - KS : T;               // tap inside its block
-    constexpr int BOFF = ((T >= KS ? 16 * LDX : 0) + 2 * S * LDX + TT) * 4;
-    const unsigned aa = a_base + (unsigned)(((c0 + T) & (NS - 1)) * 1024);
-    fa[S] = tcn_ds_read<S * 2 * 32 * 4>(aa);
+    constexpr int BOFF = ((T >= KS ? 16 * LDX : 0) + KD * S * LDX + TT) * 4;
+    const unsigned st = (unsigned)(((c0 + T) & (NS - 1)) * 1024);
 #pragma unroll
-    for (int jb = 0; jb < TN; ++jb) fb[S][jb] = tcn_ds_read<BOFF>(bb[jb]);
+    for (int rb = 0; rb < RB; ++rb) fa[SL][rb] = tcn_ds_read<S * KD * 32 * 4>(a_base[rb] + st);
+#pragma unroll
+    for (int jb = 0; jb < TN; ++jb) fb[SL][jb] = tcn_ds_read<BOFF>(bb[jb]);
   };
-  auto wait_frag = [&](auto S_) {
-    constexpr int S = decltype(S_)::value;
-    if constexpr (TN == 1) tcn_wait_frag<NFRAG * AHEAD>(fa[S], fb[S][0]);
-    else if constexpr (TN == 2) tcn_wait_frag<NFRAG * AHEAD>(fa[S], fb[S][0], fb[S][1]);
-    else tcn_wait_frag<NFRAG * AHEAD>(fa[S], fb[S][0], fb[S][1], fb[S][2]);
+  auto wait_frag = [&](auto SL_) {
+    constexpr int SL = decltype(SL_)::value;
+    constexpr int N = NFRAG * AHEAD;
+    if constexpr (RB == 1 && TN == 1) tcn_wait_frag<N>(fa[SL][0], fb[SL][0]);
+    else if constexpr (RB == 1 && TN == 2) tcn_wait_frag<N>(fa[SL][0], fb[SL][0], fb[SL][1]);
+    else if constexpr (RB == 1 && TN == 3) tcn_wait_frag<N>(fa[SL][0], fb[SL][0], fb[SL][1], fb[SL][2]);
+    else if constexpr (RB == 2 && TN == 1) tcn_wait_frag<N>(fa[SL][0], fa[SL][1], fb[SL][0]);
+    else if constexpr (RB == 2 && TN == 2) tcn_wait_frag<N>(fa[SL][0], fa[SL][1], fb[SL][0], fb[SL][1]);
+    else tcn_wait_frag<N>(fa[SL][0], fa[SL][1], fb[SL][0], fb[SL][1], fb[SL][2]);
   };
 
-  // chunk 0 and 1 landed and published; chunk NS - 1 into the free stage
+  // chunk 0 and 1 landed; chunk NS - 1 into the free stage; the activation tile is published by the barrier
   tcn_wait_vm<NS - 3>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the masked variant's ds_writes of Xs)
   __builtin_amdgcn_s_barrier();
@@ -265,7 +300,7 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
     for (int jb = 0; jb < TN; ++jb) bb[jb] = b_base[jb];
     tcn_static_for<0, AHEAD>([&](auto g) {
       constexpr int G = decltype(g)::value;
-      issue_frag(std::integral_constant<int, G / 4>{}, std::integral_constant<int, G % 4>{}, 0, bb);
+      issue_frag(std::integral_constant<int, G / NSTEP>{}, std::integral_constant<int, G % NSTEP>{}, 0, bb);
     });
   }
 
@@ -282,16 +317,19 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
         constexpr int T3 = T + NS - 1;
         issue_a(c0 + T3, cb + T3 / KS, T3 % KS);
       }
-      tcn_static_for<0, 4>([&](auto s_) {
+      tcn_static_for<0, NSTEP>([&](auto s_) {
         constexpr int S = decltype(s_)::value;
+        constexpr int SL = (T * NSTEP + S) % RING;
         constexpr int G2 = S + AHEAD;                       // the k-step AHEAD of this one
-#ifndef TCN_X_NOREAD  // experiment (wrong results): the MFMAs on whatever the fragment registers hold
-        issue_frag(std::integral_constant<int, T + G2 / 4>{}, std::integral_constant<int, G2 % 4>{}, c0, bb);
-        wait_frag(s_);
-#endif
+        issue_frag(std::integral_constant<int, T + G2 / NSTEP>{}, std::integral_constant<int, G2 % NSTEP>{}, c0, bb);
+        wait_frag(std::integral_constant<int, SL>{});
 #pragma unroll
-        for (int jb = 0; jb < TN; ++jb)
-          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S], fb[S][jb], acc[jb], 0, 0, 0);
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int jb = 0; jb < TN; ++jb) {
+            if constexpr (CB == 32) acc[rb][jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SL][rb], fb[SL][jb], acc[rb][jb], 0, 0, 0);
+            else acc[rb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[SL][rb], fb[SL][jb], acc[rb][jb], 0, 0, 0);
+          }
         __builtin_amdgcn_sched_barrier(0);
       });
     });
@@ -326,13 +364,19 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
     }
   }
   // the two K halves meet: E[kh][m][LDE] over the (now free) loop memory, added on the way out
-  // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); of the 16x16 MFMA: column =
+  // lane & 15, row = 4 (lane >> 4) + r
   {
     float* E = smem + kh * (128 * LDE);
 #pragma unroll
-    for (int jb = 0; jb < TN; ++jb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) E[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDE + jb * 32 + l31] = acc[jb][r];
+      for (int jb = 0; jb < TN; ++jb)
+#pragma unroll
+        for (int r = 0; r < (CB == 32 ? 16 : 4); ++r) {
+          const int row = CB == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : rb * 16 + 4 * lk + r;
+          E[(wr * 32 + row) * LDE + jb * CB + lc] = acc[rb][jb][r];
+        }
   }
   __syncthreads();
   {
@@ -388,8 +432,8 @@ int m2d_tcn_conv_tile(int B, int Cin, int L, int Cout, int ks, int stride, int p
   static const int force = [] { const char* e = getenv("M2D_TCN_NT"); return e ? atoi(e) : 0; }();
   int best = 0;
   double best_cost = 0.0;
-  const int cand[3] = {96, 64, 32};
-  for (int i = 0; i < 3; ++i) {
+  const int cand[5] = {96, 64, 48, 32, 16};
+  for (int i = 0; i < 5; ++i) {
     const int nt = cand[i];
     if (nt > L + 1) continue;
     if (force && nt != force) continue;
@@ -444,6 +488,8 @@ int m2d_tcn_conv_launch(const M2dTcnConv& p, int ks, int nt, hipStream_t stream,
     case 96: return tcn_conv_launch_nt<96, 7>(p, stream, what);
     case 64: return tcn_conv_launch_nt<64, 7>(p, stream, what);
     case 32: return tcn_conv_launch_nt<32, 7>(p, stream, what);
+    case 48: return tcn_conv_launch_nt<48, 7>(p, stream, what);
+    case 16: return tcn_conv_launch_nt<16, 7>(p, stream, what);
   }
   M2D_FAIL(M2D_ERR_ARG, "%s: bad TemporalBlock tile width %d", what, nt);
 }

@@ -34,17 +34,21 @@ def gen(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
-# (B, Cin, L): tile width the launcher picks -> 32: few positions; 64: 8 192 < B L <= 16 384; 96: more
+# (B, Cin, L): tile width the launcher picks (the one-round plan with the least padded work, csrc/tcn.hip:
+# m2d_tcn_conv_tile): 16 columns up to 4 096 positions, 32 up to 8 192, 48 up to 12 288, 64 up to 16 384, 96 beyond
 SHAPES = [
-    (3, 128, 120),      # 32-column tiles, three samples (the fixture size)
-    (1, 128, 40),       # one sample shorter than two tiles: second-sample columns past the batch
-    (5, 128, 300),      # T = 300 (BASELINE configs[4]); tiles straddle at 300 = 9 x 32 + 12
+    (3, 128, 120),      # 16-column tiles (16x16x4 MFMA blocks), three samples (the fixture size)
+    (1, 128, 40),       # one sample shorter than two 32-column tiles
+    (5, 128, 300),      # T = 300 (BASELINE configs[4]); tiles straddle at 300 = 18 x 16 + 12
     (7, 48, 44),        # three 16-channel blocks, L not a multiple of the tile
     (4, 100, 120),      # ragged last channel block (100 = 6 x 16 + 4)
-    (100, 128, 120),    # 64-column tiles
+    (50, 128, 120),     # 32-column tiles
+    (32, 128, 120),     # a B-row tangent of BASELINE configs[1]: 240 tiles of 16
+    (96, 128, 120),     # 3B rows of BASELINE configs[1]: 240 tiles of 48
+    (130, 128, 120),    # 64-column tiles
     (140, 128, 120),    # 96-column tiles
     (192, 128, 120),    # 3B rows of the bench: exactly 240 tiles of 96
-    (37, 128, 300),     # 64-column tiles at T = 300
+    (37, 128, 300),     # 48-column tiles at T = 300 (11 100 positions)
 ]
 
 
@@ -69,7 +73,8 @@ def test_temporal_conv_forward_and_backward_data(shape):
         assert rel_err(K().conv1d_bwd_data(dy.to(DEV), wd, L, 1, 3), gx) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(3, 128, 120), (100, 128, 120), (150, 128, 120)], ids=lambda s: "B%d_C%d_L%d" % s)
+@pytest.mark.parametrize("shape", [(3, 128, 120), (60, 128, 120), (100, 128, 120), (130, 128, 120), (150, 128, 120)],
+                         ids=lambda s: "B%d_C%d_L%d" % s)   # (16 / 32 / 48 / 64 / 96-column tiles)
 def test_temporal_conv_epilogues(shape):
     """Every epilogue form of the critic iteration (critic_step.py): the block's second conv with two outputs, the
     tangent's mask-then-residual, backward-data with a masked dy, an output mask and the skip gradient (mask last)."""
