@@ -732,6 +732,41 @@ def main():
                 # launches that move >= 64 MB (smaller ones are launch-bound, listed under "small")
                 "hbm": hbm,
             }
+            # What this part's memory system delivers to the simplest possible kernels at the size of the memory-bound
+            # families' tensors (157 MB = the audio critic's first activation at B = 64), measured here and now: a fill
+            # (write only), a copy (read + write) and a sum (read only), 50 launches each behind one event pair. The
+            # families' `frac` stays priced against the 8 TB/s spec; `frac_of_probe` prices each against the probe that
+            # matches its traffic (write-dominated -> fill, read-dominated -> read, mixed -> copy): how far a family is
+            # from what a streaming kernel reaches at all (round-5 verdict item 3: ">= 0.70 or a PMC-backed limit")
+            try:
+                nel = 157286400 // 4
+                pa, pb = torch.empty(nel, device=device), torch.empty(nel, device=device)
+                pa.fill_(1.0), pb.copy_(pa), pa.sum()
+                torch.cuda.synchronize()
+
+                def gbps(fn, nbytes, reps=50):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return reps * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+                probe = {"bytes": nel * 4, "fill_GBps": round(gbps(lambda: pa.fill_(2.0), nel * 4)),
+                         "copy_GBps": round(gbps(lambda: pb.copy_(pa), 2 * nel * 4)),
+                         "read_GBps": round(gbps(lambda: pa.sum(), nel * 4))}
+                del pa, pb
+                out["roofline"]["hbm_probe"] = probe
+                kind = {"thin_conv_fwd": "fill", "adam_multi": "copy", "bn_apply": "copy", "bn_bwd_apply": "copy",
+                        "upsample2_fwd": "fill", "maxpool2_fwd": "copy", "maxpool2_bwd": "copy", "upsample2_bwd": "copy"}
+                for tag, e in hbm.items():
+                    if "GBps" in e:
+                        k = kind.get(tag, "read")
+                        e["frac_of_probe"] = round(e["GBps"] / probe[k + "_GBps"], 3)
+                        e["probe"] = k
+            except Exception as e:
+                out["roofline"]["hbm_probe"] = {"failed": repr(e)}
             # the pose critic's k7 TemporalBlock convs (phase3/archis/default.py:207-210; Cout = 128, K = 128 * 7, the
             # weight gradient with its bias column): 5 GFLOP launches that cannot fill 256 CUs x 5 resident workgroups
             #  - their own rate, next to the engine average they pull down

@@ -514,7 +514,8 @@ struct TcnWgradCfg {
   static constexpr int LDD = KC + 1;               // dy image row (odd: the 32 rows of a fragment read hit 32 banks)
   static constexpr int XW = KC + 2 * PAD;          // x image columns
   static constexpr int LDXW = XW | 1;              // odd
-  static constexpr int STAGE = 128 * LDD + 32 * LDXW;   // floats
+  static constexpr int STAGE_DATA = 128 * LDD + 32 * LDXW;
+  static constexpr int STAGE = STAGE_DATA + 16;          // floats (+ a dummy tail: where the staging pass's idle lanes write)
   static constexpr int AHEAD = 2;
   static constexpr int NSTEP = KC / 4;             // k-steps (2 positions each) per chunk and K half: 15
   static constexpr int TILE4 = KS * 4 * 256;       // float4 units of one partial tile: [tap][reg quad][wr][lane]
@@ -581,7 +582,7 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_wgrad_kernel(const M2dTcnWgrad
     const int e = tid + 512 * i;
     const int row = e / (KC / 4), c4 = e - row * (KC / 4);
     dy_off[i] = e < 128 * (KC / 4) ? (unsigned)((row * L + 4 * c4) * 4) : TCN_OOB;
-    dy_lds[i] = e < 128 * (KC / 4) ? row * LDD + 4 * c4 : -1;
+    dy_lds[i] = e < 128 * (KC / 4) ? row * LDD + 4 * c4 : Cfg::STAGE_DATA;   // (idle lanes: the stage's dummy tail - no branch)
   }
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_wgrad_kernel(const M2dTcnWgrad
     const bool ok = e < 32 * XW && cg * 32 + ci < Cin;
     x_off[i] = ok ? (unsigned)(((cg * 32 + ci) * L) * 4) : TCN_OOB;
     x_col[i] = col - PAD;
-    x_lds[i] = e < 32 * XW ? 128 * LDD + ci * LDXW + col : -1;
+    x_lds[i] = e < 32 * XW ? 128 * LDD + ci * LDXW + col : Cfg::STAGE_DATA + 4;
   }
   tcn_f32x4 rdv[NDY], rmv[DMASK ? NDY : 1];
   float rxv[NX];
@@ -615,19 +616,16 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_wgrad_kernel(const M2dTcnWgrad
     const float ms = p.dy_mask_slope;
 #pragma unroll
     for (int i = 0; i < NDY; ++i) {
-      if (dy_lds[i] >= 0) {
-        tcn_f32x4 v = rdv[i];
-        if constexpr (DMASK) {
+      tcn_f32x4 v = rdv[i];
+      if constexpr (DMASK) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= (rmv[i][j] > 0.f ? 1.f : ms);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) st[dy_lds[i] + j] = v[j];
+        for (int j = 0; j < 4; ++j) v[j] *= (rmv[i][j] > 0.f ? 1.f : ms);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st[dy_lds[i] + j] = v[j];
     }
 #pragma unroll
-    for (int i = 0; i < NX; ++i)
-      if (x_lds[i] >= 0) st[x_lds[i]] = rxv[i];
+    for (int i = 0; i < NX; ++i) st[x_lds[i]] = rxv[i];
   };
 
   f32x16 acc[KS];
@@ -636,7 +634,7 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_wgrad_kernel(const M2dTcnWgrad
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   // bias partials: workgroup cg row-sums the rows [cg rpg, (cg + 1) rpg) of its chunks (rpg = ceil(128 / groups));
-  // pass ps covers 32 of them, row 32 ps + tid / 16 (the lanes with tid % 16 == 0 hold the sums)
+  // pass ps covers 32 of them, row 32 ps + tid / 16, lane tid % 16 its columns c = tid % 16 (mod 16)
   const int rpg = (128 + (int)gridDim.x - 1) / (int)gridDim.x;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -660,7 +658,9 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_wgrad_kernel(const M2dTcnWgrad
   for (int ck = ck0; ck < ck1; ++ck) {
     const int cur = (ck - ck0) & 1;
     const bool more = ck + 1 < ck1;
+#ifndef TCN_X_NOSTAGE  // experiment (wrong results): the chunk loop without its loads / register -> LDS pass / bias partial
     if (more) load_chunk(ck + 1);                 // in flight under the MFMAs below
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const unsigned aa = a_base + (unsigned)(cur * STAGE * 4), bb = b_base + (unsigned)(cur * STAGE * 4);
     float fa[NSTEP], fw[NW];
@@ -674,6 +674,41 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_wgrad_kernel(const M2dTcnWgrad
         fw[2 * S + KS - 1] = tcn_ds_read<(2 * S + KS - 1) * 4>(bb);
       }
     };
+    // The chunk's non-MFMA work - the bias partial of this chunk, the register -> LDS pass of the NEXT chunk - is done by
+    // the two K halves at DIFFERENT points of their 15 k-steps (after step 3 / after step 10): the two waves of a SIMD are
+    // then never both away from the matrix pipe (at the end of the chunk, in step, it idled 1.8 us of every 8.2:
+    // tools/tcn_stamps.py). The pass uses compiler-visible LDS accesses: it is fenced (all fragment reads in flight
+    // waited for, nothing moved across) so that the counted waits of the k-steps stay exact.
+    auto staging = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // bias partial: this workgroup's share of the 128 rows of the chunk's dy image, 16 lanes per row, 32 rows per pass
+      const int n = ck / cpl;
+#ifndef TCN_X_NOBIAS
+      // (per-thread partials: the 16 lanes of a row meet once, after the last chunk - a cross-lane sum per chunk cost
+      // 0.6 us of every chunk's 8)
+      if (n >= p.bias_from) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          if (ps * 32 < rpg) {   // (uniform)
+            const int rl = ps * 32 + (tid >> 4);
+            const int row = cg * rpg + rl;
+            const float* drow = smem + cur * STAGE + (rl < rpg && row < 128 ? row : 0) * LDD;
+            const float keep = (rl < rpg && row < 128) ? 1.f : 0.f;
+            float sm_ = (drow[tid & 15] + drow[(tid & 15) + 16]) + drow[(tid & 15) + 32];
+            if ((tid & 15) + 48 < KC) sm_ += drow[(tid & 15) + 48];
+            bsum[ps] += keep * sm_;
+          }
+        }
+      }
+#endif
+#ifndef TCN_X_NOSTORE
+      if (more) store_chunk(smem + (cur ^ 1) * STAGE);
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int STAGE_AT0 = 3, STAGE_AT1 = 10;
     tcn_static_for<0, AHEAD>([&](auto s_) { issue_frag(s_); });
     tcn_static_for<0, NSTEP>([&](auto s_) {
       constexpr int S = decltype(s_)::value;
@@ -684,29 +719,15 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_wgrad_kernel(const M2dTcnWgrad
 #pragma unroll
       for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S], fw[2 * S + t], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-    });
-    // bias partial: this workgroup's share of the 128 rows of the chunk's dy image, 16 lanes per row, 32 rows per pass
-    {
-      const int n = ck / cpl;
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int rl = ps * 32 + (tid >> 4);
-        const int row = cg * rpg + rl;
-        float s = 0.f;
-        if (rl < rpg && row < 128) {
-          const float* drow = smem + cur * STAGE + row * LDD;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = (tid & 15) + 16 * j;
-            if (c < KC) s += drow[c];
-          }
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (n >= p.bias_from) bsum[ps] += s;
+#ifndef TCN_X_NOSTAGE
+      if constexpr (S == STAGE_AT0) {
+        if (kh == 0) staging();
       }
-    }
-    if (more) store_chunk(smem + (cur ^ 1) * STAGE);
+      if constexpr (S == STAGE_AT1) {
+        if (kh == 1) staging();
+      }
+#endif
+    });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -737,9 +758,12 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_wgrad_kernel(const M2dTcnWgrad
         dst[(t * 4 + q) * 256 + wr * 64 + lane] = v;
       }
   }
-  if ((tid & 15) == 0) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) part[(size_t)Cfg::TILE4 * 4 + ps * 32 + (tid >> 4)] = bsum[ps];
+  for (int ps = 0; ps < 4; ++ps) {
+    float v = bsum[ps];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((tid & 15) == 0) part[(size_t)Cfg::TILE4 * 4 + ps * 32 + (tid >> 4)] = v;
   }
 #ifdef M2D_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

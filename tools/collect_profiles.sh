@@ -9,11 +9,13 @@ TAG=${1:-r02}
 O=$R/gpurun_out
 cd $R
 python3 bench.py --dump-shapes $O/${TAG}_shapes_c3.csv > $O/${TAG}_bench_c3.json 2> $O/${TAG}_bench_c3.err
+python3 bench.py --config c2 --no-cpu-baseline --parity-check --dump-shapes $O/${TAG}_shapes_c2.csv > $O/${TAG}_bench_c2.json 2>> $O/${TAG}_bench_c3.err
 python3 bench.py --config c4 --no-cpu-baseline --dump-shapes $O/${TAG}_shapes_c4.csv > $O/${TAG}_bench_c4.json 2>> $O/${TAG}_bench_c3.err
 python3 bench.py --config c5 --no-cpu-baseline --dump-shapes $O/${TAG}_shapes_c5.csv > $O/${TAG}_bench_c5.json 2>> $O/${TAG}_bench_c3.err
 python3 bench.py --gpus 2 --backend gloo --same-device --batch 16 --steps 8 --warmup 8 --no-cpu-baseline --no-prof > $O/${TAG}_bench_dp2_gloo_1gpu.json 2>> $O/${TAG}_bench_c3.err
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-prof"
+# (--no-other-configs: the default workload alone - the c2 / c4 / c5 child processes would be traced into the same files)
+ARGS="$R/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-prof --no-other-configs"
 # one stream (no branch overlap, no generator pipelining): a kernel's duration is then its own, as in bench.py's roofline pass
 M2D_BRANCH_OVERLAP=0 M2D_GEN_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 $ARGS > $O/${TAG}_prof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_overlap -- python3 $ARGS > $O/${TAG}_prof_overlap.log 2>&1

@@ -28,8 +28,10 @@ conv_case(256, 300, 512, 25, 4, 11, 0)     # audio l5 fwd
 conv_case(32, 19200, 64, 25, 4, 11, 2)     # audio l2 bwd_weight
 conv_case(256, 300, 512, 25, 4, 11, 1)     # audio l5 bwd_data
 conv_case(512, 4, 1024, 4, 2, 1, 0, b=7680)  # encoder c5 fwd
-conv_case(128, 120, 128, 7, 1, 3, 0)       # TCN fwd
-conv_case(128, 120, 128, 7, 1, 3, 2)       # TCN bwd_weight
+conv_case(128, 120, 128, 7, 1, 3, 0, b=3 * B)   # pose critic k7, 3B rows: forward (csrc/tcn.hip, 96-column tiles)
+conv_case(128, 120, 128, 7, 1, 3, 1, b=3 * B)   # ... backward-data (the same kernel, taps flipped)
+conv_case(128, 120, 128, 7, 1, 3, 2, b=3 * B)   # ... weight gradient (m2d_tcn_wgrad_kernel + its reduction)
+conv_case(128, 120, 128, 7, 1, 3, 0)            # the B-row tangent (32-column tiles)
 # FETCH_SIZE calibration: m2d_bn_reduce_kernel reads every byte of its input exactly once.
 #   L = 2    -> dword loads (4 B per lane): 7680 x 1024 x 2 floats = 62.9 MB
 #   L = 4800 -> 16-B loads:                 64 x 64 x 4800 floats  = 78.6 MB

@@ -11,7 +11,8 @@ for g in sorted(glob.glob(root + '/g*')):
         continue
     for r in csv.DictReader(open(f[0])):
         k = int(r['Dispatch_Id'])
-        e = rows.setdefault(k, {"kernel": r['Kernel_Name'].split('(')[0].replace('void ', '')[:70], "grid": int(r['Grid_Size'])})
+        e = rows.setdefault(k, {"kernel": r['Kernel_Name'].split('(')[0].replace('void ', '')[:70], "grid": int(r['Grid_Size']),
+                                "wg": int(r.get('Workgroup_Size', 256) or 256)})
         e[r['Counter_Name']] = float(r['Counter_Value'])
     t = glob.glob(g + '/*/*kernel_trace.csv')
     if t and not dur:
@@ -21,7 +22,7 @@ out = []
 for k, v in rows.items():
     if not any(t in v["kernel"] for t in ('m2d', 'k_dl', 'k_guide')):  # (k_*: the kernels of tools/probes/gemm_ceiling.hip)
         continue
-    e = {"dispatch": k, "kernel": v["kernel"], "workgroups": v["grid"] // 256, "us": round(dur.get(k, 0.0), 1)}
+    e = {"dispatch": k, "kernel": v["kernel"], "workgroups": v["grid"] // max(v.get("wg", 256), 1), "us": round(dur.get(k, 0.0), 1)}
     gui = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     if gui > 0:
         e["mfma_busy_frac"] = round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / gui, 3)

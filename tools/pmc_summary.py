@@ -25,8 +25,16 @@ for k in sorted(fetch, key=lambda k: -fetch[k]):
     out[k] = {"launches": nf[k], "fetch_MB_per_launch_raw": round(fetch[k] / nf[k] / 1e3, 3),
               "fetch_MB_per_launch_x2": round(2 * fetch[k] / nf[k] / 1e3, 3),
               "write_MB_per_launch": round(write.get(k, 0.0) / max(nw.get(k, 1), 1) / 1e3, 3)}
-g = out.get('m2d_gemm_kernel', {})
-json.dump({"unit": "MB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE are KB)", "per_kernel": out,
-           "hbm_bytes_per_launch_uncorrected": 1e6 * (g.get("fetch_MB_per_launch_raw", 0) + g.get("write_MB_per_launch", 0)),
-           "hbm_bytes_per_launch_fetch_x2": 1e6 * (g.get("fetch_MB_per_launch_x2", 0) + g.get("write_MB_per_launch", 0))},
+# the engine family = what bench.py's `roofline` prices (every dense-contraction kernel: the gather GEMM kernels, the
+# tap-vectorised and phase-major conv kernels, the split-K reduction, the TemporalBlock kernels of csrc/tcn.hip)
+ENGINE = ("m2d_gemm", "m2d_conv_k4", "m2d_splitk_reduce", "m2d_tcn_")
+fam_f = sum(v for k, v in fetch.items() if k.startswith(ENGINE))
+fam_w = sum(v for k, v in write.items() if k.startswith(ENGINE))
+fam_n = sum(v for k, v in nf.items() if k.startswith(ENGINE) and "reduce" not in k)   # (a reduction belongs to its GEMM's launch)
+fam = {"launches": fam_n, "fetch_MB_per_launch_raw": round(fam_f / max(fam_n, 1) / 1e3, 3),
+       "fetch_MB_per_launch_x2": round(2 * fam_f / max(fam_n, 1) / 1e3, 3), "write_MB_per_launch": round(fam_w / max(fam_n, 1) / 1e3, 3),
+       "fetch_GB_total_x2": round(2 * fam_f / 1e6, 3), "write_GB_total": round(fam_w / 1e6, 3)}
+json.dump({"unit": "MB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE are KB)", "engine_family": fam, "per_kernel": out,
+           "hbm_bytes_per_launch_uncorrected": 1e6 * (fam["fetch_MB_per_launch_raw"] + fam["write_MB_per_launch"]),
+           "hbm_bytes_per_launch_fetch_x2": 1e6 * (fam["fetch_MB_per_launch_x2"] + fam["write_MB_per_launch"])},
           sys.stdout, indent=1)

@@ -5,5 +5,5 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/music2dance_amd/lib_$TAG
 mkdir -p $OUT
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c $ROOT/music2dance_amd/csrc/tcn.hip -o $OUT/tcn.o || exit 1
-OBJS=$(ls $ROOT/music2dance_amd/lib/obj/*.o | grep -v /tcn.o)
+OBJS=$(ls $ROOT/music2dance_amd/lib/obj/*.o | grep -v "/tcn.o\|\.stamp\.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libm2d_hip.so $OBJS $OUT/tcn.o && rm -f $OUT/tcn.o && echo built $OUT/libm2d_hip.so
