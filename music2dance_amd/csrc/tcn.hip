@@ -277,9 +277,9 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
 #pragma unroll
     for (int jb = 0; jb < TN; ++jb) fb[SL][jb] = tcn_ds_read<BOFF>(bb[jb]);
   };
-  auto wait_frag = [&](auto SL_) {
+  auto wait_frag = [&](auto SL_, auto N_) {
     constexpr int SL = decltype(SL_)::value;
-    constexpr int N = NFRAG * AHEAD;
+    constexpr int N = decltype(N_)::value;
     if constexpr (RB == 1 && TN == 1) tcn_wait_frag<N>(fa[SL][0], fb[SL][0]);
     else if constexpr (RB == 1 && TN == 2) tcn_wait_frag<N>(fa[SL][0], fb[SL][0], fb[SL][1]);
     else if constexpr (RB == 1 && TN == 3) tcn_wait_frag<N>(fa[SL][0], fb[SL][0], fb[SL][1], fb[SL][2]);
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
         constexpr int SL = (T * NSTEP + S) % RING;
         constexpr int G2 = S + AHEAD;                       // the k-step AHEAD of this one
         issue_frag(std::integral_constant<int, T + G2 / NSTEP>{}, std::integral_constant<int, G2 % NSTEP>{}, c0, bb);
-        wait_frag(std::integral_constant<int, SL>{});
+        wait_frag(std::integral_constant<int, SL>{}, std::integral_constant<int, NFRAG * AHEAD>{});
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -335,9 +335,14 @@ __global__ void __launch_bounds__(512, 1) m2d_tcn_conv_kernel(const M2dTcnConv p
     });
   }
   TCN_STAMP_AT(2);
-  // drain: the dummy chunks past the end, the read-ahead of the steps past the end
+  // drain: the read-ahead of the steps past the end, the dummy chunks past the end. The wait for the reads is TIED to every
+  // register of the fragment ring: nothing consumes the last AHEAD steps' reads, so without the tie the compiler treats their
+  // destination registers as free from the ds_read on and hands them to the epilogue's address arithmetic while the reads
+  // are still in flight - under LDS contention (another kernel's workgroup on the same CU) they landed late and overwrote it
+  // (round 6: wrong 16 x 12 blocks of a tile in 1 of 5 launches beside a GEMM on another stream, two memory faults; never
+  // alone on the chip - tools/tcn_determinism.py)
+  tcn_static_for<0, RING>([&](auto sl_) { wait_frag(sl_, std::integral_constant<int, 0>{}); });
   tcn_wait_vm<0>();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: 16-byte pieces of rows (L % 4 == 0 and NT % 4 == 0: a piece never straddles a sample). The output mask

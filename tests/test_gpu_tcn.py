@@ -144,3 +144,30 @@ def test_temporal_conv_weight_gradient(shape):
     a = K().conv1d_bwd_weight(xd, dyd, 7, 1, 3)
     bb = K().conv1d_bwd_weight(xd, dyd, 7, 1, 3)
     assert torch.equal(a, bb)
+
+
+def test_results_do_not_depend_on_a_kernel_running_beside_them():
+    """A small launch (45 workgroups of 16 columns) repeated while a GEMM on another stream shares its CUs: bit-equal every
+    time. Round 6: the read-ahead past the last k-step landed, under LDS contention, in registers the compiler had already
+    reused for the epilogue's addresses - wrong 16 x 12 blocks in one launch of five, never when alone on the chip
+    (tools/tcn_determinism.py is the long form over every tile width)."""
+    B, L = 6, 120
+    x, dy = gen(B, 128, L, seed=11).to(DEV), gen(B, 128, L, seed=12).to(DEV)
+    w = gen(128, 128, 7, seed=13, scale=1.0 / math.sqrt(128 * 7)).to(DEV)
+    b = gen(128, seed=14, scale=0.1).to(DEV)
+    side = torch.cuda.Stream()
+    a = torch.randn(2048, 2048, device=DEV)
+    forms = [lambda: K().conv1d_fwd(x, w, b, 1, 3, act=1), lambda: K().conv1d_bwd_data(dy, w, L, 1, 3)]
+    with K().weight_cache():
+        refs = [f().clone() for f in forms]
+        torch.cuda.synchronize()
+        bad = [0, 0]
+        for i in range(150):
+            if i % 3 == 0:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        a @ a
+            for k, f in enumerate(forms):
+                bad[k] += int(not torch.equal(f(), refs[k]))
+        torch.cuda.synchronize()
+    assert bad == [0, 0], bad
