@@ -238,10 +238,13 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
     p.O.sum_out = sum_out;
     p.O.mask = out_mask;
     p.O.mask_slope = out_mask_slope;
-    if (stats) {
-      if (!ws || ws_bytes < m2d_rowstats_bytes(p.M, p.N)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd: no room for the statistics partials");
+    if (stats) {   // the statistics partials first, split-K slabs (one-launch form only) behind them
+      const size_t st = m2d_rowstats_bytes(p.M, p.N);
+      if (!ws || ws_bytes < st) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd: no room for the statistics partials");
       p.O.row_part = (float*)ws;
       p.O.row_sums = stats;
+      ws = (char*)ws + st;
+      ws_bytes -= st;
     }
     return m2d_gemm_launch(p, true, true, true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_fwd");
   }
@@ -286,10 +289,13 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
   p.O.sum_out = sum_out;
   p.O.mask = out_mask;
   p.O.mask_slope = out_mask_slope;
-  if (stats) {  // no split-K with statistics, so the slab room holds the partials
-    if (!ws || ws_bytes < m2d_rowstats_bytes(p.M, p.N)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd: no room for the statistics partials");
+  if (stats) {   // the statistics partials first, split-K slabs (one-launch form only) behind them
+    const size_t st = m2d_rowstats_bytes(p.M, p.N);
+    if (!ws || ws_bytes < st) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd: no room for the statistics partials");
     p.O.row_part = (float*)ws;
     p.O.row_sums = stats;
+    ws = (char*)ws + st;
+    ws_bytes -= st;
   }
   return m2d_gemm_launch(p, /*a_kfast=*/!conv_uses_packed(Cin), /*b_kfast=*/false, /*allow_split=*/true,
                          ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_fwd");
@@ -446,10 +452,13 @@ int m2d_conv1d_fwd_k4(const float* x, const float* w_k4, const float* bias, floa
   p.O.sum_out = sum_out;
   p.O.mask = out_mask;
   p.O.mask_slope = out_mask_slope;
-  if (stats) {
-    if (!ws || ws_bytes < m2d_rowstats_bytes(p.M, p.N)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd_k4: no room for the statistics partials");
+  if (stats) {   // the statistics partials first, split-K slabs (one-launch form only) behind them
+    const size_t st = m2d_rowstats_bytes(p.M, p.N);
+    if (!ws || ws_bytes < st) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd_k4: no room for the statistics partials");
     p.O.row_part = (float*)ws;
     p.O.row_sums = stats;
+    ws = (char*)ws + st;
+    ws_bytes -= st;
   }
   return m2d_conv_k4_launch(p, /*allow_split=*/true, ws, ws_bytes, (hipStream_t)stream, "m2d_conv1d_fwd");
 }
@@ -900,16 +909,16 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
   if (m2d_thin_applicable(Cin, Cout, ks, stride))
     return which == 2 ? m2d_thin_bwd_weight_ws(B, Cout, ks, Lout) : (which == 0 ? m2d_thin_fwd_stats_ws(B, Lout) : 0);
   if (which == 0) {
-    // split-K slabs or (never both) the per-tile partials of the epilogue statistics
+    // split-K slabs behind the per-tile partials of the epilogue statistics
     if (Lout == 1 && pad == 0 && L == ks) {
       const size_t a = m2d_gemm_plan(Cout, B, m2d_chunks(1, Cin * ks), 1, true).ws_bytes, st = m2d_rowstats_bytes(Cout, B);
-      return a > st ? a : st;
+      return a + st;
     }
     const bool packed = conv_uses_packed(Cin);
     const int nch = packed ? m2d_chunks(ks, Cin) : m2d_chunks(Cin, ks);
     const size_t a = m2d_gemm_plan(Cout, B * Lout, nch, 1, true, packed ? fwd_tile_penalty(stride) : 1.f).ws_bytes;
     const size_t st = m2d_rowstats_bytes(Cout, B * Lout);
-    return (a > st ? a : st) + (packed ? pack_bytes(Cout, Cin, ks) : 0);
+    return a + st + (packed ? pack_bytes(Cout, Cin, ks) : 0);
   }
   if (which == 1) {
     if (Lout == 1 && pad == 0 && L == ks) return m2d_gemm_plan(B, Cin * ks, m2d_chunks(1, Cout), 1, true).ws_bytes;

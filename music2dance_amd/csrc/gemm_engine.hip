@@ -2039,6 +2039,19 @@ static void decide_fused(M2dGemmParams& p, int bm, int splits, const void* ws, s
   p.tickets = t;
 }
 
+// would decide_fused take this plan? (Launches with epilogue statistics may split K only in the one-launch form: the
+// workgroup that draws a tile's last ticket holds the whole K and runs the ordinary epilogue, statistics included; the
+// two-launch form's reduction kernel has no statistics pass.)
+static bool fused_possible(const M2dGemmParams& p, int bm, int splits, const void* ws, size_t ws_bytes, hipStream_t stream) {
+  M2dGemmParams q = p;
+  decide_fused(q, bm, splits, ws, ws_bytes, stream);
+  return q.tickets != nullptr;
+}
+static bool stats_split_enabled() {   // A/B lever
+  static const bool on = [] { const char* e = getenv("M2D_STATS_SPLIT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // M2D_TILE_MAP=0: tile id = workgroup id (A/B lever)
 static int tile_map_default() {
   static const int v = [] { const char* e = getenv("M2D_TILE_MAP"); return e ? atoi(e) : 1; }();
@@ -2126,7 +2139,8 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
   // bwd_data: the widest phase has ceil(ks / phases) taps
   const int nhi_max = p.bwd_data ? (p.ph_ks + p.phases - 1) / p.phases : p.nhi;
   const int nchunks = m2d_chunks(nhi_max, p.kdiv);
-  if (p.O.row_part) allow_split = false;  // the statistics come out of the tile epilogue
+  // the statistics come out of the tile epilogue: split K only where the last arriver of a tile runs it (fused_possible)
+  if (p.O.row_part && !stats_split_enabled()) allow_split = false;
   PlanCand cand[M2D_MAX_CAND];
   int nc = plan_candidates(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, allow_split, p.small_tile_penalty, cand, p.plan_kind);
   {
@@ -2134,6 +2148,7 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
     int k = 0;
     for (int i = 0; i < nc; ++i) {
       const size_t need = cand[i].splits > 1 ? (size_t)cand[i].splits * (size_t)p.M * (size_t)p.N * sizeof(float) : 0;
+      if (p.O.row_part && cand[i].splits > 1 && !fused_possible(p, cand[i].bm, cand[i].splits, ws, ws_bytes, stream)) continue;
       if (need == 0 || (ws != nullptr && ws_bytes >= need)) cand[k++] = cand[i];
     }
     if (k == 0) {
@@ -2259,12 +2274,15 @@ int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_b
     M2D_FAIL(M2D_ERR_RANGE, "%s: operand larger than 2 GiB (buffer addressing), empty, or no tap groups", what);
   if (p.M >= (1 << 24) || p.N >= (1 << 24)) M2D_FAIL(M2D_ERR_RANGE, "%s: extent >= 2^24", what);
   const int nchunks = (p.nhi * p.k4_ng + 3) / 4;
-  if (p.O.row_part) allow_split = false;
+  if (p.O.row_part && !stats_split_enabled()) allow_split = false;
   PlanCand cand[M2D_MAX_CAND];
   const int nc = plan_candidates(p.M, p.N, nchunks, 1, allow_split, 1.0, cand);
   int bm = 128, splits = 1;
   for (int i = 0; i < nc; ++i) {
     const size_t need = cand[i].splits > 1 ? (size_t)cand[i].splits * (size_t)p.M * (size_t)p.N * sizeof(float) : 0;
+    // (statistics: one-launch split-K only, see m2d_gemm_launch)
+    if (p.O.row_part && cand[i].splits > 1 &&
+        !fused_possible(p, cand[i].bm < 64 ? 64 : cand[i].bm, cand[i].splits, ws, ws_bytes, stream)) continue;
     if (need == 0 || (ws != nullptr && ws_bytes >= need)) {
       bm = cand[i].bm < 64 ? 64 : cand[i].bm;
       splits = cand[i].splits;

@@ -609,7 +609,10 @@ def test_conv1d_over_track_windows_equals_conv_on_materialised_slices(case):
 # ----------------------------------------------------------------------------------- BN statistics from the conv epilogue
 @pytest.mark.parametrize("case", [("enc.c1", 96, 32, 64, 64, 4, 2, 1), ("enc.c0-k250", 40, 1, 3200, 32, 250, 50, 124),
                                   ("wavegan.l1-thin", 12, 1, 3200, 32, 25, 4, 0), ("wavegan.l2", 6, 32, 794, 64, 25, 4, 0),
-                                  ("unet.cb", 5, 128, 200, 128, 3, 1, 1), ("odd", 7, 19, 37, 21, 5, 2, 2)],
+                                  ("unet.cb", 5, 128, 200, 128, 3, 1, 1), ("odd", 7, 19, 37, 21, 5, 2, 2),
+                                  # few tiles, long K: the planner splits K; the statistics then come from the tile's last
+                                  # arriver (one-launch split-K, csrc/gemm_engine.hip: fused_possible) - WaveGAN l4 at B = 32
+                                  ("wavegan.l4-splitK", 30, 128, 2560, 256, 25, 4, 11), ("splitK-8-tiles", 4, 256, 512, 256, 25, 4, 11)],
                          ids=lambda c: c[0])
 def test_conv1d_epilogue_statistics_and_bn_from_sums(case):
     """conv1d_fwd(with_stats) returns the per-channel sum / sum of squares of what it stored; BatchNorm
