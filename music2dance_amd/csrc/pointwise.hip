@@ -585,6 +585,39 @@ __global__ void __launch_bounds__(256) m2d_upsample2_fwd_row_kernel(const float*
   }
 }
 
+// Any L, C * L even: the pass in the FLAT index space of a sample. Output element 2 g, 2 g + 1 of a sample's flattened
+// (C, 2L) block come from input element g of its flattened (C, L) block (and a neighbour in the same row), so a thread
+// owns two consecutive inputs g, g + 1 (g even: one 8-byte load + the two neighbours) and writes their four outputs as
+// ONE 16-byte store at flat offset 2 g - every lane of a wave stores 16 contiguous bytes next to its neighbour's, whatever
+// L is (round 6: the U-Net's L = 25 and 50 went through 8-byte stores of the per-row kernel at 2.9 TB/s, L = 100 through
+// two interleaved 16-byte stores per thread at 3.4; a plain copy of that size runs 5.3, tools/hbm_sizes.py). Rows enter
+// only through the position p = g mod L (first / last element of a row). Same expression per output as the kernels
+// above: same bits.
+__global__ void __launch_bounds__(256) m2d_upsample2_fwd_flat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                     unsigned pairs_per_sample, size_t pairs, int L,
+                                                                     long long ypitch) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < pairs; v += (size_t)gridDim.x * 256) {
+    const size_t b = v / pairs_per_sample;
+    const unsigned g = 2u * (unsigned)(v - b * pairs_per_sample);   // flat input index inside the sample (even)
+    const float* xs = x + b * (size_t)(2u * pairs_per_sample);
+    const float2 c = *reinterpret_cast<const float2*>(xs + g);
+    const unsigned p0 = g % (unsigned)L;
+    const unsigned p1 = p0 + 1 == (unsigned)L ? 0u : p0 + 1;
+    // neighbours inside the rows (clamped reads stay inside the sample: the selects below never use a clamped value)
+    const float lft0 = p0 > 0 ? xs[g - 1] : 0.f;
+    const float rgt1 = p1 + 1 < (unsigned)L ? xs[g + 2] : c.y;
+    const float lft1 = c.x, rgt0 = p0 + 1 < (unsigned)L ? c.y : c.x;
+    float4 o;
+    o.x = p0 > 0 ? 0.25f * lft0 + 0.75f * c.x : 1.0f * c.x + 0.0f * rgt0;
+    o.y = 0.75f * c.x + 0.25f * rgt0;
+    // (p1 == 0: g + 1 starts the next row - its left neighbour is not c.x, and its right one is xs[g + 2] or itself)
+    o.z = p1 > 0 ? 0.25f * lft1 + 0.75f * c.y : 1.0f * c.y + 0.0f * rgt1;
+    o.w = 0.75f * c.y + 0.25f * rgt1;
+    float* ys = y + (ypitch > 0 ? b * (size_t)ypitch : b * (size_t)(4u * pairs_per_sample));
+    *reinterpret_cast<float4*>(ys + 2 * (size_t)g) = o;
+  }
+}
+
 // transpose of the interpolation: dx[i] = sum_j coef(j -> i) dy[j]; each input position
 // receives from at most 4 outputs (2i-1 .. 2i+2), gathered here so there are no atomics.
 __global__ void __launch_bounds__(256) m2d_upsample2_bwd_kernel(const float* dy, float* dx, size_t rows, int L) {
@@ -606,6 +639,39 @@ __global__ void __launch_bounds__(256) m2d_upsample2_bwd_kernel(const float* dy,
       if (i1 == p) g += w1 * d;
     }
     dx[i] = g;
+  }
+}
+
+// (rows * L) % 4 == 0: a thread owns four consecutive elements q .. q + 3 of the flattened dx (16-byte store); their own
+// output pairs are dy[2 q .. 2 q + 7] of the flattened dy (two 16-byte loads) plus one neighbour on either side. The
+// terms of an element are added in the order of the loop above (j = 2p - 2 .. 2p + 2): same bits.
+__global__ void __launch_bounds__(256) m2d_upsample2_bwd_flat_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                     size_t quads, int L) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < quads; v += (size_t)gridDim.x * 256) {
+    const size_t q = 4 * v;
+    const float4 a = *reinterpret_cast<const float4*>(dy + 2 * q);
+    const float4 b = *reinterpret_cast<const float4*>(dy + 2 * q + 4);
+    const float d[10] = {q > 0 ? dy[2 * q - 1] : 0.f, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w,
+                         v + 1 < quads ? dy[2 * q + 8] : 0.f};   // d[1 + k] = dy[2 q + k]
+    unsigned p = (unsigned)(q % (size_t)L);
+    const float dm2 = p == 1 ? dy[2 * q - 2] : 0.f;       // (element 0's j = 0 when it is the second of its row)
+    float4 o;
+    float* op = &o.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ev = d[1 + 2 * e], od = d[2 + 2 * e];   // dy[2p], dy[2p + 1] of this element's row
+      float g = 0.f;
+      if (p == 1) g += 0.0f * (e == 0 ? dm2 : d[e == 0 ? 0 : 2 * e - 1]);   // j = 0 of the row reaches i1 = 1 with weight 0
+      if (p >= 1) g += 0.25f * d[2 * e];                  // j = 2p - 1
+      g += p >= 1 ? 0.75f * ev : 1.0f * ev;               // j = 2p
+      if (p == 0 && L == 1) g += 0.0f * ev;
+      g += 0.75f * od;                                     // j = 2p + 1
+      if (p + 1 == (unsigned)L) g += 0.25f * od;           //   (i1 clamps onto p)
+      else g += 0.25f * d[3 + 2 * e];                      // j = 2p + 2
+      op[e] = g;
+      p = p + 1 == (unsigned)L ? 0u : p + 1;
+    }
+    *reinterpret_cast<float4*>(dx + q) = o;
   }
 }
 
@@ -892,7 +958,16 @@ int m2d_upsample2_fwd_to(const float* x, float* y, size_t B, int C, int L, long 
   const int Cp = dense ? 0 : C;
   const long long yp = dense ? 0 : y_batch_stride;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L, "upsample2_fwd");
-  if ((L & 3) == 0 && L <= 1024 && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && (yp & 3) == 0) {
+  static const bool flat_on = [] { const char* e = getenv("M2D_UPSAMPLE_FLAT"); return !(e && e[0] == '0'); }();   // A/B lever
+  const size_t per_sample = (size_t)C * L;
+  if (flat_on && (per_sample & 1) == 0 && per_sample < (1u << 30) && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && (yp & 3) == 0 &&
+      true) {
+    // (16-byte stores at flat offset 2 g, g even: aligned when every sample's block starts 16-byte aligned - dense blocks of
+    // 2 C L floats with C L even, or a pitch that is a multiple of 4)
+    const size_t pairs = B * (per_sample / 2);
+    hipLaunchKernelGGL(m2d_upsample2_fwd_flat_kernel, dim3(grid_for(pairs, 16384)), dim3(256), 0, stream, x, y,
+                       (unsigned)(per_sample / 2), pairs, L, yp);
+  } else if ((L & 3) == 0 && L <= 1024 && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && (yp & 3) == 0) {
     const size_t rpb = 256 / (L >> 2);
     hipLaunchKernelGGL(m2d_upsample2_fwd_vec_kernel, dim3(grid_for((rows + rpb - 1) / rpb * 256, 4096)), dim3(256), 0, stream,
                        x, y, rows, L, Cp, yp);
@@ -914,7 +989,12 @@ int m2d_upsample2_bwd(const float* dy, float* dx, size_t rows, int L, void* stre
   hipStream_t stream = (hipStream_t)stream_;
   if (rows == 0 || L <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_upsample2_bwd: bad shape");
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 0.0, 12.0 * rows * (double)L, "upsample2_bwd");
-  hipLaunchKernelGGL(m2d_upsample2_bwd_kernel, dim3(grid_for(rows * L, 4096)), dim3(256), 0, stream, dy, dx, rows, L);
+  static const bool flat_on = [] { const char* e = getenv("M2D_UPSAMPLE_FLAT"); return !(e && e[0] == '0'); }();   // A/B lever
+  if (flat_on && ((rows * (size_t)L) & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15u) == 0)
+    hipLaunchKernelGGL(m2d_upsample2_bwd_flat_kernel, dim3(grid_for(rows * L / 4, 16384)), dim3(256), 0, stream, dy, dx,
+                       rows * L / 4, L);
+  else
+    hipLaunchKernelGGL(m2d_upsample2_bwd_kernel, dim3(grid_for(rows * L, 4096)), dim3(256), 0, stream, dy, dx, rows, L);
   M2D_CHECK_LAUNCH("m2d_upsample2_bwd");
   return M2D_OK;
 }

@@ -466,6 +466,34 @@ def test_pool_upsample(L):
     (gref,) = torch.autograd.grad(ref, x64, dy.double())
     dx = K().upsample2_bwd(dy.to(DEV))
     assert rel_err(dx, gref) < 1e-6
+    # into a channel block of a wider buffer (the U-Net's skip concatenation made in place): same bits, neighbours untouched
+    wide = torch.full((B, 2 * C, 2 * L), 7.0, device=DEV)
+    K().upsample2_fwd(x.to(DEV), out=wide[:, C:])
+    assert torch.equal(wide[:, C:], got) and bool((wide[:, :C] == 7.0).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 1), (1, 2, 7), (5, 6, 3), (3, 1, 2), (4, 5, 25), (2, 7, 33)], ids=str)
+def test_upsample_row_ends_in_the_flat_kernels(shape):
+    """Odd lengths and rows of one to three elements: the flat-index kernels (csrc/pointwise.hip) meet a row end inside a
+    thread's pair / quad at every offset; non-finite inputs propagate as in torch (0 * inf at the clamped ends)."""
+    B, C, L = shape
+    x = gen(B, C, L, seed=5)
+    x[0, 0, 0] = float("inf")
+    x[-1, -1, -1] = float("nan")
+    up = torch.nn.Upsample(scale_factor=2, mode="linear", align_corners=False)
+    ref = up(x)
+    got = K().upsample2_fwd(x.to(DEV)).cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.equal(torch.isinf(got), torch.isinf(ref))
+    assert rel_err(torch.nan_to_num(got, 0.0, 0.0, 0.0), torch.nan_to_num(ref, 0.0, 0.0, 0.0).double()) < 1e-6
+    # and the flat kernels against the per-row kernels they replace where both exist (same expressions: same bits)
+    if (C * L) % 2 == 0:
+        rows = K().upsample2_fwd(x.view(1, B * C, L).to(DEV).view(B * C, 1, L)).view(B, C, 2 * L).cpu()   # C = 1: per-row kernel when L is odd
+        assert torch.equal(torch.nan_to_num(rows, 0.0, 1e30, -1e30), torch.nan_to_num(got, 0.0, 1e30, -1e30))
+    x2 = gen(B, C, L, seed=6)
+    x64 = x2.double().requires_grad_(True)
+    dy = gen(B, C, 2 * L, seed=7)
+    (gref,) = torch.autograd.grad(up(x64), x64, dy.double())
+    assert rel_err(K().upsample2_bwd(dy.to(DEV)), gref) < 1e-6
 
 
 def test_profiler_counts_gemm_launches():
