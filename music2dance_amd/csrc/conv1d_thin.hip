@@ -36,6 +36,8 @@ struct ThinArgs {
 // wave-private LDS image with coalesced 16-B loads, the x windows are read straight from
 // global memory (lanes 0-31 read 32 consecutive samples). HBM-bound: dy (+ mask) is read once.
 typedef float thin_f32x16 __attribute__((ext_vector_type(16)));
+typedef float thin_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned thin_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KS, int S, bool MASKED>
 __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArgs a) {
@@ -382,31 +384,40 @@ size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout) {
   return nblk * (Cout * ks + Cout) * sizeof(float);  // weight partials + bias partials
 }
 
-// Forward for Cout == 32 on the matrix pipe: per wave 32 channels x 32*NT consecutive positions as
-// NT 32x32 tiles of v_mfma_f32_32x32x2_f32, K = the k taps (13 steps for k = 25; the weights stay
-// in 13 registers per lane for the whole launch). 13 MFMAs per 4 KB of output instead of 25 vector
-// FMAs per output.
+// Forward for Cout == 32 on the matrix pipe: a tile = 32 channels x 32 consecutive positions of one sample = one 32x32
+// accumulator of v_mfma_f32_32x32x2_f32, K = the k taps (13 steps for k = 25; the weights stay in 13 registers per lane
+// for the whole launch). 13 MFMAs per 4 KB of output instead of 25 vector FMAs per output.
 //   A[row = lane & 31][k = 2*ks + (lane >> 5)] = W[row, k]
 //   B[k][col = lane & 31]                      = x[n, (l0 + col)*S - pad + k]
 //   C: col = lane & 31 (position), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (channel)
-// The accumulators go through a wave-private LDS image [channel][32*NT positions] so that the
-// epilogue reads the mask and writes the result as dwordx4 runs of 128*NT bytes per channel row
-// (measured at B = 64: 79 us plain / 107 us masked, against 71 / 161 us for dword accesses
-// straight from the accumulator layout, and ~117 us for the vector-ALU kernel).
-// REP: consecutive position groups per wave (round-3 experiment: letting the stores of group i drain under the
-// gathers and MFMAs of group i + 1 did not pay - see THIN_FWD_REP).
-template <int KS, int S, int NT, int REP>
-__global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
+// The accumulators go through a wave-private LDS image [channel][32 positions] so that the epilogue reads the mask and
+// writes the result as dwordx4 runs of 128 bytes per channel row (measured at B = 64: 79 us plain / 107 us masked,
+// against 71 / 161 us for dword accesses straight from the accumulator layout, and ~117 us for the vector-ALU kernel).
+// Round 6: PERSISTENT waves. With one tile per wave (38 400 waves at B = 64) the launch took 68 us plain / 87 us masked,
+// and 39 / 44 us of that with neither the gathers nor the stores compiled in (tools/thin_time.py, -DTHIN_X_NOGATHER
+// -DTHIN_X_NOSTORE): every wave paid the weight loads, the gather latency and its own store drain one after the other.
+// Now the grid is one full-occupancy round (8 workgroups per CU); a wave walks the tiles g, g + G, g + 2G, ... (G = waves
+// of the grid; the four waves of a workgroup hold four neighbouring tiles: 512 contiguous bytes per channel row) and
+// keeps the NEXT tile's 13 gathered x values (and this tile's mask rows) in flight under this tile's MFMAs, LDS round
+// trip and stores.
+// Instruction budget (the launch is ISSUE-bound, not HBM-bound: with neither gathers nor stores compiled in it still took
+// 39 of its 68 us): 13 MFMAs = 832 matrix-pipe cycles per tile, and the first version spent more than that again on
+// vector-ALU work per tile - per-element bounds selects of the gathers, 64-bit addresses, bias loads. Now: the gathers are
+// raw buffer loads off a per-sample descriptor (positions left of the sample wrap to huge offsets, positions right of it
+// exceed num_records: the range check returns 0.0, no selects), interior tiles (all 32 positions inside the row, 16-byte
+// aligned rows) take a pass with 32-bit offsets off a per-sample output descriptor and no per-element tests; the bias
+// values of a lane's four channel rows are loaded once per launch.
+template <int KS, int S>
+#ifndef THIN_WPE
+#define THIN_WPE 4
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(THIN_WPE, 8)))
+thin_fwd_mfma_kernel(const ThinArgs a, int tiles_per_row, int total_tiles) {
   constexpr int NS = (KS + 1) / 2;
-  constexpr int NP = 32 * NT;    // positions per wave
-  constexpr int LDP = NP + 4;
-  constexpr int LPR = NP / 4;    // lanes per channel row in the epilogue
-  constexpr int RPI = 64 / LPR;  // channel rows per store instruction
+  constexpr int LDP = 32 + 4;
   __shared__ float img[4][32 * LDP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c31 = lane & 31, h = lane >> 5;
-  const int n = blockIdx.y;
-  const float* xr = a.xT > 0 ? a.x + (size_t)(n / a.xT) * a.xS + (size_t)(n % a.xT) * a.xhop : a.x + (size_t)n * a.L;
   float* im = img[wave];
   float wa[NS];
 #pragma unroll
@@ -414,100 +425,178 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(const ThinArgs a) {
     const int k = 2 * ks + h;
     wa[ks] = k < KS ? a.w[c31 * KS + k] : 0.f;
   }
-  for (int rep = 0; rep < REP; ++rep) {
-  const int p0 = ((blockIdx.x * 4 + wave) * REP + rep) * NP;  // first position of this wave's group
-  if (p0 >= a.Lout) break;
-  float xb[2][NS];
-  auto fetch = [&](int t, float (&dst)[NS]) {
-    const int l = p0 + t * 32 + c31;
-    const int base = l * S - a.pad + h;
+  const int nwaves = gridDim.x * 4;
+  // Row starts are Lout floats apart: 16-byte stores need Lout % 4 == 0, 8-byte ones Lout % 2 == 0
+  // (WaveGAN's 794-position rows take the float2 path; odd lengths store scalars).
+  const int valign = (a.Lout % 4 == 0) ? 4 : (a.Lout % 2 == 0) ? 2 : 1;
+  const int cq = lane & 7;          // 8 lanes per channel row in the epilogue, 8 rows per store instruction
+  const int crow = lane >> 3;
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = a.bias ? a.bias[crow + 8 * i] : 0.f;
+  const float act_s = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : a.slope);   // max(v, 0) + s min(v, 0)
+  const float ms = a.mask_slope;
+  const unsigned row_bytes = (unsigned)a.Lout * 4u;
+  const unsigned sample_bytes = 32u * row_bytes;   // (launcher: 32 Lout floats < 2^29)
+  // the odd half's last tap pair reaches k = KS (odd KS): its weight is 0.0, but 0 x inf = NaN - that one operand is forced to 0
+  constexpr bool LAST_DEAD = (KS & 1) != 0;
+
+  auto fetch = [&](int tile, float (&dst)[NS]) {
+    const int n = tile / tiles_per_row;
+    const int p0 = (tile - n * tiles_per_row) * 32;
+    const float* xr = a.xT > 0 ? a.x + (size_t)(n / a.xT) * a.xS + (size_t)(n % a.xT) * a.xhop : a.x + (size_t)n * a.L;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xr, (short)0, (int)((unsigned)a.L * 4u), 0x00020000);
+    const int l = p0 + c31;
+    // (positions past the row's end: l >= Lout -> force out of range; their products are never stored)
+    const unsigned voff = l < a.Lout ? (unsigned)((l * S - a.pad + h) * 4) : 0x80000000u;
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) {
-      const int pos = base + 2 * ks;
-      dst[ks] = (2 * ks + h < KS && l < a.Lout && pos >= 0 && pos < a.L) ? xr[pos] : 0.f;
+#ifdef THIN_X_NOGATHER   // experiment (wrong results): no x gathers
+      dst[ks] = (float)((voff + ks) & 7);
+#else
+      dst[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff + 8 * ks, 0, 0));
+#endif
     }
+    if (LAST_DEAD && h == 1) dst[NS - 1] = 0.f;
   };
-  fetch(0, xb[0]);
+  auto process = [&](int tile, const float (&xb)[NS]) {
+    const int n = tile / tiles_per_row;
+    const int p0 = (tile - n * tiles_per_row) * 32;
+    const bool interior = valign == 4 && p0 + 32 <= a.Lout;   // (uniform)
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * 32 * a.Lout), (short)0, (int)sample_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)((a.mask ? a.mask : a.out) + (size_t)n * 32 * a.Lout), (short)0,
+                                                                        (int)(a.mask ? sample_bytes : 0u), 0x00020000);
+    const unsigned eo = (unsigned)crow * row_bytes + (unsigned)(p0 + 4 * cq) * 4u;   // channel row crow + 8 i: + 8 i row_bytes
+    // this tile's mask rows, fetched before the MFMAs (interior tiles; the other path reads them in place)
+    thin_f32x4 mk[4];
+    if (interior && a.mask) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t + 1 < NT) fetch(t + 1, xb[(t + 1) & 1]);
+      for (int i = 0; i < 4; ++i)
+        mk[i] = __builtin_bit_cast(thin_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, (int)(eo + (unsigned)(8 * i) * row_bytes), 0, 0));
+    }
     thin_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < NS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ks], xb[t & 1][ks], acc, 0, 0, 0);
+    for (int ks = 0; ks < NS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ks], xb[ks], acc, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) im[((r & 3) + 8 * (r >> 2) + 4 * h) * LDP + t * 32 + c31] = acc[r];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // Row starts are Lout floats apart: 16-byte stores need Lout % 4 == 0, 8-byte ones Lout % 2 == 0
-  // (WaveGAN's 794-position rows take the float2 path; odd lengths store scalars).
-  const int valign = (a.Lout % 4 == 0) ? 4 : (a.Lout % 2 == 0) ? 2 : 1;
-  const int cq = lane % LPR;
-#pragma unroll 4
-  for (int i = 0; i < 32 / RPI; ++i) {
-    const int co = lane / LPR + RPI * i;
-    const float bv = a.bias ? a.bias[co] : 0.f;
-    const float4 q = *reinterpret_cast<const float4*>(im + co * LDP + 4 * cq);
-    float v[4] = {q.x + bv, q.y + bv, q.z + bv, q.w + bv};
-    const size_t o = ((size_t)n * 32 + co) * a.Lout + p0 + 4 * cq;
+    for (int r = 0; r < 16; ++r) im[((r & 3) + 8 * (r >> 2) + 4 * h) * LDP + c31] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (interior) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (a.act == 1) v[j] = v[j] > 0.f ? v[j] : 0.f;
-      else if (a.act == 2) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
-    }
-    const bool whole = p0 + 4 * cq + 4 <= a.Lout;
-    if (whole && valign == 4) {
-      if (a.mask) {
-        const float4 m = *reinterpret_cast<const float4*>(a.mask + o);
-        v[0] *= m.x > 0.f ? 1.f : a.mask_slope;
-        v[1] *= m.y > 0.f ? 1.f : a.mask_slope;
-        v[2] *= m.z > 0.f ? 1.f : a.mask_slope;
-        v[3] *= m.w > 0.f ? 1.f : a.mask_slope;
+      for (int i = 0; i < 4; ++i) {
+        const int co = crow + 8 * i;
+        const thin_f32x4 q = *reinterpret_cast<const thin_f32x4*>(im + co * LDP + 4 * cq);
+        thin_f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = q[j] + bv[i];
+          v[j] = fmaxf(t, 0.f) + act_s * fminf(t, 0.f);
+        }
+        if (a.mask) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= mk[i][j] > 0.f ? 1.f : ms;
+        }
+#ifdef THIN_X_NOSTORE    // experiment (wrong results): no output stores
+        if (v[0] == 12345.678f)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(thin_u32x4, v), ro, (int)(eo + (unsigned)(8 * i) * row_bytes), 0, 0);
+        if (a.stats) {  // wave-uniform: the 8 lanes of a channel row sum their stored values; one partial per (tile, channel)
+          float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+          float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+          for (int off = 4; off > 0; off >>= 1) {
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+          }
+          if (cq == 0) {
+            float* dst = a.stats + (size_t)tile * 64 + 2 * co;
+            dst[0] = s1;
+            dst[1] = s2;
+          }
+        }
       }
-      *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if (whole && valign == 2) {
-      if (a.mask) {
-        const float2 m0 = *reinterpret_cast<const float2*>(a.mask + o);
-        const float2 m1 = *reinterpret_cast<const float2*>(a.mask + o + 2);
-        v[0] *= m0.x > 0.f ? 1.f : a.mask_slope;
-        v[1] *= m0.y > 0.f ? 1.f : a.mask_slope;
-        v[2] *= m1.x > 0.f ? 1.f : a.mask_slope;
-        v[3] *= m1.y > 0.f ? 1.f : a.mask_slope;
-      }
-      *reinterpret_cast<float2*>(a.out + o) = make_float2(v[0], v[1]);
-      *reinterpret_cast<float2*>(a.out + o + 2) = make_float2(v[2], v[3]);
     } else {
+      // the last tile of a row, or rows that are not 16-byte aligned: per-element tests, 8-byte / scalar accesses
+      const bool whole = p0 + 4 * cq + 4 <= a.Lout;
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int co = crow + 8 * i;
+        const float4 q = *reinterpret_cast<const float4*>(im + co * LDP + 4 * cq);
+        const float b_ = i == 0 ? bv[0] : (i == 1 ? bv[1] : (i == 2 ? bv[2] : bv[3]));
+        float v[4] = {q.x + b_, q.y + b_, q.z + b_, q.w + b_};
+        const size_t o = ((size_t)n * 32 + co) * a.Lout + p0 + 4 * cq;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (p0 + 4 * cq + j < a.Lout) {
-          float y = v[j];
-          if (a.mask) y *= a.mask[o + j] > 0.f ? 1.f : a.mask_slope;
-          a.out[o + j] = y;
-          v[j] = y;
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f) + act_s * fminf(v[j], 0.f);
+        if (whole && valign == 4) {
+          if (a.mask) {
+            const float4 m = *reinterpret_cast<const float4*>(a.mask + o);
+            v[0] *= m.x > 0.f ? 1.f : ms;
+            v[1] *= m.y > 0.f ? 1.f : ms;
+            v[2] *= m.z > 0.f ? 1.f : ms;
+            v[3] *= m.w > 0.f ? 1.f : ms;
+          }
+          *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (whole && valign == 2) {
+          if (a.mask) {
+            const float2 m0 = *reinterpret_cast<const float2*>(a.mask + o);
+            const float2 m1 = *reinterpret_cast<const float2*>(a.mask + o + 2);
+            v[0] *= m0.x > 0.f ? 1.f : ms;
+            v[1] *= m0.y > 0.f ? 1.f : ms;
+            v[2] *= m1.x > 0.f ? 1.f : ms;
+            v[3] *= m1.y > 0.f ? 1.f : ms;
+          }
+          *reinterpret_cast<float2*>(a.out + o) = make_float2(v[0], v[1]);
+          *reinterpret_cast<float2*>(a.out + o + 2) = make_float2(v[2], v[3]);
         } else {
-          v[j] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (p0 + 4 * cq + j < a.Lout) {
+              float y = v[j];
+              if (a.mask) y *= a.mask[o + j] > 0.f ? 1.f : ms;
+              a.out[o + j] = y;
+              v[j] = y;
+            } else {
+              v[j] = 0.f;
+            }
+          }
+        }
+        if (a.stats) {
+          float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+          float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+          for (int off = 4; off > 0; off >>= 1) {
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+          }
+          if (cq == 0) {
+            float* dst = a.stats + (size_t)tile * 64 + 2 * co;
+            dst[0] = s1;
+            dst[1] = s2;
+          }
         }
       }
     }
-    if (a.stats) {  // wave-uniform: the LPR lanes of a channel row sum their stored values
-      float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-      float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-      for (int off = LPR / 2; off > 0; off >>= 1) {
-        s1 += __shfl_xor(s1, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
-      }
-      if (cq == 0) {
-        float* dst = a.stats + ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * REP + rep) * 64 + 2 * co;
-        dst[0] = s1;
-        dst[1] = s2;
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();  // the image is read before the next group overwrites it (one wave, in order)
+    __builtin_amdgcn_wave_barrier();  // the image is read before the next tile overwrites it (one wave, in order)
+  };
+
+  int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (tile >= total_tiles) return;
+  float xa[NS], xb2[NS];
+  fetch(tile, xa);
+#pragma unroll 1
+  for (;;) {
+    const int t2 = tile + nwaves;
+    if (t2 < total_tiles) fetch(t2, xb2);
+    process(tile, xa);
+    if (t2 >= total_tiles) break;
+    const int t3 = t2 + nwaves;
+    if (t3 < total_tiles) fetch(t3, xa);
+    process(t2, xb2);
+    if (t3 >= total_tiles) break;
+    tile = t3;
   }
 }
 
@@ -517,13 +606,17 @@ struct M2dWinView {
 
 int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, double* scratch, hipStream_t stream);  // gemm_engine.hip
 
-// per-wave partials + the scratch of the two-stage row sum (256 groups x 32 rows x fp64 pair)
-// measured (B = 64): REP = 4 -> 80 us plain / 122 us masked against 78 / 106 us for one group per wave: kept at 1
-#define THIN_FWD_REP 1
-static int thin_fwd_nt() { static const int v = [] { const char* e = getenv("M2D_THIN_NT"); return e ? atoi(e) : 1; }(); return v; }   // tiles of 32 positions per wave: 1 (default; the masked forward 104 -> 84 us, the plain one unchanged at 73) or 2
-static int thin_fwd_gridx(int Lout) { return m2d_ceil_div(Lout, 128 * thin_fwd_nt() * THIN_FWD_REP); }
-static size_t thin_fwd_stats_part(int B, int Lout) { return (size_t)B * thin_fwd_gridx(Lout) * 4 * THIN_FWD_REP * 64 * sizeof(float); }
+// per-tile partials + the scratch of the two-stage row sum (256 groups x 32 rows x fp64 pair)
+static int thin_fwd_tiles_per_row(int Lout) { return m2d_ceil_div(Lout, 32); }
+static size_t thin_fwd_stats_part(int B, int Lout) { return (size_t)B * thin_fwd_tiles_per_row(Lout) * 64 * sizeof(float); }
 size_t m2d_thin_fwd_stats_ws(int B, int Lout) { return thin_fwd_stats_part(B, Lout) + (size_t)256 * 32 * 2 * sizeof(double); }
+// workgroups of the persistent forward: one full-occupancy round (8 per CU: 18 KB of LDS, 35-50 registers), fewer when
+// there are not that many groups of four tiles. M2D_THIN_WG_PER_CU: A/B lever
+static int thin_fwd_grid(int total_tiles) {
+  static const int per_cu = [] { const char* e = getenv("M2D_THIN_WG_PER_CU"); const int v = e ? atoi(e) : THIN_WPE; return v >= 1 && v <= 64 ? v : THIN_WPE; }();
+  const int need = m2d_ceil_div(total_tiles, 4), full = 256 * per_cu;
+  return need < full ? need : full;
+}
 
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
                  int stride, int pad, int Lout, int act, float slope, const float* out_mask, float out_mask_slope,
@@ -531,11 +624,12 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   ThinArgs a;
   memset(&a, 0, sizeof(a));
   if (wv) { a.xT = wv->T; a.xS = wv->S; a.xhop = wv->hop; }
-  if (stats) {
+  const int tpr = thin_fwd_tiles_per_row(Lout);
+  if ((long long)B * tpr >= (1LL << 30) || (long long)Lout * 32 * 4 >= (1LL << 31) || (long long)L * 4 >= (1LL << 31))
+    M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd (thin): too many tiles / a sample beyond 2 GiB");
+  const int total = B * tpr;
+  if (stats) {   // (every tile writes its slot: nothing to zero)
     if (!ws || ws_bytes < m2d_thin_fwd_stats_ws(B, Lout)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd (thin): no room for the statistics partials");
-    // waves that return early (past the end of the row) leave their slots untouched: zero them
-    if (hipMemsetAsync(ws, 0, m2d_thin_fwd_stats_ws(B, Lout), stream) != hipSuccess)
-      M2D_FAIL(M2D_ERR_HIP, "m2d_conv1d_fwd (thin): memset failed");
     a.stats = (float*)ws;
   }
   a.x = x; a.w = w; a.bias = bias; a.mask = out_mask; a.out = y;
@@ -543,12 +637,10 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
-  if (thin_fwd_nt() == 1) hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 1, THIN_FWD_REP>), dim3(thin_fwd_gridx(Lout), B), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4, 2, THIN_FWD_REP>), dim3(thin_fwd_gridx(Lout), B), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4>), dim3(thin_fwd_grid(total)), dim3(256), 0, stream, a, tpr, total);
   M2D_CHECK_LAUNCH("thin_fwd_mfma_kernel");
   if (stats)
-    return m2d_rowsums_reduce(a.stats, B * thin_fwd_gridx(Lout) * 4 * THIN_FWD_REP, 32, stats,
-                              (double*)((char*)a.stats + thin_fwd_stats_part(B, Lout)), stream);
+    return m2d_rowsums_reduce(a.stats, total, 32, stats, (double*)((char*)a.stats + thin_fwd_stats_part(B, Lout)), stream);
   return M2D_OK;
 }
 

@@ -2151,6 +2151,10 @@ int m2d_gemm_launch(M2dGemmParams& p, bool a_kfast, bool b_kfast, bool allow_spl
       if (p.O.row_part && cand[i].splits > 1 && !fused_possible(p, cand[i].bm, cand[i].splits, ws, ws_bytes, stream)) continue;
       if (need == 0 || (ws != nullptr && ws_bytes >= need)) cand[k++] = cand[i];
     }
+    if (k == 0 && p.O.row_part && allow_split) {   // every plan of the model splits K beyond the one-launch form: plan without
+      nc = plan_candidates(p.M, p.N, nchunks, p.bwd_data ? p.phases : 1, false, p.small_tile_penalty, cand, p.plan_kind);
+      k = nc;
+    }
     if (k == 0) {
       if (nc > 0)
         M2D_FAIL(M2D_ERR_WORKSPACE, "%s: split-K needs %zu workspace bytes, got %zu", what,
