@@ -67,6 +67,16 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
   // fetch(d, lt): this lane's 8 x float4 of the dy tile starting at position lt (and its mask), and its share of the
   // tile's x window; positions past the chunk / outside the sample read as zero
   auto fetch = [&](float4 (&d4)[8], float (&xq)[(XW + 63) / 64], int lt) {
+#ifdef THIN_X_BW_NOLOAD   // experiment (wrong results): no global loads in the loop
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      d4[i] = make_float4((float)lt, 1.f, 2.f, (float)lane);
+      if (MASKED) mv[i] = make_float4(1.f, -1.f, 1.f, (float)(lane - 32));
+    }
+#pragma unroll
+    for (int i = 0; i < (XW + 63) / 64; ++i) xq[i] = (float)(lt + i);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int co = (lane >> 4) + 4 * i;
@@ -143,7 +153,11 @@ __global__ void __launch_bounds__(256) thin_bwd_weight_mfma_kernel(const ThinArg
     for (int j = 0; j < 32; ++j) {
       float av = xa[2 * S * j];
       if (KS < 32) av = i31 == 31 ? 1.f : av;
+#ifdef THIN_X_BW_NOMFMA   // experiment (wrong results)
+      acc[j & 15] += av * bb[2 * j];
+#else
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[2 * j], acc, 0, 0, 0);
+#endif
     }
     __builtin_amdgcn_wave_barrier();
   }
