@@ -39,6 +39,7 @@ struct BnReduceArgs {
   int B, C, L;
   int cpb;             // channels per block
   int rows_per_block;
+  int vec_rows;        // short rows read as 16-byte pieces, four samples per step (launch_reduce decides)
   int mode, act;
   float slope;
   // Self-cleaning accumulation (callers that pass a zero-kept scratch, m2d_bn_scratch_bytes): `acc` is that scratch,
@@ -149,6 +150,39 @@ __global__ void __launch_bounds__(256) m2d_bn_reduce_kernel(const BnReduceArgs a
     }
     s0 = (q0[0] + q0[1]) + (q0[2] + q0[3]);
     s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+  } else if (a.cpb > 1 && (a.L & 3) == 0 && (a.vec_rows != 0)) {
+    // short rows, several channels per block (the decoder / encoder BatchNorms of (B*T, C, L <= 128) activations): the
+    // block's P = cpb * L <= 256 contiguous floats of a sample are at most 64 16-byte pieces, so the 256 threads take
+    // FOUR samples per step (thread = (sample t / 64, piece t % 64)), four steps in flight - round 6: the scalar walk
+    // below read 4 bytes per lane and load (2.3-2.5 TB/s on the 126 MB backward sums of C3, the U-Net's L = 100 / 50)
+    const int piece = t & 63, rsub = t >> 6;
+    const int P4 = P >> 2;
+    if (piece < P4) {
+      const int c = c0 + (4 * piece) / a.L;
+      float g = 0.f, bt = 0.f, mu = 0.f, is = 0.f;
+      if (a.mode == 1) {
+        g = a.gamma[c];
+        bt = a.beta[c];
+        mu = a.mean[c];
+        is = a.invstd[c];
+      }
+      const size_t base = (size_t)c0 * a.L + 4 * piece;
+      float q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int n = n_begin + rsub; n < n_end; n += 4) {
+        const size_t idx = (size_t)n * row_stride + base;
+        const float4 xv = *reinterpret_cast<const float4*>(a.x + idx);
+        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), mv = dv;
+        if (a.mode == 1) dv = *reinterpret_cast<const float4*>(a.dy + idx);
+        if (a.mode == 2 && a.mask) mv = *reinterpret_cast<const float4*>(a.mask + idx);
+        bn_accum(a, xv.x, dv.x, mv.x, g, bt, mu, is, q0[0], q1[0]);
+        bn_accum(a, xv.y, dv.y, mv.y, g, bt, mu, is, q0[1], q1[1]);
+        bn_accum(a, xv.z, dv.z, mv.z, g, bt, mu, is, q0[2], q1[2]);
+        bn_accum(a, xv.w, dv.w, mv.w, g, bt, mu, is, q0[3], q1[3]);
+      }
+      s0 = (q0[0] + q0[1]) + (q0[2] + q0[3]);
+      s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+    }
   } else {
     for (int p = t; p < P; p += 256) {
       const int c = c0 + (a.cpb > 1 ? p / a.L : 0);
@@ -190,6 +224,14 @@ __global__ void __launch_bounds__(256) m2d_bn_reduce_kernel(const BnReduceArgs a
     // thread j < nch sums the L partials of its channel (L <= 256 / cpb)
     if (t < nch) {
       double r0 = 0.0, r1 = 0.0;
+      if ((a.L & 3) == 0 && (a.vec_rows != 0)) {   // partials at [sample slot][piece]: the channel's L / 4 pieces x 4 slots
+        const int L4 = a.L >> 2;
+        for (int rs = 0; rs < 4; ++rs)
+          for (int l = 0; l < L4; ++l) {
+            r0 += sh0[rs * 64 + t * L4 + l];
+            r1 += sh1[rs * 64 + t * L4 + l];
+          }
+      } else
       for (int l = 0; l < a.L; ++l) {
         r0 += sh0[t * a.L + l];
         r1 += sh1[t * a.L + l];
@@ -248,6 +290,11 @@ static int launch_reduce(BnReduceArgs& a, hipStream_t stream) {
   if (nsplit > 65535) nsplit = 65535;
   if (nsplit < 1) nsplit = 1;
   a.rows_per_block = m2d_ceil_div(a.B, nsplit);
+  {
+    static const bool on = [] { const char* e = getenv("M2D_BN_VEC_ROWS"); return !(e && e[0] == '0'); }();   // A/B lever
+    const uintptr_t al = (uintptr_t)a.x | (uintptr_t)(a.mode == 1 ? a.dy : a.x) | (uintptr_t)((a.mode == 2 && a.mask) ? a.mask : a.x);
+    a.vec_rows = (on && a.cpb > 1 && (a.L & 3) == 0 && (al & 15u) == 0) ? 1 : 0;
+  }
   nsplit = m2d_ceil_div(a.B, a.rows_per_block);
   if (!a.ticket && hipMemsetAsync(a.acc, 0, sizeof(double) * 2 * a.C, stream) != hipSuccess)
     M2D_FAIL(M2D_ERR_HIP, "bn reduce: memset failed");

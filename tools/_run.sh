@@ -1,7 +1,2 @@
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d /tmp/trace -- python3 $R/tools/steady.py 16 > /tmp/steady.log 2>&1
-grep -v rocprofv3 /tmp/steady.log | tail -3
-python tools/fill_timeline.py /tmp/trace 16 > gpurun_out/fill_timeline.txt 2>&1
-python tools/body_timeline.py /tmp/trace > gpurun_out/body_timeline.txt 2>&1
-head -45 gpurun_out/fill_timeline.txt
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_beside_another_stream.py -m gpu -q -x -k "bn or batch or norm or stats or channel_sums or beside" 2>&1 | tail -3
+for v in 0 1; do echo "M2D_BN_VEC_ROWS=$v"; M2D_BN_VEC_ROWS=$v python tools/bn_bwd_time.py 2>&1 | tail -25; done
