@@ -758,13 +758,25 @@ def main():
                          "read_GBps": round(gbps(lambda: pa.sum(), nel * 4))}
                 del pa, pb
                 out["roofline"]["hbm_probe"] = probe
+                # the same three passes at 4x the size: beyond the 256 MiB Infinity Cache (a 157 MB fill stays inside it);
+                # families whose launches move more than 256 MB are priced against THESE (round 6, tools/hbm_sizes.py)
+                nel2 = 4 * nel
+                pa, pb = torch.empty(nel2, device=device), torch.empty(nel2, device=device)
+                pa.fill_(1.0), pb.copy_(pa), pa.sum()
+                torch.cuda.synchronize()
+                probe_l = {"bytes": nel2 * 4, "fill_GBps": round(gbps(lambda: pa.fill_(2.0), nel2 * 4, 20)),
+                           "copy_GBps": round(gbps(lambda: pb.copy_(pa), 2 * nel2 * 4, 20)),
+                           "read_GBps": round(gbps(lambda: pa.sum(), nel2 * 4, 20))}
+                del pa, pb
+                out["roofline"]["hbm_probe_large"] = probe_l
                 kind = {"thin_conv_fwd": "fill", "adam_multi": "copy", "bn_apply": "copy", "bn_bwd_apply": "copy",
                         "upsample2_fwd": "fill", "maxpool2_fwd": "copy", "maxpool2_bwd": "copy", "upsample2_bwd": "copy"}
                 for tag, e in hbm.items():
                     if "GBps" in e:
                         k = kind.get(tag, "read")
-                        e["frac_of_probe"] = round(e["GBps"] / probe[k + "_GBps"], 3)
-                        e["probe"] = k
+                        big = e.get("MB_per_launch", 0) > 256
+                        e["frac_of_probe"] = round(e["GBps"] / (probe_l if big else probe)[k + "_GBps"], 3)
+                        e["probe"] = k + (" (629 MB)" if big else " (157 MB)")
             except Exception as e:
                 out["roofline"]["hbm_probe"] = {"failed": repr(e)}
             # the pose critic's k7 TemporalBlock convs (phase3/archis/default.py:207-210; Cout = 128, K = 128 * 7, the
