@@ -27,6 +27,10 @@ struct M2dWinView {
   int T, S, hop;
 };
 bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride);
+bool m2d_thin_long_applicable(int Cin, int Cout, int ks, int stride, int pad, int L);
+size_t m2d_thin_long_stats_ws(int B, int Lout);
+int m2d_thin_long_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int pad, int Lout, int act,
+                      float slope, const M2dWinView* wv, double* stats, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout);
 size_t m2d_thin_fwd_stats_ws(int B, int Lout);
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
@@ -211,6 +215,8 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
   if (Lout <= 0) M2D_FAIL(M2D_ERR_ARG, "m2d_conv1d_fwd: empty output (L=%d k=%d s=%d p=%d)", L, ks, stride, pad);
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd: tensor exceeds 2^31 elements");
+  if (!residual && !sum_out && !out_mask && m2d_thin_long_applicable(Cin, Cout, ks, stride, pad, L))
+    return m2d_thin_long_fwd(x, w, bias, y, B, L, pad, Lout, act, slope, wv, stats, ws, ws_bytes, (hipStream_t)stream);
   if (!residual && !sum_out && m2d_thin_applicable(Cin, Cout, ks, stride))
     return m2d_thin_fwd(x, w, bias, y, B, L, Cout, ks, stride, pad, Lout, act, slope, out_mask, out_mask_slope,
                         wv, stats, ws, ws_bytes, (hipStream_t)stream);
@@ -908,6 +914,12 @@ size_t m2d_conv1d_workspace_bytes(int which, int B, int Cin, int L, int Cout, in
   if (Lout <= 0) return 0;
   if (m2d_thin_applicable(Cin, Cout, ks, stride))
     return which == 2 ? m2d_thin_bwd_weight_ws(B, Cout, ks, Lout) : (which == 0 ? m2d_thin_fwd_stats_ws(B, Lout) : 0);
+  if (which == 0 && m2d_thin_long_applicable(Cin, Cout, ks, stride, pad, L)) {
+    // (a masked launch of this layer goes through the engine: room for both)
+    const size_t a = m2d_gemm_plan(Cout, B * Lout, m2d_chunks(Cin, ks), 1, true).ws_bytes + m2d_rowstats_bytes(Cout, B * Lout);
+    const size_t t = m2d_thin_long_stats_ws(B, Lout);
+    return a > t ? a : t;
+  }
   if (which == 0) {
     // split-K slabs behind the per-tile partials of the epilogue statistics
     if (Lout == 1 && pad == 0 && L == ks) {

@@ -658,6 +658,179 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   return M2D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The audio encoder's first conv, Conv1d(1, 32, 250, stride 50, pad 124) on 3 200-sample windows
+// (phase3/archis/default.py:64 of the reference; DefaultAudioEncoder.conv_layers[0]): Cin = 1 again, but K = 250 taps.
+// On the engine it is a 32-row GEMM with N = 491 520 at B = 64 (the 32-row tiles: 9.4 scalar instructions per MFMA,
+// MFMA busy 0.60): 163 us = 48 TFLOP/s in the step. Here a tile = 32 channels x 32 positions x all 250 taps = 125
+// v_mfma_f32_32x32x2_f32 in a row on one accumulator:
+//   A[row = channel c31][k = 2 ks + h] = W[c31][k]           from an LDS image of the weights [k][32] (block-shared, 32 KB)
+//   B[k][col = position c31]           = x[(p0 + c31) S - pad + k]   from the tile's x segment in LDS: (32 - 1) S + KS = 1 800
+//                                        consecutive samples of the window, zeros outside it (range-checked buffer loads)
+// The 125 k-steps are unrolled: every LDS offset is an instruction immediate. Persistent waves (8 per workgroup, one
+// workgroup per CU) walk the tiles g, g + G, ...; the NEXT tile's segment is fetched into registers (7 x 16 bytes per lane)
+// before this tile's MFMAs and written to LDS after them. Epilogue as the k25 kernel's interior pass: wave-private LDS image,
+// 16-byte stores (a window's 32 x 64 outputs are 8 KB contiguous), statistics partials per (tile, channel).
+template <int KS, int S>
+__global__ void __launch_bounds__(512) thin_long_fwd_kernel(const ThinArgs a, int tiles_per_row, int total_tiles) {
+  static_assert(KS % 2 == 0 && S % 2 == 0, "even taps / stride");
+  constexpr int NS = KS / 2;
+  constexpr int SEG = 31 * S + KS;             // samples a tile reads
+  constexpr int SEG4 = (SEG + 3) / 4;          // 16-byte pieces
+  constexpr int NP = (SEG4 + 63) / 64;         // pieces per lane
+  constexpr int LDP = 32 + 4;
+  constexpr int WAVE_FLOATS = SEG4 * 4 + 32 * LDP;
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  float* Ws = lsm;                             // [KS][32]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* xs = lsm + KS * 32 + wave * WAVE_FLOATS;
+  float* im = xs + SEG4 * 4;
+  const int c31 = lane & 31, h = lane >> 5;
+  for (int e = threadIdx.x; e < KS * 32; e += 512) {
+    const int k = e >> 5, c = e & 31;
+    Ws[e] = a.w[c * KS + k];
+  }
+  __syncthreads();
+  const int nwaves = gridDim.x * 8;
+  const int cq = lane & 7, crow = lane >> 3;
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = a.bias ? a.bias[crow + 8 * i] : 0.f;
+  const float act_s = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : a.slope);
+  const unsigned row_bytes = (unsigned)a.Lout * 4u;
+  const unsigned sample_bytes = 32u * row_bytes;
+
+  thin_f32x4 seg[NP];
+  auto fetch = [&](int tile) {
+    const int n = tile / tiles_per_row;
+    const int p0 = (tile - n * tiles_per_row) * 32;
+    const float* xr = a.xT > 0 ? a.x + (size_t)(n / a.xT) * a.xS + (size_t)(n % a.xT) * a.xhop : a.x + (size_t)n * a.L;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xr, (short)0, (int)((unsigned)a.L * 4u), 0x00020000);
+    // piece q of the segment = samples p0 S - pad + 4 q ..+3 (pad, S, L multiples of 4: a piece is inside the window or outside it)
+    const int first = p0 * S - a.pad;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = lane + 64 * i;
+      const unsigned voff = q < SEG4 ? (unsigned)((first + 4 * q) * 4) : 0x80000000u;
+      seg[i] = __builtin_bit_cast(thin_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0));
+    }
+  };
+  auto land = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = lane + 64 * i;
+      if (q < SEG4) *reinterpret_cast<thin_f32x4*>(xs + 4 * q) = seg[i];
+    }
+  };
+  int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 8 + wave);
+  if (tile >= total_tiles) return;
+  fetch(tile);
+  land();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float* ap = Ws + h * 32 + c31;
+  const float* bp = xs + c31 * S + h;
+#pragma unroll 1
+  for (;;) {
+    const int next = tile + nwaves;
+    if (next < total_tiles) fetch(next);
+    thin_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 64], bp[2 * ks], acc, 0, 0, 0);
+    const int n = tile / tiles_per_row;
+    const int p0 = (tile - n * tiles_per_row) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) im[((r & 3) + 8 * (r >> 2) + 4 * h) * LDP + c31] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (the segment's reads are done: the next one may land while the epilogue runs)
+    if (next < total_tiles) land();
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * 32 * a.Lout), (short)0, (int)sample_bytes, 0x00020000);
+    const unsigned eo = (unsigned)crow * row_bytes + (unsigned)(p0 + 4 * cq) * 4u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = crow + 8 * i;
+      const thin_f32x4 q = *reinterpret_cast<const thin_f32x4*>(im + co * LDP + 4 * cq);
+      thin_f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = q[j] + bv[i];
+        v[j] = fmaxf(t, 0.f) + act_s * fminf(t, 0.f);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(thin_u32x4, v), ro, (int)(eo + (unsigned)(8 * i) * row_bytes), 0, 0);
+      if (a.stats) {
+        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        if (cq == 0) {
+          float* dst = a.stats + (size_t)tile * 64 + 2 * co;
+          dst[0] = s1;
+          dst[1] = s2;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // image read, next segment landed: visible to the next tile's fragment reads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (next >= total_tiles) break;
+    tile = next;
+  }
+}
+
+static bool thin_long_enabled() {
+  static const bool on = [] { const char* e = getenv("M2D_THIN_LONG"); return !(e && e[0] == '0'); }();   // A/B lever
+  return on;
+}
+// Conv1d(1, 32, 250, 50, 124) on windows whose length and padding are multiples of 4 and whose output rows are whole
+// 32-position tiles
+bool m2d_thin_long_applicable(int Cin, int Cout, int ks, int stride, int pad, int L) {
+  if (!thin_long_enabled() || Cin != 1 || Cout != 32 || ks != 250 || stride != 50) return false;
+  if ((pad & 3) || (L & 3) || pad >= ks) return false;
+  const int Lout = (L + 2 * pad - ks) / stride + 1;
+  return Lout > 0 && Lout % 32 == 0;
+}
+size_t m2d_thin_long_stats_ws(int B, int Lout) { return (size_t)B * (Lout / 32) * 64 * sizeof(float) + (size_t)256 * 32 * 2 * sizeof(double); }
+
+int m2d_thin_long_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int pad, int Lout, int act,
+                      float slope, const M2dWinView* wv, double* stats, void* ws, size_t ws_bytes, hipStream_t stream) {
+  constexpr int KS = 250, S = 50;
+  ThinArgs a;
+  memset(&a, 0, sizeof(a));
+  if (wv) { a.xT = wv->T; a.xS = wv->S; a.xhop = wv->hop; }
+  const int tpr = Lout / 32;
+  if ((long long)B * tpr >= (1LL << 30) || (long long)Lout * 32 * 4 >= (1LL << 31) || (long long)L * 4 >= (1LL << 31))
+    M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd (k250): too many tiles / a sample beyond 2 GiB");
+  const int total = B * tpr;
+  const size_t part = (size_t)total * 64 * sizeof(float);
+  if (stats) {
+    if (!ws || ws_bytes < m2d_thin_long_stats_ws(B, Lout)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd (k250): no room for the statistics partials");
+    a.stats = (float*)ws;
+  }
+  a.x = x; a.w = w; a.bias = bias; a.out = y;
+  a.B = B; a.L = L; a.Cout = 32; a.ks = KS; a.stride = S; a.pad = pad; a.Lout = Lout;
+  a.act = act; a.slope = slope;
+  constexpr int SEG4 = (31 * S + KS + 3) / 4;
+  constexpr size_t lds = (size_t)(KS * 32 + 8 * (SEG4 * 4 + 32 * 36)) * sizeof(float);
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_long_fwd_kernel<KS, S>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  if (!attr_ok) M2D_FAIL(M2D_ERR_HIP, "m2d_conv1d_fwd (k250): cannot reserve %zu bytes of LDS", lds);
+  const int need = m2d_ceil_div(total, 8);
+  const int grid = need < 256 ? need : 256;
+  M2dProfScope prof(M2D_FAM_GEMM, stream, 2.0 * B * Lout * 32.0 * KS, 0.0, "m2d_conv1d_fwd", 32, B * Lout, KS);
+  hipLaunchKernelGGL((thin_long_fwd_kernel<KS, S>), dim3(grid), dim3(512), lds, stream, a, tpr, total);
+  M2D_CHECK_LAUNCH("thin_long_fwd_kernel");
+  if (stats) return m2d_rowsums_reduce(a.stats, total, 32, stats, (double*)((char*)a.stats + part), stream);
+  return M2D_OK;
+}
+
 int m2d_thin_bwd_data(const float* dy, const float* w, float* dx, int B, int L, int Cout, int ks, int stride,
                       int pad, int Lout, const float* dy_mask, float dy_mask_slope, hipStream_t stream) {
   ThinArgs a;

@@ -1,2 +1,6 @@
-timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_beside_another_stream.py -m gpu -q -x -k "bn or batch or norm or stats or channel_sums or beside" 2>&1 | tail -3
-for v in 0 1; do echo "M2D_BN_VEC_ROWS=$v"; M2D_BN_VEC_ROWS=$v python tools/bn_bwd_time.py 2>&1 | tail -25; done
+for v in 0 1 0 1; do echo "M2D_THIN_LONG=$v"; M2D_THIN_LONG=$v python bench.py --no-other-configs 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['whole_cycles']['value'], d['roofline']['frac'])"; done
+for v in 0 1 0 1; do echo "C2 M2D_THIN_LONG=$v"; M2D_THIN_LONG=$v python bench.py --config c2 --no-other-configs --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"; done
