@@ -170,6 +170,9 @@ struct M2dGemmParams {
   // workgroup -> tile map, set by the launcher (m2d_tile_of in gemm_engine.hip): 0 = tile id = workgroup id (N fastest),
   // 1 = XCD-aware grouped order (M2D_TILE_MAP=0 restores 0)
   int tile_map;
+  // set by the launcher: row statistics of one-element-per-lane tiles from a second, 16-byte read of the epilogue image
+  // instead of a 32-lane sum per element (M2D_STATS_NARROW_FAST=0: the round-5 form)
+  int stats_narrow_fast;
 };
 
 struct M2dGemmPlan {

@@ -522,8 +522,44 @@ __device__ __forceinline__ void m2d_tile_epilogue(const M2dGemmParams& p, const 
       {
         const float act_s = act == 0 ? 1.f : (act == 1 ? 0.f : O.slope);
         bool fast = !has_res && m_div <= 0;
-        if constexpr (!WIDE) fast = fast && !stats && __ballot(red_t[0]) == 0ull;
+        // (one element per lane: no redirect column in this tile; statistics only in the form that re-reads the image in
+        // 16-byte pieces below - no output mask, no position window)
+        if constexpr (!WIDE) fast = fast && (!stats || (!has_mask && c_lim <= 0 && (p.stats_narrow_fast != 0))) && __ballot(red_t[0]) == 0ull;
         if (fast) {
+          if constexpr (!WIDE) {
+            if (stats) {
+              // Row statistics of a one-element-per-lane tile (output rows that are not 16-byte aligned: WaveGAN's 193- and
+              // 794-position rows): the general pass sums a row over its 32 lanes with five shuffle steps per ELEMENT (160
+              // per tile and lane, round 5: those launches ran at 93 TFLOP/s against 110-118 for aligned rows). The image
+              // is still in LDS: read it once more the way the 16-byte pass does (lane -> row rl0 + 8 it, four columns),
+              // three shuffle steps per ROW PIECE. Same values as stored: activation applied, columns past N dropped.
+#pragma unroll
+              for (int jj = 0; jj < NT; ++jj) {
+                const int colb = n0 + wn * (TN * 32) + (j0 + jj) * 32 + c4;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                  const int rl = rl0 + 8 * it;
+                  float4 x = m2d_ld4(wl + jj * 1024 + rl * 32 + c4);
+                  x.x = colb + 0 < N ? fmaxf(x.x, 0.f) + act_s * fminf(x.x, 0.f) : 0.f;
+                  x.y = colb + 1 < N ? fmaxf(x.y, 0.f) + act_s * fminf(x.y, 0.f) : 0.f;
+                  x.z = colb + 2 < N ? fmaxf(x.z, 0.f) + act_s * fminf(x.z, 0.f) : 0.f;
+                  x.w = colb + 3 < N ? fmaxf(x.w, 0.f) + act_s * fminf(x.w, 0.f) : 0.f;
+                  float a1 = (x.x + x.y) + (x.z + x.w);
+                  float a2 = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+#pragma unroll
+                  for (int off = 4; off > 0; off >>= 1) {
+                    a1 += __shfl_xor(a1, off, 64);
+                    a2 += __shfl_xor(a2, off, 64);
+                  }
+                  if ((lane & 7) == 0 && rowb + rl < p.M) {
+                    float* dst = O.row_part + ((size_t)(((n0 / BN) * WN + wn) * TN + j0 + jj) * p.M + rowb + rl) * 2;
+                    dst[0] = a1;
+                    dst[1] = a2;
+                  }
+                }
+              }
+            }
+          }
           const __amdgpu_buffer_rsrc_t rso = m2d_rsrc(out_base, 0x7ffffffcu);
 #pragma unroll
           for (int jj = 0; jj < NT; ++jj) {
@@ -2052,6 +2088,10 @@ static bool stats_split_enabled() {   // A/B lever
   return on;
 }
 
+static int stats_narrow_fast_default() {   // A/B lever
+  static const int v = [] { const char* e = getenv("M2D_STATS_NARROW_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
+}
 // M2D_TILE_MAP=0: tile id = workgroup id (A/B lever)
 static int tile_map_default() {
   static const int v = [] { const char* e = getenv("M2D_TILE_MAP"); return e ? atoi(e) : 1; }();
@@ -2062,6 +2102,7 @@ static int tile_map_default() {
 static int plan_run(M2dGemmParams& p, int bm, int splits, bool a_kfast, bool b_kfast, void* ws, hipStream_t stream) {
   p.splits = splits;
   p.tile_map = tile_map_default();
+  p.stats_narrow_fast = stats_narrow_fast_default();
   p.slab = splits > 1 ? (float*)ws : nullptr;
   const int mt = m2d_ceil_div(p.M, bm);
   const long long nt = m2d_ceil_div(p.N, 128);
@@ -2295,6 +2336,7 @@ int m2d_conv_k4_launch(M2dGemmParams& p, bool allow_split, void* ws, size_t ws_b
   }
   p.splits = splits;
   p.tile_map = tile_map_default();
+  p.stats_narrow_fast = stats_narrow_fast_default();
   p.slab = splits > 1 ? (float*)ws : nullptr;
   decide_fused(p, bm, splits, ws, ws_bytes, stream);
   decide_wide(p, splits, ws);
