@@ -364,6 +364,7 @@ struct BnApplyArgs {
   long long out_pitch;    // elements between consecutive samples of `out` (>= row_len; the inputs are dense)
   int backward, act;
   float slope;
+  float* pool_out;        // forward, optional: MaxPool1d(2, 2) of the result as well, dense (B, C, L / 2) (L even)
 };
 
 // A thread owns ONE vector position of the (C, L) row and walks the batch: its channel(s) - one when L % 4 == 0, four
@@ -453,6 +454,106 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
     } else {
       a.out[odx] = ov[0];
     }
+    if constexpr (VEC >= 2) {
+      if (a.pool_out) {   // (a > b ? a : b, as m2d_maxpool2_fwd: the pairs of a row never straddle a vector - L is even)
+        const size_t pdx = (size_t)r * (size_t)(a.row_len >> 1) + (e0 >> 1);
+        if constexpr (VEC == 4)
+          *reinterpret_cast<float2*>(a.pool_out + pdx) = make_float2(ov[0] > ov[1] ? ov[0] : ov[1], ov[2] > ov[3] ? ov[2] : ov[3]);
+        else
+          a.pool_out[pdx] = ov[0] > ov[1] ? ov[0] : ov[1];
+      }
+    }
+  }
+}
+
+// BatchNorm apply + activation + Upsample(scale_factor=2, linear) in ONE pass (round 6; the U-Net's decoder levels without
+// an autograd graph: the normalised tensor is consumed by the upsampling alone - writing and re-reading it was 2 of the 5
+// tensor-sized transfers of the pair of passes). Flat index space of a sample as m2d_upsample2_fwd_flat_kernel
+// (csrc/pointwise.hip): a thread owns two consecutive inputs g, g + 1 and writes their four outputs as one 16-byte store;
+// here each input is normalised first ((x - mean) * invstd * gamma + beta, activation - the expression of
+// m2d_bn_apply_kernel, so the result equals bn_apply followed by upsample bit for bit). The channel of an element follows
+// from its flat index; the parameters come from the cache.
+__global__ void __launch_bounds__(256) m2d_bn_upsample2_flat_kernel(const BnApplyArgs a, unsigned pairs_per_sample, size_t pairs) {
+  const unsigned L = (unsigned)a.L;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < pairs; v += (size_t)gridDim.x * 256) {
+    const size_t b = v / pairs_per_sample;
+    const unsigned g = 2u * (unsigned)(v - b * pairs_per_sample);
+    const float* xs = a.x + b * (size_t)a.row_len;
+    const unsigned c0 = g / L, p0 = g - c0 * L;
+    const bool wrap = p0 + 1 == L;                 // g + 1 starts the next row
+    const unsigned p1 = wrap ? 0u : p0 + 1, c1 = wrap ? c0 + 1 : c0;
+    const float g0 = a.gamma[c0], b0 = a.beta[c0], m0 = a.mean[c0], i0 = a.invstd[c0];
+    const float g1 = a.gamma[c1], b1 = a.beta[c1], m1 = a.mean[c1], i1 = a.invstd[c1];
+    auto norm = [&](float x, float gg, float bb, float mm, float ii) {
+      const float xh = (x - mm) * ii;
+      const float z = gg * xh + bb;
+      float y = z;
+      if (a.act == 1) y = z > 0.f ? z : 0.f;
+      else if (a.act == 2) y = z > 0.f ? z : z * a.slope;
+      return y;
+    };
+    const float2 raw = *reinterpret_cast<const float2*>(xs + g);
+    const float n0 = norm(raw.x, g0, b0, m0, i0), n1 = norm(raw.y, g1, b1, m1, i1);
+    const float lft0 = p0 > 0 ? norm(xs[g - 1], g0, b0, m0, i0) : 0.f;
+    const float rgt1 = p1 + 1 < L ? norm(xs[g + 2], g1, b1, m1, i1) : n1;
+    const float lft1 = n0, rgt0 = p0 + 1 < L ? n1 : n0;
+    float4 o;
+    o.x = p0 > 0 ? 0.25f * lft0 + 0.75f * n0 : 1.0f * n0 + 0.0f * rgt0;
+    o.y = 0.75f * n0 + 0.25f * rgt0;
+    o.z = p1 > 0 ? 0.25f * lft1 + 0.75f * n1 : 1.0f * n1 + 0.0f * rgt1;
+    o.w = 0.75f * n1 + 0.25f * rgt1;
+    float* ys = a.out + b * (size_t)a.out_pitch;
+    *reinterpret_cast<float4*>(ys + 2 * (size_t)g) = o;
+  }
+}
+
+// The same for even L in m2d_bn_apply_kernel's organisation: a thread owns TWO consecutive positions of the (C, L) row -
+// one channel, its parameters in registers for the whole launch, the pair never straddles a row - and walks the batch:
+// 8-byte load + two neighbours, four outputs as one 16-byte store. No division and no parameter load in the loop
+// (the flat form above: 3.6-3.9 TB/s at the U-Net's L = 50 / 100 / 200; it stays for odd L).
+__global__ void __launch_bounds__(256) m2d_bn_upsample2_rows_kernel(const BnApplyArgs a, int B) {
+  const int rvl = a.row_len / 2;  // pairs per row
+  const int tid = threadIdx.x;
+  int pv, r0, rstep;
+  if (rvl >= 256) {
+    pv = blockIdx.x * 256 + tid;
+    if (pv >= rvl) return;
+    r0 = blockIdx.y;
+    rstep = gridDim.y;
+  } else {
+    const int rpb = 256 / rvl;
+    pv = tid % rvl;
+    const int rib = tid / rvl;
+    if (rib >= rpb) return;
+    r0 = blockIdx.y * rpb + rib;
+    rstep = gridDim.y * rpb;
+  }
+  const int e0 = 2 * pv;
+  const int c = e0 / a.L, p0 = e0 - c * a.L;
+  const float gg = a.gamma[c], bb = a.beta[c], mm = a.mean[c], ii = a.invstd[c];
+  const bool has_l = p0 > 0, has_r = p0 + 2 < a.L;
+  auto norm = [&](float x) {
+    const float xh = (x - mm) * ii;
+    const float z = gg * xh + bb;
+    float y = z;
+    if (a.act == 1) y = z > 0.f ? z : 0.f;
+    else if (a.act == 2) y = z > 0.f ? z : z * a.slope;
+    return y;
+  };
+#pragma unroll 2
+  for (int r = r0; r < B; r += rstep) {
+    const float* xp = a.x + (size_t)r * a.row_len + e0;
+    const float2 raw = *reinterpret_cast<const float2*>(xp);
+    const float lraw = has_l ? xp[-1] : 0.f, rraw = has_r ? xp[2] : 0.f;
+    const float n0 = norm(raw.x), n1 = norm(raw.y);
+    const float lft0 = norm(lraw);
+    const float rgt1 = has_r ? norm(rraw) : n1;
+    float4 o;
+    o.x = has_l ? 0.25f * lft0 + 0.75f * n0 : 1.0f * n0 + 0.0f * n1;
+    o.y = 0.75f * n0 + 0.25f * n1;
+    o.z = 0.25f * n0 + 0.75f * n1;
+    o.w = 0.75f * n1 + 0.25f * rgt1;
+    *reinterpret_cast<float4*>(a.out + (size_t)r * (size_t)a.out_pitch + 2 * (size_t)e0) = o;
   }
 }
 
@@ -463,6 +564,8 @@ static int launch_apply(BnApplyArgs& a, int B, hipStream_t stream) {
   const bool vec4 = (a.row_len % 4 == 0) && (a.L == 1 || a.L % 4 == 0) && (a.out_pitch % 4 == 0) && (((uintptr_t)a.out & 15) == 0);
   const bool vec2 = !vec4 && (a.row_len % 2 == 0) && (a.L == 1 || a.L % 2 == 0) && (a.out_pitch % 2 == 0) &&
                     (((uintptr_t)a.out & 7) == 0);  // e.g. the WaveGAN encoder's L = 794
+  if (a.pool_out && ((a.L & 1) || !(vec4 || vec2) || a.backward))
+    M2D_FAIL(M2D_ERR_ARG, "BatchNorm apply + max-pool: even L and 8-byte aligned rows");
   const int rvl = vec4 ? a.row_len / 4 : vec2 ? a.row_len / 2 : a.row_len;
   unsigned gx, gy;
   if (rvl >= 256) {
@@ -587,6 +690,78 @@ int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const floa
                     void* stream_) {
   return m2d_bn_fwd_sums_to(x, sums, count, gamma, beta, running_mean, running_var, y, save_mean, save_invstd, B, C, L, eps,
                             momentum, act, slope, residual, 0, stream_);
+}
+
+// The normalisation pass alone, from mean / invstd already finalised (m2d_bn_update_running's tmp, or the save_* of an
+// earlier call), with the pass that follows it in the U-Net fused in (phase3/archis/default.py:235-245 of the reference:
+// MaxPool1d(2, 2) after a skip's BatchNorm, Upsample(x2, linear) after a decoder level's):
+//   m2d_bn_apply_pool_to:      y = act(bn(x)) -> y (batch stride as m2d_bn_fwd_sums_to) AND pooled (B, C, L / 2), L even
+//   m2d_bn_apply_upsample2_to: up = upsample2(act(bn(x))) -> (B, C, 2L) at up + b * up_batch_stride; y itself is not written.
+//                              C * L even.
+int m2d_bn_apply_pool_to(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                         float* y, float* pooled, int B, int C, int L, int act, float slope, long long y_batch_stride,
+                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int rc = bn_check("m2d_bn_apply_pool_to", B, C, L)) return rc;
+  if (!pooled || (L & 1)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_apply_pool_to: even L and a pooled output");
+  BnApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.out_pitch = y_batch_stride;
+  a.x = x;
+  a.gamma = gamma; a.beta = beta;
+  a.mean = mean; a.invstd = invstd;
+  a.out = y;
+  a.pool_out = pooled;
+  a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
+  a.row_len = C * L;
+  a.act = act; a.slope = slope;
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.5 * 4.0 * B * C * (double)L, "bn_apply_pool", B, C, L);
+  return launch_apply(a, B, stream);
+}
+
+int m2d_bn_apply_upsample2_to(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                              float* up, int B, int C, int L, int act, float slope, long long up_batch_stride,
+                              void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int rc = bn_check("m2d_bn_apply_upsample2_to", B, C, L)) return rc;
+  const long long per = (long long)C * L;
+  if (up_batch_stride <= 0) up_batch_stride = 2 * per;
+  if ((per & 1) || up_batch_stride < 2 * per || (up_batch_stride & 3) || (((uintptr_t)x | (uintptr_t)up) & 15u))
+    M2D_FAIL(M2D_ERR_ARG, "m2d_bn_apply_upsample2_to: C * L even, 16-byte aligned samples");
+  BnApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.out_pitch = up_batch_stride;
+  a.x = x;
+  a.gamma = gamma; a.beta = beta;
+  a.mean = mean; a.invstd = invstd;
+  a.out = up;
+  a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
+  a.row_len = C * L;
+  a.act = act; a.slope = slope;
+  const size_t pairs = (size_t)B * (size_t)(per / 2);
+  size_t blocks = (pairs + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 3.0 * 4.0 * B * C * (double)L, "bn_apply_upsample2", B, C, L);
+  if ((L & 1) == 0) {
+    const int rvl = a.row_len / 2;
+    unsigned gx, gy;
+    if (rvl >= 256) {
+      gx = (unsigned)m2d_ceil_div(rvl, 256);
+      gy = 4096u / gx;
+      if (gy < 1) gy = 1;
+      if (gy > (unsigned)B) gy = (unsigned)B;
+    } else {
+      gx = 1;
+      gy = (unsigned)m2d_ceil_div(B, 256 / rvl);
+      if (gy > 4096u) gy = 4096u;
+    }
+    hipLaunchKernelGGL(m2d_bn_upsample2_rows_kernel, dim3(gx, gy), dim3(256), 0, stream, a, B);
+    M2D_CHECK_LAUNCH("m2d_bn_upsample2_rows_kernel");
+    return M2D_OK;
+  }
+  hipLaunchKernelGGL(m2d_bn_upsample2_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, (unsigned)(per / 2), pairs);
+  M2D_CHECK_LAUNCH("m2d_bn_upsample2_flat_kernel");
+  return M2D_OK;
 }
 
 // Training / eval forward of nn.BatchNorm1d fused with ReLU (act=1) / LeakyReLU (act=2)

@@ -124,6 +124,28 @@ class BatchNorm1d(nn.BatchNorm1d):
                               self.eps, self.momentum, act, slope, residual, sums if self.training else None, out)
 
     @torch.no_grad()
+    def forward_then(self, x, sums, then, act=ops.ACT_NONE, slope=0.0, out=None, then_out=None):
+        """No autograd graph, training mode, batch statistics handed over as `sums`: the normalisation with the pass
+        that follows it fused in (kernels.bn_apply_pool / bn_apply_upsample2; the U-Net, phase3/archis/default.py).
+        then = "pool":      -> (y, max_pool(y)); y into `out` (ops.batch_norm's)
+        then = "upsample":  -> upsample2_linear(y) into `then_out`; y itself is not produced.
+        Same values, same running-buffer update as forward() followed by the separate pass."""
+        if self.momentum is None or not self.affine or not self.track_running_stats:
+            raise NotImplementedError("m2d BatchNorm1d: only the reference's configuration is supported")
+        assert self.training and sums is not None and not torch.is_grad_enabled() and x.dim() == 3
+        if not _BN_COUNT_BATCHED[0]:
+            self.num_batches_tracked.add_(1)
+        from . import kernels
+        k = kernels.impl()
+        x = x.contiguous()
+        count = float(x.numel() // x.shape[1])
+        mean, invstd = k.bn_finalize(sums, count, self.running_mean, self.running_var, float(self.eps), float(self.momentum))
+        if then == "pool":
+            return k.bn_apply_pool(x, self.weight, self.bias, mean, invstd, int(act), float(slope), out=out)
+        assert then == "upsample"
+        return k.bn_apply_upsample2(x, self.weight, self.bias, mean, invstd, int(act), float(slope), out=then_out)
+
+    @torch.no_grad()
     def observe(self, x):
         """Advance the running statistics with a batch without producing an output graph
         (the dead fc1 -> bn1 branch of LinearBlock, phase3/archis/default.py:184-187)."""

@@ -33,10 +33,16 @@ _FUSED_BN_STATS = os.environ.get("M2D_FUSED_BN_STATS", "1") != "0"  # dev switch
 RELU_IN = (ops.ACT_RELU, 0.0)  # "my input is the sole-consumer output of a fused conv + ReLU" (ops.conv1d)
 
 
-def _conv_bn(conv, bn, x, act, slope=0.0, into=None):
+_FUSED_BN_THEN = os.environ.get("M2D_FUSED_BN_THEN", "1") != "0"  # A/B lever: the U-Net's pool / upsample inside the BatchNorm pass
+
+
+def _conv_bn(conv, bn, x, act, slope=0.0, into=None, then=None, then_out=None):
     """bn(conv(x)) + activation. In training mode the conv's epilogue hands the BatchNorm its batch
     statistics (no second pass over the activation); x may be a WindowView of the padded track
-    (first encoder conv: the audio windows are read in place). into: ops.batch_norm's `out`."""
+    (first encoder conv: the audio windows are read in place). into: ops.batch_norm's `out`.
+    then (no autograd graph only): the pass that follows in the U-Net - "pool": -> (y, max_pool(y)); "upsample": ->
+    upsample2_linear(y) written into `then_out` - made inside the normalisation pass when the batch statistics come from the
+    conv's epilogue (layers.BatchNorm1d.forward_then), by the separate kernels otherwise."""
     stats = bn.training and _FUSED_BN_STATS
     if isinstance(x, WindowView):
         out = conv.forward_windows(x.track, x.T, x.hop, x.window, with_stats=stats)
@@ -47,7 +53,19 @@ def _conv_bn(conv, bn, x, act, slope=0.0, into=None):
         # (SequenceGenerator.audio_path(keep=True): the batch statistics every BatchNorm of the audio path was advanced
         # with - None when this one computed its own: the path then cannot be replayed)
         _BN_SUMS_LOG[0].append((bn, sums if (stats and not ops.sync_batchnorm_active()) else None, y.numel() // y.shape[1]))
-    return bn(y, act=act, slope=slope, sums=sums, out=into)
+    if then is None:
+        return bn(y, act=act, slope=slope, sums=sums, out=into)
+    assert not torch.is_grad_enabled()
+    if _FUSED_BN_THEN and stats and not ops.sync_batchnorm_active() and y.dim() == 3:
+        L = y.shape[2]
+        if then == "pool" and L % 2 == 0:
+            return bn.forward_then(y, sums, "pool", act, slope, out=into)
+        if then == "upsample" and (y.shape[1] * L) % 2 == 0:
+            return bn.forward_then(y, sums, "upsample", act, slope, then_out=then_out)
+    z = bn(y, act=act, slope=slope, sums=sums, out=into)
+    if then == "pool":
+        return z, ops.maxpool2(z)
+    return ops.upsample2_linear(z, out=then_out)
 
 
 _BN_SUMS_LOG = [None]
@@ -155,8 +173,8 @@ class BasisConvBlock(nn.Module):
         self.bn = BatchNorm1d(channels_out)
         self.relu = nn.LeakyReLU(0.2)
 
-    def forward(self, x, out=None):
-        return _conv_bn(self.conv, self.bn, x, ops.ACT_LEAKY, 0.2, into=out)
+    def forward(self, x, out=None, then=None, then_out=None):
+        return _conv_bn(self.conv, self.bn, x, ops.ACT_LEAKY, 0.2, into=out, then=then, then_out=then_out)
 
 
 class UBlock(nn.Module):
@@ -183,15 +201,14 @@ class UBlock(nn.Module):
             cat1 = torch.empty((B, 2 * C, L), dtype=x.dtype, device=x.device)
             cat2 = torch.empty((B, 2 * C, L // 2), dtype=x.dtype, device=x.device)
             cat3 = torch.empty((B, 2 * C, L // 4), dtype=x.dtype, device=x.device)
-            d1 = self.convblock1(x, out=cat1[:, C:])
-            d2 = self.convblock2(ops.maxpool2(d1), out=cat2[:, C:])
-            d3 = self.convblock3(ops.maxpool2(d2), out=cat3[:, C:])
-            d4 = self.convblock4(ops.maxpool2(d3))
-            ops.upsample2_linear(d4, out=cat3[:, :C])
-            u3 = self.convblock5(cat3)
-            ops.upsample2_linear(u3, out=cat2[:, :C])
-            u2 = self.convblock6(cat2)
-            ops.upsample2_linear(u2, out=cat1[:, :C])
+            # (round 6: a skip's max-pool and a decoder level's upsampling are made inside the BatchNorm pass that
+            # produces their input - `then`: the normalised decoder tensors d4 / u3 / u2 are never written)
+            _, p1 = self.convblock1(x, out=cat1[:, C:], then="pool")
+            _, p2 = self.convblock2(p1, out=cat2[:, C:], then="pool")
+            _, p3 = self.convblock3(p2, out=cat3[:, C:], then="pool")
+            self.convblock4(p3, then="upsample", then_out=cat3[:, :C])
+            self.convblock5(cat3, then="upsample", then_out=cat2[:, :C])
+            self.convblock6(cat2, then="upsample", then_out=cat1[:, :C])
             return self.convblock7(cat1)
         d1 = self.convblock1(x)
         d2 = self.convblock2(ops.maxpool2(d1))

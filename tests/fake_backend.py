@@ -203,6 +203,23 @@ class FakeKernels:
         running_mean.mul_(1 - momentum).add_(momentum * mean64.float())
         running_var.mul_(1 - momentum).add_(momentum * var64.float() * (count / (count - 1) if count > 1 else 1.0))
 
+    def bn_finalize(self, sums, count, running_mean, running_var, eps, momentum):
+        mean64 = sums[0::2] / count
+        var64 = (sums[1::2] / count - mean64 * mean64).clamp_min(0.0)
+        self.bn_update_running(sums, count, running_mean, running_var, eps, momentum)
+        return mean64.float(), (1.0 / torch.sqrt(var64 + eps)).float()
+
+    def bn_apply_pool(self, x, gamma, beta, mean, invstd, act=0, slope=0.0, out=None):
+        shape = (1, -1, 1)
+        y = _act((x - mean.view(shape)) * invstd.view(shape) * gamma.view(shape) + beta.view(shape), act, slope)
+        y = self._into(out, y)
+        return y, F.max_pool1d(y, 2, 2)
+
+    def bn_apply_upsample2(self, x, gamma, beta, mean, invstd, act=0, slope=0.0, out=None):
+        shape = (1, -1, 1)
+        y = _act((x - mean.view(shape)) * invstd.view(shape) * gamma.view(shape) + beta.view(shape), act, slope)
+        return self._into(out, F.interpolate(y, scale_factor=2, mode="linear", align_corners=False))
+
     def _bn_dz(self, dy, x, gamma, beta, save_mean, save_invstd, act, slope):
         shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
         xh = (x - save_mean.view(shape)) * save_invstd.view(shape)
