@@ -29,8 +29,9 @@ struct M2dWinView {
 bool m2d_thin_applicable(int Cin, int Cout, int ks, int stride);
 bool m2d_thin_long_applicable(int Cin, int Cout, int ks, int stride, int pad, int L);
 size_t m2d_thin_long_stats_ws(int B, int Lout);
-int m2d_thin_long_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int pad, int Lout, int act,
-                      float slope, const M2dWinView* wv, double* stats, void* ws, size_t ws_bytes, hipStream_t stream);
+int m2d_thin_long_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int ks, int stride, int pad,
+                      int Lout, int act, float slope, const M2dWinView* wv, double* stats, void* ws, size_t ws_bytes,
+                      hipStream_t stream);
 size_t m2d_thin_bwd_weight_ws(int B, int Cout, int ks, int Lout);
 size_t m2d_thin_fwd_stats_ws(int B, int Lout);
 int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cout, int ks,
@@ -216,7 +217,7 @@ static int conv1d_fwd_impl(const float* x, const float* w, const float* w_packed
   if (!fits_i32((long long)B * Cin * L) || !fits_i32((long long)B * Cout * Lout))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd: tensor exceeds 2^31 elements");
   if (!residual && !sum_out && !out_mask && m2d_thin_long_applicable(Cin, Cout, ks, stride, pad, L))
-    return m2d_thin_long_fwd(x, w, bias, y, B, L, pad, Lout, act, slope, wv, stats, ws, ws_bytes, (hipStream_t)stream);
+    return m2d_thin_long_fwd(x, w, bias, y, B, L, ks, stride, pad, Lout, act, slope, wv, stats, ws, ws_bytes, (hipStream_t)stream);
   if (!residual && !sum_out && m2d_thin_applicable(Cin, Cout, ks, stride))
     return m2d_thin_fwd(x, w, bias, y, B, L, Cout, ks, stride, pad, Lout, act, slope, out_mask, out_mask_slope,
                         wv, stats, ws, ws_bytes, (hipStream_t)stream);

@@ -450,6 +450,7 @@ thin_fwd_mfma_kernel(const ThinArgs a, int tiles_per_row, int total_tiles) {
   for (int i = 0; i < 4; ++i) bv[i] = a.bias ? a.bias[crow + 8 * i] : 0.f;
   const float act_s = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : a.slope);   // max(v, 0) + s min(v, 0)
   const float ms = a.mask_slope;
+  double st1[4] = {0.0, 0.0, 0.0, 0.0}, st2[4] = {0.0, 0.0, 0.0, 0.0};   // statistics of this wave's tiles (a lane's share)
   const unsigned row_bytes = (unsigned)a.Lout * 4u;
   const unsigned sample_bytes = 32u * row_bytes;   // (launcher: 32 Lout floats < 2^29)
   // the odd half's last tap pair reaches k = KS (odd KS): its weight is 0.0, but 0 x inf = NaN - that one operand is forced to 0
@@ -517,20 +518,9 @@ thin_fwd_mfma_kernel(const ThinArgs a, int tiles_per_row, int total_tiles) {
         if (v[0] == 12345.678f)
 #endif
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(thin_u32x4, v), ro, (int)(eo + (unsigned)(8 * i) * row_bytes), 0, 0);
-        if (a.stats) {  // wave-uniform: the 8 lanes of a channel row sum their stored values; one partial per (tile, channel)
-          float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-          float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-          for (int off = 4; off > 0; off >>= 1) {
-            s1 += __shfl_xor(s1, off, 64);
-            s2 += __shfl_xor(s2, off, 64);
-          }
-          if (cq == 0) {
-            float* dst = a.stats + (size_t)tile * 64 + 2 * co;
-            dst[0] = s1;
-            dst[1] = s2;
-          }
-        }
+        // statistics: summed per lane over ALL the wave's tiles; the 8 lanes of a channel row meet once, at the end
+        st1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+        st2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
       }
     } else {
       // the last tile of a row, or rows that are not 16-byte aligned: per-element tests, 8-byte / scalar accesses
@@ -577,19 +567,13 @@ thin_fwd_mfma_kernel(const ThinArgs a, int tiles_per_row, int total_tiles) {
             }
           }
         }
-        if (a.stats) {
-          float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-          float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-          for (int off = 4; off > 0; off >>= 1) {
-            s1 += __shfl_xor(s1, off, 64);
-            s2 += __shfl_xor(s2, off, 64);
-          }
-          if (cq == 0) {
-            float* dst = a.stats + (size_t)tile * 64 + 2 * co;
-            dst[0] = s1;
-            dst[1] = s2;
-          }
+        {
+          const float t1 = (v[0] + v[1]) + (v[2] + v[3]);
+          const float t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          if (i == 0) { st1[0] += t1; st2[0] += t2; }
+          else if (i == 1) { st1[1] += t1; st2[1] += t2; }
+          else if (i == 2) { st1[2] += t1; st2[2] += t2; }
+          else { st1[3] += t1; st2[3] += t2; }
         }
       }
     }
@@ -597,7 +581,30 @@ thin_fwd_mfma_kernel(const ThinArgs a, int tiles_per_row, int total_tiles) {
   };
 
   int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
-  if (tile >= total_tiles) return;
+  const int gw = tile;   // this wave's slot of the statistics partials
+  auto flush_stats = [&]() {
+    if (!a.stats) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // (fp64 across the wave's tiles and lanes - a tile's four values per lane are summed in fp32 as before; the
+      // partial is rounded to fp32 once, when it is written: as accurate as the per-tile partials it replaces)
+      double s1 = st1[i], s2 = st2[i];
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
+      if (cq == 0) {
+        float* dst = a.stats + (size_t)gw * 64 + 2 * (crow + 8 * i);
+        dst[0] = (float)s1;
+        dst[1] = (float)s2;
+      }
+    }
+  };
+  if (tile >= total_tiles) {   // (a wave without a tile still owns a slot: zeros)
+    flush_stats();
+    return;
+  }
   float xa[NS], xb2[NS];
   fetch(tile, xa);
 #pragma unroll 1
@@ -612,6 +619,7 @@ thin_fwd_mfma_kernel(const ThinArgs a, int tiles_per_row, int total_tiles) {
     if (t3 >= total_tiles) break;
     tile = t3;
   }
+  flush_stats();
 }
 
 struct M2dWinView {
@@ -622,12 +630,14 @@ int m2d_rowsums_reduce(const float* part, int P, int M, double* sums, double* sc
 
 // per-tile partials + the scratch of the two-stage row sum (256 groups x 32 rows x fp64 pair)
 static int thin_fwd_tiles_per_row(int Lout) { return m2d_ceil_div(Lout, 32); }
-static size_t thin_fwd_stats_part(int B, int Lout) { return (size_t)B * thin_fwd_tiles_per_row(Lout) * 64 * sizeof(float); }
+// statistics partials: one (sum, sum of squares) pair per channel and WAVE of the grid (at most 256 x 16 workgroups x 4)
+#define THIN_FWD_MAX_WAVES (256 * 16 * 4)
+static size_t thin_fwd_stats_part(int B, int Lout) { (void)B; (void)Lout; return (size_t)THIN_FWD_MAX_WAVES * 64 * sizeof(float); }
 size_t m2d_thin_fwd_stats_ws(int B, int Lout) { return thin_fwd_stats_part(B, Lout) + (size_t)256 * 32 * 2 * sizeof(double); }
 // workgroups of the persistent forward: one full-occupancy round (8 per CU: 18 KB of LDS, 35-50 registers), fewer when
 // there are not that many groups of four tiles. M2D_THIN_WG_PER_CU: A/B lever
 static int thin_fwd_grid(int total_tiles) {
-  static const int per_cu = [] { const char* e = getenv("M2D_THIN_WG_PER_CU"); const int v = e ? atoi(e) : THIN_WPE; return v >= 1 && v <= 64 ? v : THIN_WPE; }();
+  static const int per_cu = [] { const char* e = getenv("M2D_THIN_WG_PER_CU"); const int v = e ? atoi(e) : THIN_WPE; return v >= 1 && v <= 16 ? v : THIN_WPE; }();
   const int need = m2d_ceil_div(total_tiles, 4), full = 256 * per_cu;
   return need < full ? need : full;
 }
@@ -642,7 +652,7 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   if ((long long)B * tpr >= (1LL << 30) || (long long)Lout * 32 * 4 >= (1LL << 31) || (long long)L * 4 >= (1LL << 31))
     M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd (thin): too many tiles / a sample beyond 2 GiB");
   const int total = B * tpr;
-  if (stats) {   // (every tile writes its slot: nothing to zero)
+  if (stats) {   // (every wave of the grid writes its slot: nothing to zero)
     if (!ws || ws_bytes < m2d_thin_fwd_stats_ws(B, Lout)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd (thin): no room for the statistics partials");
     a.stats = (float*)ws;
   }
@@ -651,10 +661,11 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
   a.act = act; a.slope = slope; a.mask_slope = out_mask_slope;
   M2dProfScope prof(M2D_FAM_POINTWISE, stream, 2.0 * B * Lout * (double)Cout * ks,
                     4.0 * B * ((double)L + (double)Cout * Lout * (out_mask ? 2 : 1)), "thin_conv_fwd", Cout, B * Lout, ks);
-  hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4>), dim3(thin_fwd_grid(total)), dim3(256), 0, stream, a, tpr, total);
+  const int grid = thin_fwd_grid(total);
+  hipLaunchKernelGGL((thin_fwd_mfma_kernel<25, 4>), dim3(grid), dim3(256), 0, stream, a, tpr, total);
   M2D_CHECK_LAUNCH("thin_fwd_mfma_kernel");
   if (stats)
-    return m2d_rowsums_reduce(a.stats, total, 32, stats, (double*)((char*)a.stats + thin_fwd_stats_part(B, Lout)), stream);
+    return m2d_rowsums_reduce(a.stats, grid * 4, 32, stats, (double*)((char*)a.stats + thin_fwd_stats_part(B, Lout)), stream);
   return M2D_OK;
 }
 
@@ -670,12 +681,13 @@ int m2d_thin_fwd(const float* x, const float* w, const float* bias, float* y, in
 // The 125 k-steps are unrolled: every LDS offset is an instruction immediate. Persistent waves (8 per workgroup, one
 // workgroup per CU) walk the tiles g, g + G, ...; the NEXT tile's segment is fetched into registers (7 x 16 bytes per lane)
 // before this tile's MFMAs and written to LDS after them. Epilogue as the k25 kernel's interior pass: wave-private LDS image,
-// 16-byte stores (a window's 32 x 64 outputs are 8 KB contiguous), statistics partials per (tile, channel).
+// 16-byte stores (a window's 32 x 64 outputs are 8 KB contiguous), statistics summed per wave over all its tiles.
 template <int KS, int S>
 __global__ void __launch_bounds__(512) thin_long_fwd_kernel(const ThinArgs a, int tiles_per_row, int total_tiles) {
   static_assert(KS % 2 == 0 && S % 2 == 0, "even taps / stride");
   constexpr int NS = KS / 2;
-  constexpr int SEG = 31 * S + KS;             // samples a tile reads
+  constexpr int SEG = 31 * S + KS + 3;         // samples a tile reads (+ up to 3 of lead-in: the segment starts on the
+                                               // window's 16-byte grid, `lead` = pad rounded up to 4, minus pad)
   constexpr int SEG4 = (SEG + 3) / 4;          // 16-byte pieces
   constexpr int NP = (SEG4 + 63) / 64;         // pieces per lane
   constexpr int LDP = 32 + 4;
@@ -686,6 +698,7 @@ __global__ void __launch_bounds__(512) thin_long_fwd_kernel(const ThinArgs a, in
   float* xs = lsm + KS * 32 + wave * WAVE_FLOATS;
   float* im = xs + SEG4 * 4;
   const int c31 = lane & 31, h = lane >> 5;
+  const int lead = ((a.pad + 3) & ~3) - a.pad;
   for (int e = threadIdx.x; e < KS * 32; e += 512) {
     const int k = e >> 5, c = e & 31;
     Ws[e] = a.w[c * KS + k];
@@ -706,8 +719,9 @@ __global__ void __launch_bounds__(512) thin_long_fwd_kernel(const ThinArgs a, in
     const int p0 = (tile - n * tiles_per_row) * 32;
     const float* xr = a.xT > 0 ? a.x + (size_t)(n / a.xT) * a.xS + (size_t)(n % a.xT) * a.xhop : a.x + (size_t)n * a.L;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xr, (short)0, (int)((unsigned)a.L * 4u), 0x00020000);
-    // piece q of the segment = samples p0 S - pad + 4 q ..+3 (pad, S, L multiples of 4: a piece is inside the window or outside it)
-    const int first = p0 * S - a.pad;
+    // piece q of the segment = samples p0 S - pad4 + 4 q ..+3, pad4 = pad rounded up to 4 (S, L multiples of 4: a piece
+    // is inside the window or outside it)
+    const int first = p0 * S - a.pad - lead;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int q = lane + 64 * i;
@@ -723,14 +737,38 @@ __global__ void __launch_bounds__(512) thin_long_fwd_kernel(const ThinArgs a, in
     }
   };
   int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 8 + wave);
-  if (tile >= total_tiles) return;
+  const int gw = tile;   // this wave's slot of the statistics partials
+  double st1[4] = {0.0, 0.0, 0.0, 0.0}, st2[4] = {0.0, 0.0, 0.0, 0.0};
+  auto flush_stats = [&]() {
+    if (!a.stats) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // (fp64 across the wave's tiles and lanes - a tile's four values per lane are summed in fp32 as before; the
+      // partial is rounded to fp32 once, when it is written: as accurate as the per-tile partials it replaces)
+      double s1 = st1[i], s2 = st2[i];
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
+      if (cq == 0) {
+        float* dst = a.stats + (size_t)gw * 64 + 2 * (crow + 8 * i);
+        dst[0] = (float)s1;
+        dst[1] = (float)s2;
+      }
+    }
+  };
+  if (tile >= total_tiles) {   // (a wave without a tile still owns a slot: zeros)
+    flush_stats();
+    return;
+  }
   fetch(tile);
   land();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const float* ap = Ws + h * 32 + c31;
-  const float* bp = xs + c31 * S + h;
+  const float* bp = xs + c31 * S + h + lead;
 #pragma unroll 1
   for (;;) {
     const int next = tile + nwaves;
@@ -762,20 +800,11 @@ __global__ void __launch_bounds__(512) thin_long_fwd_kernel(const ThinArgs a, in
         v[j] = fmaxf(t, 0.f) + act_s * fminf(t, 0.f);
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(thin_u32x4, v), ro, (int)(eo + (unsigned)(8 * i) * row_bytes), 0, 0);
-      if (a.stats) {
-        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-        for (int off = 4; off > 0; off >>= 1) {
-          s1 += __shfl_xor(s1, off, 64);
-          s2 += __shfl_xor(s2, off, 64);
-        }
-        if (cq == 0) {
-          float* dst = a.stats + (size_t)tile * 64 + 2 * co;
-          dst[0] = s1;
-          dst[1] = s2;
-        }
-      }
+      // statistics: a lane's four values of channel row crow + 8 i, summed over ALL the wave's tiles in registers; the
+      // eight lanes of a row meet once, after the last tile (one partial per (wave, channel): the tile -> wave assignment
+      // is fixed, so the sums are repeatable)
+      st1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+      st2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // image read, next segment landed: visible to the next tile's fragment reads
@@ -783,51 +812,72 @@ __global__ void __launch_bounds__(512) thin_long_fwd_kernel(const ThinArgs a, in
     if (next >= total_tiles) break;
     tile = next;
   }
+  flush_stats();
 }
 
 static bool thin_long_enabled() {
   static const bool on = [] { const char* e = getenv("M2D_THIN_LONG"); return !(e && e[0] == '0'); }();   // A/B lever
   return on;
 }
-// Conv1d(1, 32, 250, 50, 124) on windows whose length and padding are multiples of 4 and whose output rows are whole
-// 32-position tiles
+// Conv1d(1, 32, 250, 50, 124) (DefaultAudioEncoder) and Conv1d(1, 32, 160, 4, 79) (UNetAudioEncoder, phase3/archis/
+// default.py:210) on windows whose length is a multiple of 4 and whose output rows are whole 32-position tiles
+static int thin_long_kind(int Cin, int Cout, int ks, int stride) {
+  if (Cin != 1 || Cout != 32) return 0;
+  if (ks == 250 && stride == 50) return 1;
+  if (ks == 160 && stride == 4) return 2;
+  return 0;
+}
 bool m2d_thin_long_applicable(int Cin, int Cout, int ks, int stride, int pad, int L) {
-  if (!thin_long_enabled() || Cin != 1 || Cout != 32 || ks != 250 || stride != 50) return false;
-  if ((pad & 3) || (L & 3) || pad >= ks) return false;
+  if (!thin_long_enabled() || !thin_long_kind(Cin, Cout, ks, stride)) return false;
+  if ((L & 3) || pad < 0 || pad >= ks) return false;
   const int Lout = (L + 2 * pad - ks) / stride + 1;
   return Lout > 0 && Lout % 32 == 0;
 }
-size_t m2d_thin_long_stats_ws(int B, int Lout) { return (size_t)B * (Lout / 32) * 64 * sizeof(float) + (size_t)256 * 32 * 2 * sizeof(double); }
+// statistics partials: one (sum, sum of squares) pair per channel and WAVE of the grid (at most 512 workgroups x 8)
+#define THIN_LONG_MAX_WAVES (512 * 8)
+size_t m2d_thin_long_stats_ws(int B, int Lout) { (void)B; (void)Lout; return (size_t)THIN_LONG_MAX_WAVES * 64 * sizeof(float) + (size_t)256 * 32 * 2 * sizeof(double); }
 
-int m2d_thin_long_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int pad, int Lout, int act,
-                      float slope, const M2dWinView* wv, double* stats, void* ws, size_t ws_bytes, hipStream_t stream) {
-  constexpr int KS = 250, S = 50;
+template <int KS, int S>
+static int thin_long_launch(const ThinArgs& a, int tpr, int total, hipStream_t stream, int* waves) {
+  constexpr int SEG4 = (31 * S + KS + 3 + 3) / 4;
+  constexpr size_t lds = (size_t)(KS * 32 + 8 * (SEG4 * 4 + 32 * 36)) * sizeof(float);
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_long_fwd_kernel<KS, S>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  if (!attr_ok) M2D_FAIL(M2D_ERR_HIP, "m2d_conv1d_fwd (long single-channel kernel): cannot reserve %zu bytes of LDS", lds);
+  // one workgroup (8 waves) per CU, two when the LDS image is small enough for two to be resident
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int need = m2d_ceil_div(total, 8);
+  const int grid = need < 256 * per_cu ? need : 256 * per_cu;
+  *waves = grid * 8;
+  hipLaunchKernelGGL((thin_long_fwd_kernel<KS, S>), dim3(grid), dim3(512), lds, stream, a, tpr, total);
+  M2D_CHECK_LAUNCH("thin_long_fwd_kernel");
+  return M2D_OK;
+}
+
+int m2d_thin_long_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int ks, int stride, int pad,
+                      int Lout, int act, float slope, const M2dWinView* wv, double* stats, void* ws, size_t ws_bytes,
+                      hipStream_t stream) {
   ThinArgs a;
   memset(&a, 0, sizeof(a));
   if (wv) { a.xT = wv->T; a.xS = wv->S; a.xhop = wv->hop; }
   const int tpr = Lout / 32;
   if ((long long)B * tpr >= (1LL << 30) || (long long)Lout * 32 * 4 >= (1LL << 31) || (long long)L * 4 >= (1LL << 31))
-    M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd (k250): too many tiles / a sample beyond 2 GiB");
+    M2D_FAIL(M2D_ERR_RANGE, "m2d_conv1d_fwd (long single-channel kernel): too many tiles / a sample beyond 2 GiB");
   const int total = B * tpr;
-  const size_t part = (size_t)total * 64 * sizeof(float);
+  const size_t part = (size_t)THIN_LONG_MAX_WAVES * 64 * sizeof(float);
   if (stats) {
-    if (!ws || ws_bytes < m2d_thin_long_stats_ws(B, Lout)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd (k250): no room for the statistics partials");
+    if (!ws || ws_bytes < m2d_thin_long_stats_ws(B, Lout)) M2D_FAIL(M2D_ERR_WORKSPACE, "m2d_conv1d_fwd (long single-channel kernel): no room for the statistics partials");
     a.stats = (float*)ws;
   }
   a.x = x; a.w = w; a.bias = bias; a.out = y;
-  a.B = B; a.L = L; a.Cout = 32; a.ks = KS; a.stride = S; a.pad = pad; a.Lout = Lout;
+  a.B = B; a.L = L; a.Cout = 32; a.ks = ks; a.stride = stride; a.pad = pad; a.Lout = Lout;
   a.act = act; a.slope = slope;
-  constexpr int SEG4 = (31 * S + KS + 3) / 4;
-  constexpr size_t lds = (size_t)(KS * 32 + 8 * (SEG4 * 4 + 32 * 36)) * sizeof(float);
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_long_fwd_kernel<KS, S>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-  if (!attr_ok) M2D_FAIL(M2D_ERR_HIP, "m2d_conv1d_fwd (k250): cannot reserve %zu bytes of LDS", lds);
-  const int need = m2d_ceil_div(total, 8);
-  const int grid = need < 256 ? need : 256;
-  M2dProfScope prof(M2D_FAM_GEMM, stream, 2.0 * B * Lout * 32.0 * KS, 0.0, "m2d_conv1d_fwd", 32, B * Lout, KS);
-  hipLaunchKernelGGL((thin_long_fwd_kernel<KS, S>), dim3(grid), dim3(512), lds, stream, a, tpr, total);
-  M2D_CHECK_LAUNCH("thin_long_fwd_kernel");
-  if (stats) return m2d_rowsums_reduce(a.stats, total, 32, stats, (double*)((char*)a.stats + part), stream);
+  M2dProfScope prof(M2D_FAM_GEMM, stream, 2.0 * B * Lout * 32.0 * ks, 0.0, "m2d_conv1d_fwd", 32, B * Lout, ks);
+  int rc, waves = 0;
+  if (thin_long_kind(1, 32, ks, stride) == 1) rc = thin_long_launch<250, 50>(a, tpr, total, stream, &waves);
+  else rc = thin_long_launch<160, 4>(a, tpr, total, stream, &waves);
+  if (rc) return rc;
+  if (stats) return m2d_rowsums_reduce(a.stats, waves, 32, stats, (double*)((char*)a.stats + part), stream);
   return M2D_OK;
 }
 

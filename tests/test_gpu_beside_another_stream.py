@@ -44,7 +44,7 @@ def cases():
     for name, args in [("k25s4 64->128", (4, 64, 128, 1024, 25, 4, 11)), ("k25s4 16->32", (6, 16, 32, 2048, 25, 4, 11)),
                        ("k3 256->512", (40, 256, 512, 24, 3, 1, 1)), ("k4s2 32->64", (8, 32, 64, 500, 4, 2, 1)),
                        ("k25s4 1->32", (6, 1, 32, 4096, 25, 4, 11)), ("k25 69->128", (6, 69, 128, 120, 25, 1, 12)),
-                       ("k250s50 1->32", (24, 1, 32, 3200, 250, 50, 124))]:
+                       ("k250s50 1->32", (24, 1, 32, 3200, 250, 50, 124)), ("k160s4 1->32", (5, 1, 32, 3200, 160, 4, 79))]:
         for form, f in conv_case(*args).items():
             out["conv %s %s" % (name, form)] = f
     a, b, bias = gen(480, 256, seed=5), gen(256, 256, seed=6, scale=1 / 16.0), gen(256, seed=7)

@@ -640,6 +640,7 @@ def test_conv1d_over_track_windows_equals_conv_on_materialised_slices(case):
                                   ("unet.cb", 5, 128, 200, 128, 3, 1, 1), ("odd", 7, 19, 37, 21, 5, 2, 2),
                                   # few tiles, long K: the planner splits K; the statistics then come from the tile's last
                                   # arriver (one-launch split-K, csrc/gemm_engine.hip: fused_possible) - WaveGAN l4 at B = 32
+                                  ("unet.c0-k160", 10, 1, 3200, 32, 160, 4, 79),
                                   ("wavegan.l4-splitK", 30, 128, 2560, 256, 25, 4, 11), ("splitK-8-tiles", 4, 256, 512, 256, 25, 4, 11)],
                          ids=lambda c: c[0])
 def test_conv1d_epilogue_statistics_and_bn_from_sums(case):
