@@ -445,7 +445,10 @@ class HipKernels:
         # channel-sum pass over dy instead (M2D_SEPARATE_BIAS=0: always the column) - for short outputs and for up to four
         # column tiles; measured not to pay on the critic's layers (profiles/r05_separate_bias_shapes_diff.txt: the pose
         # critic's 896 + 1 columns 95.5 -> 89.2 us + a 22 us pass, the audio critic's 3 200 + 1 columns 567 -> 604 us).
-        sep_bias = (with_bias and self._SEPARATE_BIAS and (Cin * ks) % 128 == 0 and (Lout < 16 or Cin * ks <= 512)
+        # (round 6: also for up to eight column tiles when the launch is long - the U-Net's 256 -> 128 k3 blocks at
+        # 4 800 x 200 positions: 768 + 1 columns ran 7 tiles for 6.008, 2.46 ms at 77 TFLOP/s; the sum pass costs 0.12 ms)
+        sep_bias = (with_bias and self._SEPARATE_BIAS and (Cin * ks) % 128 == 0 and
+                    (Lout < 16 or Cin * ks <= 512 or (Cin * ks <= 1024 and B * Lout >= 200000))
                     and not self._thin(Cin, ks, stride) and _bn_scratch(dev, Cout) is not None)
         db = torch.empty((Cout,), dtype=torch.float32, device=dev) if (with_bias and not sep_bias) else None
         h = _lib.lib()
