@@ -224,17 +224,18 @@ int m2d_bn_fwd_sums_to(const float* x, const double* sums, double count, const f
                        float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, int B,
                        int C, int L, float eps, float momentum, int act, float slope, const float* residual,
                        long long y_batch_stride, void* stream);
-/* Round 6: the normalisation pass alone (mean / invstd finalised before: the tmp of m2d_bn_update_running, whose first C
- * floats are the batch mean and the next C 1 / sqrt(var + eps), or the save_* of an earlier call) with the pass that follows
- * it in the U-Net fused in (phase3/archis/default.py:235-245): MaxPool1d(2, 2) behind a skip's BatchNorm (y AND pooled are
- * written), Upsample(scale_factor=2, linear) behind a decoder level's (only the upsampled tensor is written). Same values
- * as m2d_bn_fwd_sums_to followed by m2d_maxpool2_fwd_from / m2d_upsample2_fwd_to. */
-int m2d_bn_apply_pool_to(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
-                         float* y, float* pooled, int B, int C, int L, int act, float slope, long long y_batch_stride,
-                         void* stream);
-int m2d_bn_apply_upsample2_to(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
-                              float* up, int B, int C, int L, int act, float slope, long long up_batch_stride,
-                              void* stream);
+/* Round 6: m2d_bn_fwd_sums_to with the pass that follows it in the U-Net fused in (phase3/archis/default.py:235-245):
+ * MaxPool1d(2, 2) behind a skip's BatchNorm (y AND pooled (B, C, L / 2) are written; L even), Upsample(scale_factor=2, linear)
+ * behind a decoder level's (only the upsampled (B, C, 2L) tensor is written, at up + b * up_batch_stride; C * L even). Same
+ * values, save_* and running buffers as m2d_bn_fwd_sums_to followed by m2d_maxpool2_fwd_from / m2d_upsample2_fwd_to. */
+int m2d_bn_fwd_sums_pool_to(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* y, float* pooled, float* save_mean,
+                            float* save_invstd, int B, int C, int L, float eps, float momentum, int act, float slope,
+                            long long y_batch_stride, void* stream);
+int m2d_bn_fwd_sums_upsample2_to(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float* up, float* save_mean, float* save_invstd,
+                                 int B, int C, int L, float eps, float momentum, int act, float slope,
+                                 long long up_batch_stride, void* stream);
 int m2d_bn_bwd_stats(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                      const float* save_invstd, double* sums, int B, int C, int L, int act, float slope,
                      void* scratch, void* stream);

@@ -45,8 +45,10 @@ SIGNATURES = {
     "m2d_conv1d_fwd_k4": (_I, [_F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _I, _f, _F, _F, _f, _F, _F, _S, _F]),
     "m2d_conv1d_bwd_data_res": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _F, _F, _f, _F, _S, _F]),
     "m2d_bn_update_running": (_I, [_F, _c.c_double, _F, _F, _F, _I, _f, _f, _F]),
-    "m2d_bn_apply_pool_to": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _c.c_longlong, _F]),
-    "m2d_bn_apply_upsample2_to": (_I, [_F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _f, _c.c_longlong, _F]),
+    "m2d_bn_fwd_sums_pool_to": (_I, [_F, _F, _c.c_double, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _f,
+                                    _c.c_longlong, _F]),
+    "m2d_bn_fwd_sums_upsample2_to": (_I, [_F, _F, _c.c_double, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _f, _f, _I, _f,
+                                         _c.c_longlong, _F]),
     "m2d_conv1d_bwd_data_shared_mask": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _I, _F, _S, _F]),
     "m2d_conv1d_bwd_weight_from": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I, _F, _f, _I, _F, _S, _F]),
     "m2d_gemm_ld": (_I, [_I, _F, _I, _F, _I, _F, _F, _I, _I, _I, _I, _I, _f, _F, _f, _F, _f, _F, _S, _F]),

@@ -365,7 +365,46 @@ struct BnApplyArgs {
   int backward, act;
   float slope;
   float* pool_out;        // forward, optional: MaxPool1d(2, 2) of the result as well, dense (B, C, L / 2) (L even)
+  // forward, optional: the finalisation of the batch statistics inside this launch (round 6: one launch less per
+  // BatchNorm). fin_sums != NULL: mean / invstd of a thread's channels are computed from the fp64 sums in its prologue
+  // (the expressions of m2d_bn_finalize_fwd_kernel: same bits), `mean` / `invstd` above are then OUTPUTS (save_mean /
+  // save_invstd) written - with the running-buffer update - by workgroup (0, 0) alone; nobody reads them in this launch.
+  const double* fin_sums;
+  double fin_count;
+  float fin_eps, fin_momentum;
+  float* fin_running_mean;
+  float* fin_running_var;
 };
+
+// mean / invstd of channel c: from the arrays, or from the batch sums (see BnApplyArgs::fin_sums)
+__device__ __forceinline__ void bn_mean_invstd(const BnApplyArgs& a, int c, float& mu, float& is) {
+  if (a.fin_sums) {
+    const double m = a.fin_sums[2 * c] / a.fin_count;
+    double var = a.fin_sums[2 * c + 1] / a.fin_count - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    is = (float)(1.0 / sqrt(var + (double)a.fin_eps));
+  } else {
+    mu = a.mean[c];
+    is = a.invstd[c];
+  }
+}
+// workgroup (0, 0): save_mean / save_invstd and the running buffers (what m2d_bn_finalize_fwd_kernel leaves behind)
+__device__ __forceinline__ void bn_finalize_side(const BnApplyArgs& a) {
+  if (!a.fin_sums || blockIdx.x != 0 || blockIdx.y != 0) return;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    const double m = a.fin_sums[2 * c] / a.fin_count;
+    double var = a.fin_sums[2 * c + 1] / a.fin_count - m * m;
+    if (var < 0.0) var = 0.0;
+    const_cast<float*>(a.mean)[c] = (float)m;
+    const_cast<float*>(a.invstd)[c] = (float)(1.0 / sqrt(var + (double)a.fin_eps));
+    if (a.fin_running_mean) {
+      const double unbiased = a.fin_count > 1.0 ? var * (a.fin_count / (a.fin_count - 1.0)) : var;
+      a.fin_running_mean[c] = (float)((1.0 - a.fin_momentum) * (double)a.fin_running_mean[c] + a.fin_momentum * m);
+      a.fin_running_var[c] = (float)((1.0 - a.fin_momentum) * (double)a.fin_running_var[c] + a.fin_momentum * unbiased);
+    }
+  }
+}
 
 // A thread owns ONE vector position of the (C, L) row and walks the batch: its channel(s) - one when L % 4 == 0, four
 // consecutive ones when L == 1 - and their parameters are fixed for the whole launch (registers), so the loop body is
@@ -375,6 +414,7 @@ template <int VEC>
 __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, int B) {
   const int rvl = a.row_len / VEC;  // vectors per row
   const int tid = threadIdx.x;
+  bn_finalize_side(a);
   int pv, r0, rstep;
   if (rvl >= 256) {
     pv = blockIdx.x * 256 + tid;
@@ -395,7 +435,9 @@ __global__ void __launch_bounds__(256) m2d_bn_apply_kernel(const BnApplyArgs a, 
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     const int c = percol ? e0 + j : e0 / a.L;
-    g[j] = a.gamma[c]; bt[j] = a.beta[c]; mu[j] = a.mean[c]; is[j] = a.invstd[c];
+    g[j] = a.gamma[c]; bt[j] = a.beta[c];
+    if (j == 0 || percol) bn_mean_invstd(a, c, mu[j], is[j]);
+    else { mu[j] = mu[0]; is[j] = is[0]; }
     sdz[j] = a.backward ? a.s_dz[c] : 0.f;
     sdzx[j] = a.backward ? a.s_dzx[c] : 0.f;
   }
@@ -514,6 +556,7 @@ __global__ void __launch_bounds__(256) m2d_bn_upsample2_flat_kernel(const BnAppl
 __global__ void __launch_bounds__(256) m2d_bn_upsample2_rows_kernel(const BnApplyArgs a, int B) {
   const int rvl = a.row_len / 2;  // pairs per row
   const int tid = threadIdx.x;
+  bn_finalize_side(a);
   int pv, r0, rstep;
   if (rvl >= 256) {
     pv = blockIdx.x * 256 + tid;
@@ -530,7 +573,9 @@ __global__ void __launch_bounds__(256) m2d_bn_upsample2_rows_kernel(const BnAppl
   }
   const int e0 = 2 * pv;
   const int c = e0 / a.L, p0 = e0 - c * a.L;
-  const float gg = a.gamma[c], bb = a.beta[c], mm = a.mean[c], ii = a.invstd[c];
+  const float gg = a.gamma[c], bb = a.beta[c];
+  float mm, ii;
+  bn_mean_invstd(a, c, mm, ii);
   const bool has_l = p0 > 0, has_r = p0 + 2 < a.L;
   auto norm = [&](float x) {
     const float xh = (x - mm) * ii;
@@ -611,11 +656,35 @@ static int bn_apply_bwd(const float* dy, const float* x, const float* gamma, con
                         const float* save_invstd, const float* s_dz, const float* s_dzx, float* dx, int B, int C, int L,
                         int act, float slope, hipStream_t stream);
 
+// the finalisation of the batch statistics folded into a normalisation launch (BnApplyArgs::fin_sums)
+struct BnFin {
+  const double* sums;
+  double count;
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+};
+static bool bn_fin_in_apply() {   // A/B lever (0: the separate m2d_bn_finalize_fwd_kernel launch of rounds 1-5)
+  static const bool on = [] { const char* e = getenv("M2D_BN_FIN_IN_APPLY"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static void bn_set_fin(BnApplyArgs& a, const BnFin* fin) {
+  if (!fin) return;
+  a.fin_sums = fin->sums;
+  a.fin_count = fin->count;
+  a.fin_eps = fin->eps;
+  a.fin_momentum = fin->momentum;
+  a.fin_running_mean = fin->running_mean;
+  a.fin_running_var = fin->running_var;
+}
+
 static int bn_apply_fwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
                         float* y, int B, int C, int L, int act, float slope, const float* residual, hipStream_t stream,
-                        long long y_batch_stride = 0) {
+                        long long y_batch_stride = 0, const BnFin* fin = nullptr, float* pool_out = nullptr) {
   BnApplyArgs a;
   memset(&a, 0, sizeof(a));
+  bn_set_fin(a, fin);
+  a.pool_out = pool_out;
   a.out_pitch = y_batch_stride;
   a.x = x;
   a.residual = residual;
@@ -625,7 +694,8 @@ static int bn_apply_fwd(const float* x, const float* gamma, const float* beta, c
   a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
   a.row_len = C * L;
   a.act = act; a.slope = slope;
-  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, (residual ? 3.0 : 2.0) * 4.0 * B * C * (double)L, "bn_apply", B, C, L);
+  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, ((residual ? 3.0 : 2.0) + (pool_out ? 0.5 : 0.0)) * 4.0 * B * C * (double)L,
+                    pool_out ? "bn_apply_pool" : "bn_apply", B, C, L);
   return launch_apply(a, B, stream);
 }
 
@@ -663,6 +733,10 @@ int m2d_bn_fwd_sums_to(const float* x, const double* sums, double count, const f
   hipStream_t stream = (hipStream_t)stream_;
   if (int rc = bn_check("m2d_bn_fwd_sums", B, C, L)) return rc;
   if (!sums || !(count > 0.0)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd_sums: no statistics");
+  if (bn_fin_in_apply()) {   // mean / invstd in every thread's prologue, save_* and the running buffers by workgroup (0, 0)
+    const BnFin fin = {sums, count, eps, momentum, running_mean, running_var};
+    return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, residual, stream, y_batch_stride, &fin);
+  }
   hipLaunchKernelGGL(m2d_bn_finalize_fwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream, sums, save_mean,
                      save_invstd, running_mean, running_var, C, count, eps, momentum);
   M2D_CHECK_LAUNCH("m2d_bn_finalize_fwd_kernel");
@@ -692,57 +766,63 @@ int m2d_bn_fwd_sums(const float* x, const double* sums, double count, const floa
                             momentum, act, slope, residual, 0, stream_);
 }
 
-// The normalisation pass alone, from mean / invstd already finalised (m2d_bn_update_running's tmp, or the save_* of an
-// earlier call), with the pass that follows it in the U-Net fused in (phase3/archis/default.py:235-245 of the reference:
-// MaxPool1d(2, 2) after a skip's BatchNorm, Upsample(x2, linear) after a decoder level's):
-//   m2d_bn_apply_pool_to:      y = act(bn(x)) -> y (batch stride as m2d_bn_fwd_sums_to) AND pooled (B, C, L / 2), L even
-//   m2d_bn_apply_upsample2_to: up = upsample2(act(bn(x))) -> (B, C, 2L) at up + b * up_batch_stride; y itself is not written.
-//                              C * L even.
-int m2d_bn_apply_pool_to(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
-                         float* y, float* pooled, int B, int C, int L, int act, float slope, long long y_batch_stride,
-                         void* stream_) {
+// The training forward from batch sums (m2d_bn_fwd_sums_to) with the pass that follows it in the U-Net fused in
+// (phase3/archis/default.py:235-245 of the reference: MaxPool1d(2, 2) after a skip's BatchNorm, Upsample(x2, linear)
+// after a decoder level's):
+//   m2d_bn_fwd_sums_pool_to:      y = act(bn(x)) -> y (batch stride as m2d_bn_fwd_sums_to) AND pooled (B, C, L / 2), L even
+//   m2d_bn_fwd_sums_upsample2_to: up = upsample2(act(bn(x))) -> (B, C, 2L) at up + b * up_batch_stride; y itself is not
+//                                 written. C * L even.
+// save_mean / save_invstd and the running buffers as m2d_bn_fwd_sums_to.
+int m2d_bn_fwd_sums_pool_to(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* y, float* pooled, float* save_mean,
+                            float* save_invstd, int B, int C, int L, float eps, float momentum, int act, float slope,
+                            long long y_batch_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (int rc = bn_check("m2d_bn_apply_pool_to", B, C, L)) return rc;
-  if (!pooled || (L & 1)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_apply_pool_to: even L and a pooled output");
-  BnApplyArgs a;
-  memset(&a, 0, sizeof(a));
-  a.out_pitch = y_batch_stride;
-  a.x = x;
-  a.gamma = gamma; a.beta = beta;
-  a.mean = mean; a.invstd = invstd;
-  a.out = y;
-  a.pool_out = pooled;
-  a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
-  a.row_len = C * L;
-  a.act = act; a.slope = slope;
-  M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 2.5 * 4.0 * B * C * (double)L, "bn_apply_pool", B, C, L);
-  return launch_apply(a, B, stream);
+  if (int rc = bn_check("m2d_bn_fwd_sums_pool_to", B, C, L)) return rc;
+  if (!sums || !(count > 0.0)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd_sums_pool_to: no statistics");
+  if (!pooled || (L & 1)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd_sums_pool_to: even L and a pooled output");
+  const BnFin fin = {sums, count, eps, momentum, running_mean, running_var};
+  if (!bn_fin_in_apply()) {
+    hipLaunchKernelGGL(m2d_bn_finalize_fwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream, sums, save_mean,
+                       save_invstd, running_mean, running_var, C, count, eps, momentum);
+    M2D_CHECK_LAUNCH("m2d_bn_finalize_fwd_kernel");
+  }
+  return bn_apply_fwd(x, gamma, beta, save_mean, save_invstd, y, B, C, L, act, slope, nullptr, stream, y_batch_stride,
+                      bn_fin_in_apply() ? &fin : nullptr, pooled);
 }
 
-int m2d_bn_apply_upsample2_to(const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
-                              float* up, int B, int C, int L, int act, float slope, long long up_batch_stride,
-                              void* stream_) {
+int m2d_bn_fwd_sums_upsample2_to(const float* x, const double* sums, double count, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float* up, float* save_mean, float* save_invstd,
+                                 int B, int C, int L, float eps, float momentum, int act, float slope,
+                                 long long up_batch_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (int rc = bn_check("m2d_bn_apply_upsample2_to", B, C, L)) return rc;
+  if (int rc = bn_check("m2d_bn_fwd_sums_upsample2_to", B, C, L)) return rc;
+  if (!sums || !(count > 0.0)) M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd_sums_upsample2_to: no statistics");
   const long long per = (long long)C * L;
   if (up_batch_stride <= 0) up_batch_stride = 2 * per;
   if ((per & 1) || up_batch_stride < 2 * per || (up_batch_stride & 3) || (((uintptr_t)x | (uintptr_t)up) & 15u))
-    M2D_FAIL(M2D_ERR_ARG, "m2d_bn_apply_upsample2_to: C * L even, 16-byte aligned samples");
+    M2D_FAIL(M2D_ERR_ARG, "m2d_bn_fwd_sums_upsample2_to: C * L even, 16-byte aligned samples");
+  const bool rows = (L & 1) == 0;
+  const bool fused_fin = rows && bn_fin_in_apply();   // (the flat form reads the parameters per pair: it keeps the arrays)
+  if (!fused_fin) {
+    hipLaunchKernelGGL(m2d_bn_finalize_fwd_kernel, dim3(m2d_ceil_div(C, 256)), dim3(256), 0, stream, sums, save_mean,
+                       save_invstd, running_mean, running_var, C, count, eps, momentum);
+    M2D_CHECK_LAUNCH("m2d_bn_finalize_fwd_kernel");
+  }
   BnApplyArgs a;
   memset(&a, 0, sizeof(a));
+  const BnFin fin = {sums, count, eps, momentum, running_mean, running_var};
+  if (fused_fin) bn_set_fin(a, &fin);
   a.out_pitch = up_batch_stride;
   a.x = x;
   a.gamma = gamma; a.beta = beta;
-  a.mean = mean; a.invstd = invstd;
+  a.mean = save_mean; a.invstd = save_invstd;
   a.out = up;
   a.C = C; a.L = L; a.L_inv = 1.f / (float)L;
   a.row_len = C * L;
   a.act = act; a.slope = slope;
-  const size_t pairs = (size_t)B * (size_t)(per / 2);
-  size_t blocks = (pairs + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
   M2dProfScope prof(M2D_FAM_BN, stream, 0.0, 3.0 * 4.0 * B * C * (double)L, "bn_apply_upsample2", B, C, L);
-  if ((L & 1) == 0) {
+  if (rows) {
     const int rvl = a.row_len / 2;
     unsigned gx, gy;
     if (rvl >= 256) {
@@ -759,6 +839,9 @@ int m2d_bn_apply_upsample2_to(const float* x, const float* gamma, const float* b
     M2D_CHECK_LAUNCH("m2d_bn_upsample2_rows_kernel");
     return M2D_OK;
   }
+  const size_t pairs = (size_t)B * (size_t)(per / 2);
+  size_t blocks = (pairs + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(m2d_bn_upsample2_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, (unsigned)(per / 2), pairs);
   M2D_CHECK_LAUNCH("m2d_bn_upsample2_flat_kernel");
   return M2D_OK;

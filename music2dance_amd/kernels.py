@@ -779,48 +779,47 @@ class HipKernels:
                                                   _ptr(tmp), C, eps, momentum, _stream(dev))
         _lib.check(rc, "m2d_bn_update_running")
 
-    def bn_finalize(self, sums, count, running_mean, running_var, eps, momentum):
-        """Batch sums -> (mean, invstd) (C,) each, running buffers advanced: the finalisation of bn_fwd_sums as a call of
-        its own (m2d_bn_update_running's tmp), for the fused normalisation passes below."""
-        dev = _chk(running_mean, running_var)
-        C = running_mean.numel()
-        self._sums_ok(sums, C, dev)
-        tmp = torch.empty((2 * C,), dtype=torch.float32, device=dev)
-        with _on(dev):
-            rc = _lib.lib().m2d_bn_update_running(_ptr(sums), float(count), _ptr(running_mean), _ptr(running_var),
-                                                  _ptr(tmp), C, eps, momentum, _stream(dev))
-        _lib.check(rc, "m2d_bn_update_running")
-        return tmp[:C], tmp[C:]
-
-    def bn_apply_pool(self, x, gamma, beta, mean, invstd, act=0, slope=0.0, out=None):
-        """y = act(bn(x)) from finalised mean / invstd AND MaxPool1d(2, 2) of it in the same pass. -> (y, pooled);
+    def bn_fwd_sums_pool(self, x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act=0, slope=0.0,
+                         out=None):
+        """bn_fwd_sums with MaxPool1d(2, 2) of the result made in the same pass. -> (y, pooled, save_mean, save_invstd);
         out: where y goes (a channel block of a wider buffer, as bn_fwd_sums)."""
-        dev = _chk(x, gamma, beta, mean, invstd)
+        dev = _chk(x, gamma, beta, running_mean, running_var)
         B, C, L = x.shape
+        self._sums_ok(sums, C, dev)
         y, ypitch = self._out_block(out, x)
         pooled = torch.empty((B, C, L // 2), dtype=torch.float32, device=dev)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
         with _on(dev):
-            rc = _lib.lib().m2d_bn_apply_pool_to(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(y),
-                                                 _ptr(pooled), B, C, L, act, slope, ypitch, _stream(dev))
-        _lib.check(rc, "m2d_bn_apply_pool_to")
-        return y, pooled
+            rc = _lib.lib().m2d_bn_fwd_sums_pool_to(_ptr(x), _ptr(sums), float(count), _ptr(gamma), _ptr(beta),
+                                                    _ptr(running_mean), _ptr(running_var), _ptr(y), _ptr(pooled),
+                                                    _ptr(save_mean), _ptr(save_invstd), B, C, L, eps, momentum, act, slope,
+                                                    ypitch, _stream(dev))
+        _lib.check(rc, "m2d_bn_fwd_sums_pool_to")
+        return y, pooled, save_mean, save_invstd
 
-    def bn_apply_upsample2(self, x, gamma, beta, mean, invstd, act=0, slope=0.0, out=None):
-        """upsample2_linear(act(bn(x))) in one pass (the normalised tensor itself is not written). -> (B, C, 2L);
-        out: a (B, C, 2L) channel block of a wider buffer."""
-        dev = _chk(x, gamma, beta, mean, invstd)
+    def bn_fwd_sums_upsample2(self, x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act=0, slope=0.0,
+                              out=None):
+        """upsample2_linear(bn_fwd_sums(x)) in one pass (the normalised tensor itself is not written).
+        -> (up (B, C, 2L), save_mean, save_invstd); out: a (B, C, 2L) channel block of a wider buffer."""
+        dev = _chk(x, gamma, beta, running_mean, running_var)
         B, C, L = x.shape
+        self._sums_ok(sums, C, dev)
         if out is None:
             up, pitch = torch.empty((B, C, 2 * L), dtype=torch.float32, device=dev), 0
         else:
             assert out.shape == (B, C, 2 * L) and out.dtype == torch.float32 and out.device == x.device
             assert out.stride(2) == 1 and out.stride(1) == 2 * L and out.stride(0) >= 2 * C * L
             up, pitch = out, out.stride(0)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
         with _on(dev):
-            rc = _lib.lib().m2d_bn_apply_upsample2_to(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(up),
-                                                      B, C, L, act, slope, pitch, _stream(dev))
-        _lib.check(rc, "m2d_bn_apply_upsample2_to")
-        return up
+            rc = _lib.lib().m2d_bn_fwd_sums_upsample2_to(_ptr(x), _ptr(sums), float(count), _ptr(gamma), _ptr(beta),
+                                                         _ptr(running_mean), _ptr(running_var), _ptr(up), _ptr(save_mean),
+                                                         _ptr(save_invstd), B, C, L, eps, momentum, act, slope, pitch,
+                                                         _stream(dev))
+        _lib.check(rc, "m2d_bn_fwd_sums_upsample2_to")
+        return up, save_mean, save_invstd
 
     def bn_bwd_stats(self, dy, x, gamma, beta, save_mean, save_invstd, act=0, slope=0.0):
         """(2C,) float64: sum dz and sum dz * xhat, dz = dy * act'(bn(x))."""

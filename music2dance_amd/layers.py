@@ -126,7 +126,7 @@ class BatchNorm1d(nn.BatchNorm1d):
     @torch.no_grad()
     def forward_then(self, x, sums, then, act=ops.ACT_NONE, slope=0.0, out=None, then_out=None):
         """No autograd graph, training mode, batch statistics handed over as `sums`: the normalisation with the pass
-        that follows it fused in (kernels.bn_apply_pool / bn_apply_upsample2; the U-Net, phase3/archis/default.py).
+        that follows it fused in (kernels.bn_fwd_sums_pool / bn_fwd_sums_upsample2; the U-Net, phase3/archis/default.py).
         then = "pool":      -> (y, max_pool(y)); y into `out` (ops.batch_norm's)
         then = "upsample":  -> upsample2_linear(y) into `then_out`; y itself is not produced.
         Same values, same running-buffer update as forward() followed by the separate pass."""
@@ -139,11 +139,12 @@ class BatchNorm1d(nn.BatchNorm1d):
         k = kernels.impl()
         x = x.contiguous()
         count = float(x.numel() // x.shape[1])
-        mean, invstd = k.bn_finalize(sums, count, self.running_mean, self.running_var, float(self.eps), float(self.momentum))
+        args = (x, sums, count, self.weight, self.bias, self.running_mean, self.running_var, float(self.eps),
+                float(self.momentum), int(act), float(slope))
         if then == "pool":
-            return k.bn_apply_pool(x, self.weight, self.bias, mean, invstd, int(act), float(slope), out=out)
+            return k.bn_fwd_sums_pool(*args, out=out)[:2]
         assert then == "upsample"
-        return k.bn_apply_upsample2(x, self.weight, self.bias, mean, invstd, int(act), float(slope), out=then_out)
+        return k.bn_fwd_sums_upsample2(*args, out=then_out)[0]
 
     @torch.no_grad()
     def observe(self, x):

@@ -203,22 +203,16 @@ class FakeKernels:
         running_mean.mul_(1 - momentum).add_(momentum * mean64.float())
         running_var.mul_(1 - momentum).add_(momentum * var64.float() * (count / (count - 1) if count > 1 else 1.0))
 
-    def bn_finalize(self, sums, count, running_mean, running_var, eps, momentum):
-        mean64 = sums[0::2] / count
-        var64 = (sums[1::2] / count - mean64 * mean64).clamp_min(0.0)
-        self.bn_update_running(sums, count, running_mean, running_var, eps, momentum)
-        return mean64.float(), (1.0 / torch.sqrt(var64 + eps)).float()
+    def bn_fwd_sums_pool(self, x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act=0, slope=0.0,
+                         out=None):
+        y, mean, invstd = self.bn_fwd_sums(x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act, slope,
+                                           None, out)
+        return y, F.max_pool1d(y, 2, 2), mean, invstd
 
-    def bn_apply_pool(self, x, gamma, beta, mean, invstd, act=0, slope=0.0, out=None):
-        shape = (1, -1, 1)
-        y = _act((x - mean.view(shape)) * invstd.view(shape) * gamma.view(shape) + beta.view(shape), act, slope)
-        y = self._into(out, y)
-        return y, F.max_pool1d(y, 2, 2)
-
-    def bn_apply_upsample2(self, x, gamma, beta, mean, invstd, act=0, slope=0.0, out=None):
-        shape = (1, -1, 1)
-        y = _act((x - mean.view(shape)) * invstd.view(shape) * gamma.view(shape) + beta.view(shape), act, slope)
-        return self._into(out, F.interpolate(y, scale_factor=2, mode="linear", align_corners=False))
+    def bn_fwd_sums_upsample2(self, x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act=0, slope=0.0,
+                              out=None):
+        y, mean, invstd = self.bn_fwd_sums(x, sums, count, gamma, beta, running_mean, running_var, eps, momentum, act, slope)
+        return self._into(out, F.interpolate(y, scale_factor=2, mode="linear", align_corners=False)), mean, invstd
 
     def _bn_dz(self, dy, x, gamma, beta, save_mean, save_invstd, act, slope):
         shape = (1, -1) if x.dim() == 2 else (1, -1, 1)

@@ -982,28 +982,34 @@ def test_phase_major_sub_pixel_backward_data(cin, cout, L, B):
 
 @pytest.mark.parametrize("shape", [(9, 16, 200), (5, 8, 50), (4, 6, 25), (7, 6, 3), (3, 5, 10), (40, 128, 100)], ids=str)
 def test_batchnorm_pass_with_the_following_pool_or_upsampling_fused_in(shape):
-    """kernels.bn_apply_pool / bn_apply_upsample2 (the U-Net without an autograd graph, csrc/bn.hip round 6): the same bits
-    as the normalisation pass followed by the separate max-pool / upsampling kernels, into dense outputs and into channel
-    blocks of a wider buffer; bn_finalize = the finalisation of bn_fwd_sums (mean, invstd, running buffers)."""
+    """kernels.bn_fwd_sums_pool / bn_fwd_sums_upsample2 (the U-Net without an autograd graph, csrc/bn.hip round 6): the same
+    bits as bn_fwd_sums followed by the separate max-pool / upsampling kernels - outputs, save_mean / save_invstd and the
+    running buffers (the finalisation of the statistics runs inside the normalisation launch) - into dense outputs and into
+    channel blocks of a wider buffer."""
     B, C, L = shape
     k = K()
     x = gen(B, C, L, seed=1).to(DEV)
     g, b = gen(C, seed=2).abs().add(0.5).to(DEV), gen(C, seed=3, scale=0.3).to(DEV)
     x64 = x.double()
     sums = torch.stack((x64.sum((0, 2)), (x64 * x64).sum((0, 2))), 1).reshape(-1)
-    rm1, rv1 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-    rm2, rv2 = rm1.clone(), rv1.clone()
+
+    def buffers():
+        return torch.full((C,), 0.25, device=DEV), torch.full((C,), 1.5, device=DEV)
+    rm1, rv1 = buffers()
     y_ref, m_ref, i_ref = k.bn_fwd_sums(x, sums, float(B * L), g, b, rm1, rv1, 1e-5, 0.1, act=2, slope=0.2)
-    mean, inv = k.bn_finalize(sums, float(B * L), rm2, rv2, 1e-5, 0.1)
-    assert torch.equal(mean, m_ref) and torch.equal(inv, i_ref) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
     if (C * L) % 2 == 0:
         up_ref = k.upsample2_fwd(y_ref)
-        assert torch.equal(k.bn_apply_upsample2(x, g, b, mean, inv, act=2, slope=0.2), up_ref)
-        wide = torch.full((B, 2 * C, 2 * L), 7.0, device=DEV)
+        rm2, rv2 = buffers()
+        up, m2, i2 = k.bn_fwd_sums_upsample2(x, sums, float(B * L), g, b, rm2, rv2, 1e-5, 0.1, act=2, slope=0.2)
+        assert torch.equal(up, up_ref) and torch.equal(m2, m_ref) and torch.equal(i2, i_ref)
+        assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
         if (2 * C * 2 * L) % 4 == 0:
-            k.bn_apply_upsample2(x, g, b, mean, inv, act=2, slope=0.2, out=wide[:, :C])
+            wide = torch.full((B, 2 * C, 2 * L), 7.0, device=DEV)
+            k.bn_fwd_sums_upsample2(x, sums, float(B * L), g, b, *buffers(), 1e-5, 0.1, act=2, slope=0.2, out=wide[:, :C])
             assert torch.equal(wide[:, :C], up_ref) and bool((wide[:, C:] == 7.0).all())
     if L % 2 == 0:
         wide = torch.full((B, 2 * C, L), 7.0, device=DEV)
-        y, p = k.bn_apply_pool(x, g, b, mean, inv, act=2, slope=0.2, out=wide[:, C:])
+        rm3, rv3 = buffers()
+        y, p, m3, i3 = k.bn_fwd_sums_pool(x, sums, float(B * L), g, b, rm3, rv3, 1e-5, 0.1, act=2, slope=0.2, out=wide[:, C:])
         assert torch.equal(y, y_ref) and torch.equal(p, k.maxpool2_fwd(y_ref)) and bool((wide[:, :C] == 7.0).all())
+        assert torch.equal(m3, m_ref) and torch.equal(i3, i_ref) and torch.equal(rm1, rm3) and torch.equal(rv1, rv3)
